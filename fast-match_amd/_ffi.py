@@ -1,0 +1,257 @@
+"""ctypes binding of libfastmatch_hip.so (C-ABI: include/fastmatch_hip.h).
+
+This is the only bridge between the Python surface (fastmatch / cache / matchutil) and
+the HIP kernels.  There is no CPU fallback: if the library is missing, or no gfx950
+device is present, every compute entry point raises ``FastMatchHipError``.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastmatch_hip.so")
+
+FM_BANK_I8 = 1
+FM_BANK_F32 = 2
+
+
+class FastMatchHipError(RuntimeError):
+    """Raised for every failure of the HIP path (the analogue of cv2.error)."""
+
+
+class fm_stats(ctypes.Structure):
+    _fields_ = [("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+                ("kernel_launches", ctypes.c_int64), ("pairs", ctypes.c_int64),
+                ("calls", ctypes.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/fastmatch_hip.h declares
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_INT = ctypes.c_int
+SYMBOLS = {
+    "fm_ctx_create": (_INT, [_INT, ctypes.POINTER(_P)]),
+    "fm_ctx_destroy": (_INT, [_P]),
+    "fm_last_error": (ctypes.c_char_p, [_P]),
+    "fm_sync": (_INT, [_P]),
+    "fm_get_stats": (_INT, [_P, ctypes.POINTER(fm_stats)]),
+    "fm_reset_stats": (_INT, [_P]),
+    "fm_device_name": (_INT, [_P, ctypes.c_char_p, _INT]),
+    "fm_bank_create_u8": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
+    "fm_bank_create_f32": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
+    "fm_bank_destroy": (_INT, [_P, _P]),
+    "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
+    "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
+    "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
+    "fm_self_dist": (_INT, [_P, _P, _P]),
+    "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
+    "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libfastmatch_hip.so and declare every prototype.  Raises if missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise FastMatchHipError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise FastMatchHipError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)     # AttributeError here = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Bank(object):
+    """Device-resident descriptor bank (fm_bank)."""
+
+    def __init__(self, ctx, handle, n, dim, kind):
+        self.ctx, self.handle, self.n, self.dim, self.kind = ctx, handle, n, dim, kind
+        self.has_selfdist = False
+
+    def set_selfdist(self, selfdist):
+        sd = np.ascontiguousarray(selfdist, dtype=np.float64)
+        if sd.shape != (self.n,):
+            raise ValueError("selfdist must have shape (%d,)" % self.n)
+        self.ctx._check(self.ctx.lib.fm_bank_set_selfdist(self.ctx.handle, self.handle, _ptr(sd)))
+        self.has_selfdist = True
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.ctx.lib.fm_bank_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One fm_ctx (= one device + one HIP stream)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = None
+        h = _P()
+        rc = self.lib.fm_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            msg = self.lib.fm_last_error(None)
+            raise FastMatchHipError("fm_ctx_create(%d) failed (%d): %s"
+                                    % (device, rc, msg.decode() if msg else "?"))
+        self.handle = h
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.fm_last_error(self.handle)
+            raise FastMatchHipError("libfastmatch_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.fm_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- banks -------------------------------------------------------------------------
+    def bank(self, rows):
+        """Upload an [n, dim] uint8 or float32 matrix.  Other dtypes are converted to
+        float32 first (cv2 would reject them)."""
+        a = np.asarray(rows)
+        if a.ndim != 2:
+            raise ValueError("descriptor bank must be 2-D [n, dim]")
+        h = _P()
+        if a.dtype == np.uint8:
+            a = np.ascontiguousarray(a)
+            self._check(self.lib.fm_bank_create_u8(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._check(self.lib.fm_bank_create_f32(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
+        n, dim, kind = _I64(), _INT(), _INT()
+        self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
+        return Bank(self, h, n.value, dim.value, kind.value)
+
+    # -- operators -----------------------------------------------------------------------
+    def knn2(self, q, t):
+        idx = np.empty((q.n, 2), dtype=np.int32)
+        dist = np.empty((q.n, 2), dtype=np.float32)
+        self._check(self.lib.fm_knn2(self.handle, q.handle, t.handle, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def self_dist(self, bank):
+        out = np.empty(bank.n, dtype=np.float64)
+        self._check(self.lib.fm_self_dist(self.handle, bank.handle, _ptr(out)))
+        return out
+
+    def xcheck1(self, q, t):
+        tidx = np.empty(q.n, dtype=np.int32)
+        dist = np.empty(q.n, dtype=np.float32)
+        self._check(self.lib.fm_xcheck1(self.handle, q.handle, t.handle, _ptr(tidx), _ptr(dist)))
+        return tidx, dist
+
+    def match_ratio(self, q, t, tau):
+        tidx = np.empty(q.n, dtype=np.int32)
+        dist = np.empty(q.n, dtype=np.float32)
+        ratio = np.empty(q.n, dtype=np.float64)
+        passed = np.empty(q.n, dtype=np.uint8)
+        npass = _I64(0)
+        self._check(self.lib.fm_match_ratio(self.handle, q.handle, t.handle, float(tau), _ptr(tidx),
+                                            _ptr(dist), _ptr(ratio), _ptr(passed), ctypes.byref(npass)))
+        return tidx, dist, ratio, passed.astype(bool), npass.value
+
+    def ratio_filter(self, dist, selfdist, tau, qrows=None):
+        dist = np.ascontiguousarray(dist, dtype=np.float32)
+        selfdist = np.ascontiguousarray(selfdist, dtype=np.float64)
+        n = dist.shape[0]
+        if qrows is not None:
+            qrows = np.ascontiguousarray(qrows, dtype=np.int32)
+            if qrows.shape[0] != n:
+                raise ValueError("qrows and dist must have the same length")
+            if n and int(qrows.max()) >= selfdist.shape[0]:
+                raise ValueError("qrows index beyond selfdist")
+        elif selfdist.shape[0] < n:
+            raise ValueError("selfdist shorter than dist")
+        ratio = np.empty(n, dtype=np.float64)
+        passed = np.empty(n, dtype=np.uint8)
+        npass = _I64(0)
+        self._check(self.lib.fm_ratio_filter(self.handle, _ptr(dist), _ptr(selfdist), _ptr(qrows), n,
+                                             float(tau), _ptr(ratio), _ptr(passed), ctypes.byref(npass)))
+        return ratio, passed.astype(bool), npass.value
+
+    def xcheck1_batched(self, q, q_rows, q_off, t, t_off):
+        q_rows = np.ascontiguousarray(q_rows, dtype=np.int32)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.int64)
+        if q_off.shape != t_off.shape or q_off.ndim != 1 or q_off.shape[0] < 1:
+            raise ValueError("q_off and t_off must both be [B+1]")
+        nb = q_off.shape[0] - 1
+        tot = int(q_off[-1])
+        if q_rows.shape[0] != tot:
+            raise ValueError("q_rows length must equal q_off[-1]")
+        tidx = np.empty(tot, dtype=np.int32)
+        dist = np.empty(tot, dtype=np.float32)
+        ratio = np.empty(tot, dtype=np.float64)
+        self._check(self.lib.fm_xcheck1_batched(self.handle, q.handle, _ptr(q_rows), _ptr(q_off), t.handle,
+                                                _ptr(t_off), nb, _ptr(tidx), _ptr(dist), _ptr(ratio)))
+        return tidx, dist, ratio
+
+    # -- bookkeeping ---------------------------------------------------------------------
+    def stats(self):
+        s = fm_stats()
+        self._check(self.lib.fm_get_stats(self.handle, ctypes.byref(s)))
+        return {"kernel_ms": s.kernel_ms, "total_ms": s.total_ms, "kernel_launches": s.kernel_launches,
+                "pairs": s.pairs, "calls": s.calls}
+
+    def reset_stats(self):
+        self._check(self.lib.fm_reset_stats(self.handle))
+
+    def sync(self):
+        self._check(self.lib.fm_sync(self.handle))
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self.lib.fm_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device=None):
+    """Process-wide context per device.  ``device=None`` uses LOCAL_RANK (one process per
+    GPU under torch.distributed.run) or 0."""
+    if device is None:
+        device = int(os.environ.get("FM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _default_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None or ctx.handle is None:
+            ctx = Context(device)
+            _default_ctx[device] = ctx
+        return ctx

@@ -1,0 +1,692 @@
+// C-ABI of libfastmatch_hip.so (include/fastmatch_hip.h) and the small kernels around K1:
+//   K6  bank upload: bytes XOR 0x80, row norms, accumulator-order aux words
+//   K2  cross-check finaliser: reverse-NN partials -> packed (d2,idx) 64-bit scatter-min
+//   K3  float64 ratio + threshold
+//   top-2 merge of the split partials for knnMatch(k=2)
+// Reference call sites are cited in the header next to each entry point.
+#include "fm_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+using namespace fm;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+static std::mutex g_err_mu;
+static std::string g_err;   // last context-less error
+
+struct fm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    std::string err;
+    std::string devname;
+    // growable device workspaces
+    void*  ws_partial = nullptr; size_t ws_partial_bytes = 0;
+    void*  ws_out = nullptr;     size_t ws_out_bytes = 0;
+    void*  ws_in = nullptr;      size_t ws_in_bytes = 0;
+    // configuration (env overridable, for experiments)
+    int force_nb = 0, force_nsplit = 0;
+    bool use_glds = true;
+    fm_stats stats{};
+    bool kernel_timed = false;
+    int64_t pending_pairs = 0;
+};
+
+static int fail(fm_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    else { std::lock_guard<std::mutex> lk(g_err_mu); g_err = msg; }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            char _b[512];                                                                   \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                   \
+            (void)hipGetLastError();                                                        \
+            return fail(ctx, _e == hipErrorOutOfMemory ? FM_ENOMEM : FM_EDEVICE, _b);       \
+        }                                                                                   \
+    } while (0)
+
+static int ws_ensure(fm_ctx* ctx, void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap && *p) return FM_OK;
+    if (*p) { HIP_TRY(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t sz = need + need / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(p, sz));
+    *cap = sz;
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K6: bank preparation
+// ---------------------------------------------------------------------------------------
+// One 256-thread block per 32-row tile; thread (r = tid>>3, c = tid&7) owns the 16 bytes
+// [16c, 16c+16) of tile row r.  SRC_F32: source rows are float32; values are converted to
+// uint8 and *nonint is raised if any value is not an integer in [0,255].
+template <bool SRC_F32>
+__global__ __launch_bounds__(256)
+void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
+                      int8_t* __restrict__ rows8, int32_t* __restrict__ norm,
+                      int32_t* __restrict__ aux, int* __restrict__ nonint)
+{
+    const int tid = threadIdx.x;
+    const int r = tid >> 3, c = tid & 7;
+    const int64_t tile = blockIdx.x;
+    const int64_t row = tile * kTileRows + r;
+    unsigned w[4] = {0, 0, 0, 0};
+    int sumsq = 0;
+    bool bad = false;
+    if (row < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = 16 * c + 4 * q + b;
+                int u = 128;                         // padding beyond dim: 0 after the shift
+                if (k < dim) {
+                    if constexpr (SRC_F32) {
+                        const float f = ((const float*)src)[row * dim + k];
+                        const float fr = rintf(f);
+                        if (!(f == fr) || f < 0.f || f > 255.f) { bad = true; u = 128; }
+                        else u = (int)fr;
+                    } else {
+                        u = ((const uint8_t*)src)[row * dim + k];
+                    }
+                }
+                const int s = u - 128;               // == (int8)(u ^ 0x80)
+                sumsq += s * s;
+                word |= (unsigned)(s & 0xff) << (8 * b);
+            }
+            w[q] = word;
+        }
+    }
+    *(uint4*)(rows8 + row * kDim + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+    sumsq += __shfl_xor(sumsq, 1);
+    sumsq += __shfl_xor(sumsq, 2);
+    sumsq += __shfl_xor(sumsq, 4);
+    if (c == 0) {
+        const int hh = (r >> 2) & 1;
+        const int reg = (r & 3) + 4 * (r >> 3);
+        int32_t* a = aux + tile * kAuxPerTile;
+        if (row < n) {
+            norm[row] = sumsq;
+            a[16 * hh + reg]      = -(sumsq >> 1);
+            a[32 + 16 * hh + reg] = 1 - (sumsq & 1);
+        } else {
+            norm[row] = 0;
+            a[16 * hh + reg]      = kPadCinit;
+            a[32 + 16 * hh + reg] = 0;
+        }
+    }
+    if constexpr (SRC_F32) {
+        if (bad) atomicOr(nonint, 1);
+    }
+}
+
+// float32 bank for the general (non-integer) route: zero-padded copy [n_pad][128].
+__global__ void bank_copy_f32_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                     float* __restrict__ dst, int64_t n_pad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad * kDim) return;
+    const int64_t row = i / kDim;
+    const int k = (int)(i % kDim);
+    dst[i] = (row < n && k < dim) ? src[row * dim + k] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// merge / finalise kernels
+// ---------------------------------------------------------------------------------------
+// knnMatch(k=2): merge nsplit partial top-2 lists per query row (keys are (d2<<32)|idx,
+// ascending = cv::batchDistance order) and emit idx / sqrtf(d2).
+__global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial, int nsplit,
+                                  int ncols_alloc, int64_t n, int32_t* __restrict__ idx,
+                                  float* __restrict__ dist)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long b0 = ~0ull, b1 = ~0ull;
+    for (int s = 0; s < nsplit; ++s) {
+        const unsigned long long* p = partial + ((size_t)s * ncols_alloc + i) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long v = p[k];
+            if (v < b0) { b1 = b0; b0 = v; }
+            else if (v < b1) { b1 = v; }
+        }
+    }
+    idx[2 * i]     = (b0 == ~0ull) ? -1 : (int32_t)(unsigned)b0;
+    idx[2 * i + 1] = (b1 == ~0ull) ? -1 : (int32_t)(unsigned)b1;
+    dist[2 * i]     = (b0 == ~0ull) ? INFINITY : sqrtf((float)(unsigned)(b0 >> 32));
+    dist[2 * i + 1] = (b1 == ~0ull) ? INFINITY : sqrtf((float)(unsigned)(b1 >> 32));
+}
+
+// Cross-check step 2: train row t elects rq = argmin_q d(q,t)
+// (lowest q on ties) = min over the split partials; then scatter-min of (d2<<32 | t)
+// into qbest[rq]: q keeps the closest electing train row, lowest t on ties.  64-bit
+// atomicMin is order independent, so the result is deterministic.
+__global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ partial, int nsplit,
+                                      int ncols_alloc, int64_t nt,
+                                      unsigned long long* __restrict__ qbest)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    unsigned long long b = ~0ull;
+    for (int s = 0; s < nsplit; ++s) {
+        const unsigned long long v = partial[(size_t)s * ncols_alloc + t];
+        b = v < b ? v : b;
+    }
+    if (b == ~0ull) return;
+    const unsigned q = (unsigned)b;
+    const unsigned long long key = (b & 0xffffffff00000000ull) | (unsigned long long)(unsigned)t;
+    atomicMin(&qbest[q], key);
+}
+
+// Cross-check step 3 + optional R1: decode qbest, distance = sqrtf(d2) (float32, exact
+// for integer d2 < 2^24), ratio = (double)dist / selfdist[q] in float64, pass = ratio < tau
+// (fastmatch.pyx:124,165; :50,75,82).
+__global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qbest, int64_t nq,
+                                       const double* __restrict__ selfdist, double tau,
+                                       int32_t* __restrict__ tidx, float* __restrict__ dist,
+                                       double* __restrict__ ratio, uint8_t* __restrict__ pass,
+                                       unsigned long long* __restrict__ npass)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool p = false;
+    if (q < nq) {
+        const unsigned long long key = qbest[q];
+        int32_t ti = -1;
+        float d = INFINITY;
+        double r = NAN;
+        if (key != ~0ull) {
+            ti = (int32_t)(unsigned)key;
+            d = sqrtf((float)(unsigned)(key >> 32));
+            if (selfdist) { r = (double)d / selfdist[q]; p = r < tau; }
+        }
+        tidx[q] = ti;
+        dist[q] = d;
+        if (ratio) ratio[q] = r;
+        if (pass) pass[q] = p ? 1 : 0;
+    }
+    if (npass) {
+        const unsigned long long m = __ballot(p);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(npass, (unsigned long long)__popcll(m));
+    }
+}
+
+__global__ void ratio_filter_kernel(const float* __restrict__ dist, const double* __restrict__ selfdist,
+                                    const int32_t* __restrict__ qrows, int64_t n, double tau,
+                                    double* __restrict__ ratio, uint8_t* __restrict__ pass,
+                                    unsigned long long* __restrict__ npass)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool p = false;
+    if (i < n) {
+        const int64_t q = qrows ? qrows[i] : i;
+        const double r = (double)dist[i] / selfdist[q];
+        p = r < tau;
+        if (ratio) ratio[i] = r;
+        if (pass) pass[i] = p ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(p);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(npass, (unsigned long long)__popcll(m));
+}
+
+__global__ void selfdist_from_knn_kernel(const float* __restrict__ dist2, int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)dist2[2 * i + 1];
+}
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" const char* fm_last_error(const fm_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
+{
+    if (!out) return fail(nullptr, FM_EINVAL, "fm_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, FM_EDEVICE,
+                    std::string("fm_ctx_create: no HIP device available (") +
+                    (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                    "); libfastmatch_hip has no CPU fallback");
+    }
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, FM_EINVAL, "fm_ctx_create: bad device id");
+    fm_ctx* ctx = new (std::nothrow) fm_ctx();
+    if (!ctx) return fail(nullptr, FM_ENOMEM, "fm_ctx_create: out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, FM_EDEVICE, std::string("fm_ctx_create: ") + hipGetErrorString(e));
+    }
+    ctx->devname = std::string(prop.gcnArchName) + " " + prop.name;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string m = "fm_ctx_create: device is " + ctx->devname + "; this library is built for gfx950 only";
+        delete ctx;
+        return fail(nullptr, FM_EUNSUPPORTED, m);
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_call0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_call1)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_k0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, FM_EDEVICE, std::string("fm_ctx_create: ") + hipGetErrorString(e));
+    }
+    if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
+    if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
+    if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
+    *out = ctx;
+    return FM_OK;
+}
+
+extern "C" int fm_ctx_destroy(fm_ctx* ctx)
+{
+    if (!ctx) return FM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws_partial) (void)hipFree(ctx->ws_partial);
+    if (ctx->ws_out) (void)hipFree(ctx->ws_out);
+    if (ctx->ws_in) (void)hipFree(ctx->ws_in);
+    if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
+    if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
+    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FM_OK;
+}
+
+extern "C" int fm_sync(fm_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_sync: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FM_OK;
+}
+
+extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)
+{
+    if (!ctx || !out) return fail(ctx, FM_EINVAL, "fm_get_stats: NULL argument");
+    *out = ctx->stats;
+    return FM_OK;
+}
+
+extern "C" int fm_reset_stats(fm_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_reset_stats: ctx is NULL");
+    ctx->stats = fm_stats{};
+    return FM_OK;
+}
+
+extern "C" int fm_device_name(fm_ctx* ctx, char* buf, int buflen)
+{
+    if (!ctx || !buf || buflen <= 0) return fail(ctx, FM_EINVAL, "fm_device_name: bad argument");
+    snprintf(buf, (size_t)buflen, "%s", ctx->devname.c_str());
+    return FM_OK;
+}
+
+// Brackets one API call: events for total time, stats accounting after the final sync.
+struct CallScope {
+    fm_ctx* ctx;
+    explicit CallScope(fm_ctx* c) : ctx(c)
+    {
+        ctx->kernel_timed = false;
+        ctx->pending_pairs = 0;
+        (void)hipEventRecord(ctx->ev_call0, ctx->stream);
+    }
+    int finish()
+    {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_call1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_call0, ctx->ev_call1));
+        ctx->stats.total_ms += ms;
+        ctx->stats.calls += 1;
+        if (ctx->kernel_timed) {
+            float kms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&kms, ctx->ev_k0, ctx->ev_k1));
+            ctx->stats.kernel_ms += kms;
+            ctx->stats.kernel_launches += 1;
+            ctx->stats.pairs += ctx->pending_pairs;
+        }
+        return FM_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// banks
+// ---------------------------------------------------------------------------------------
+static void bank_free(Bank* b)
+{
+    if (b->rows8) (void)hipFree(b->rows8);
+    if (b->norm) (void)hipFree(b->norm);
+    if (b->aux) (void)hipFree(b->aux);
+    if (b->rowsf) (void)hipFree(b->rowsf);
+    if (b->selfdist) (void)hipFree(b->selfdist);
+    b->rows8 = nullptr; b->norm = nullptr; b->aux = nullptr; b->rowsf = nullptr; b->selfdist = nullptr;
+}
+
+static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_bank_create: ctx is NULL");
+    if (!out) return fail(ctx, FM_EINVAL, "fm_bank_create: bank out pointer is NULL");
+    *out = nullptr;
+    if (n < 0 || dim < 1 || (n > 0 && !rows)) return fail(ctx, FM_EINVAL, "fm_bank_create: bad rows/n/dim");
+    if (dim > kDim) return fail(ctx, FM_EUNSUPPORTED, "fm_bank_create: dim > 128 is not supported");
+    if (n > (int64_t)INT32_MAX - 2 * kStageRows) return fail(ctx, FM_EUNSUPPORTED, "fm_bank_create: n too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_bank* b = new (std::nothrow) fm_bank();
+    if (!b) return fail(ctx, FM_ENOMEM, "fm_bank_create: out of host memory");
+    b->n = n;
+    b->dim = dim;
+    b->n_pad = ((n + kStageRows - 1) / kStageRows) * kStageRows;
+    if (b->n_pad == 0) b->n_pad = kStageRows;
+    b->kind = FM_BANK_I8;
+    const size_t elt = f32 ? 4 : 1;
+    const size_t src_bytes = (size_t)n * dim * elt;
+    int rc = FM_OK;
+    auto bail = [&](int code) { bank_free(b); delete b; return code; };
+
+    const size_t flag_off = (src_bytes + 15) & ~(size_t)15;
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 16)) != FM_OK) return bail(rc);
+    int* d_flag = (int*)((char*)ctx->ws_in + flag_off);
+#define BTRY(expr)                                                                               \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            (void)hipGetLastError();                                                             \
+            return bail(fail(ctx, _e == hipErrorOutOfMemory ? FM_ENOMEM : FM_EDEVICE,            \
+                             std::string(#expr " failed: ") + hipGetErrorString(_e)));           \
+        }                                                                                        \
+    } while (0)
+    BTRY(hipMalloc((void**)&b->rows8, (size_t)b->n_pad * kDim));
+    BTRY(hipMalloc((void**)&b->norm, (size_t)b->n_pad * 4));
+    BTRY(hipMalloc((void**)&b->aux, (size_t)(b->n_pad / kTileRows) * kAuxPerTile * 4));
+    if (src_bytes) BTRY(hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    BTRY(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    const int ntiles = (int)(b->n_pad / kTileRows);
+    if (f32)
+        hipLaunchKernelGGL(bank_prep_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream,
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag);
+    else
+        hipLaunchKernelGGL(bank_prep_kernel<false>, dim3(ntiles), dim3(256), 0, ctx->stream,
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag);
+    BTRY(hipGetLastError());
+    int flag = 0;
+    BTRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BTRY(hipStreamSynchronize(ctx->stream));
+    if (f32 && flag) {
+        // not integer-valued: keep a float32 bank for the fma-chain route
+        b->kind = FM_BANK_F32;
+        (void)hipFree(b->rows8); b->rows8 = nullptr;
+        (void)hipFree(b->aux); b->aux = nullptr;
+        BTRY(hipMalloc((void**)&b->rowsf, (size_t)b->n_pad * kDim * 4));
+        const int64_t tot = b->n_pad * kDim;
+        hipLaunchKernelGGL(bank_copy_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float*)ctx->ws_in, n, dim, b->rowsf, b->n_pad);
+        BTRY(hipGetLastError());
+        BTRY(hipStreamSynchronize(ctx->stream));
+    }
+#undef BTRY
+    *out = b;
+    return FM_OK;
+}
+
+extern "C" int fm_bank_create_u8(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, fm_bank** bank)
+{
+    return bank_create(ctx, rows, n, dim, false, bank);
+}
+
+extern "C" int fm_bank_create_f32(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank)
+{
+    return bank_create(ctx, rows, n, dim, true, bank);
+}
+
+extern "C" int fm_bank_destroy(fm_ctx* ctx, fm_bank* bank)
+{
+    if (!bank) return FM_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    bank_free(bank);
+    delete bank;
+    return FM_OK;
+}
+
+extern "C" int fm_bank_info(const fm_bank* bank, int64_t* n, int* dim, int* kind)
+{
+    if (!bank) return fail(nullptr, FM_EINVAL, "fm_bank_info: bank is NULL");
+    if (n) *n = bank->n;
+    if (dim) *dim = bank->dim;
+    if (kind) *kind = bank->kind;
+    return FM_OK;
+}
+
+extern "C" int fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* selfdist)
+{
+    if (!ctx || !bank) return fail(ctx, FM_EINVAL, "fm_bank_set_selfdist: NULL argument");
+    if (bank->n > 0 && !selfdist) return fail(ctx, FM_EINVAL, "fm_bank_set_selfdist: selfdist is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!bank->selfdist) HIP_TRY(ctx, hipMalloc((void**)&bank->selfdist, (size_t)(bank->n > 0 ? bank->n : 1) * 8));
+    if (bank->n > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(bank->selfdist, selfdist, (size_t)bank->n * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FM_OK;
+}
+
+static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const char* who)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, std::string(who) + ": ctx is NULL");
+    if (!q || !t) return fail(ctx, FM_EINVAL, std::string(who) + ": bank is NULL");
+    if (q->dim != t->dim) return fail(ctx, FM_EINVAL, std::string(who) + ": query/train dim mismatch");
+    if (q->kind != t->kind)
+        return fail(ctx, FM_EINVAL, std::string(who) + ": query/train kind mismatch (one bank is integer-valued, the other is not)");
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 entry points
+// ---------------------------------------------------------------------------------------
+// Device-side knn2 into d_idx/d_dist (device pointers).
+static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t* d_idx, float* d_dist)
+{
+    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_knn2: float32 (non-integer) banks are not supported yet");
+    const int64_t nq = q->n;
+    if (nq == 0) return FM_OK;
+    RowReducePlan pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit);
+    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2));
+    if (rc != FM_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, ctx->use_glds, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    ctx->pending_pairs += nq * t->n;
+    hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nq, d_idx, d_dist);
+    HIP_TRY(ctx, hipGetLastError());
+    return FM_OK;
+}
+
+extern "C" int fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t* idx, float* dist)
+{
+    int rc = check_pair(ctx, q, t, "fm_knn2");
+    if (rc != FM_OK) return rc;
+    const int64_t nq = q->n;
+    if (nq > 0 && (!idx || !dist)) return fail(ctx, FM_EINVAL, "fm_knn2: output pointer is NULL");
+    if (nq == 0) return FM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, (size_t)nq * 16 + 64)) != FM_OK) return rc;
+    int32_t* d_idx = (int32_t*)ctx->ws_out;
+    float* d_dist = (float*)((char*)ctx->ws_out + (size_t)nq * 8);
+    CallScope cs(ctx);
+    if ((rc = knn2_device(ctx, q, t, d_idx, d_dist)) != FM_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return cs.finish();
+}
+
+extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
+{
+    int rc = check_pair(ctx, bank, bank, "fm_self_dist");
+    if (rc != FM_OK) return rc;
+    const int64_t n = bank->n;
+    if (n == 0) return FM_OK;
+    if (!selfdist) return fail(ctx, FM_EINVAL, "fm_self_dist: output pointer is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, (size_t)n * 24 + 64)) != FM_OK) return rc;
+    int32_t* d_idx = (int32_t*)ctx->ws_out;
+    float* d_dist = (float*)((char*)ctx->ws_out + (size_t)n * 8);
+    double* d_sd = (double*)((char*)ctx->ws_out + (size_t)n * 16);
+    CallScope cs(ctx);
+    if ((rc = knn2_device(ctx, bank, bank, d_idx, d_dist)) != FM_OK) return rc;
+    hipLaunchKernelGGL(selfdist_from_knn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float*)d_dist, n, d_sd);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(selfdist, d_sd, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return cs.finish();
+}
+
+// ---------------------------------------------------------------------------------------
+// X1 (+R1) entry points
+// ---------------------------------------------------------------------------------------
+static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
+                         int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
+                         const char* who)
+{
+    int rc = check_pair(ctx, q, t, who);
+    if (rc != FM_OK) return rc;
+    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, std::string(who) + ": float32 (non-integer) banks are not supported yet");
+    const int64_t nq = q->n, nt = t->n;
+    if (n_pass) *n_pass = 0;
+    if (nq == 0) return FM_OK;
+    if (!tidx || !dist) return fail(ctx, FM_EINVAL, std::string(who) + ": output pointer is NULL");
+    if (with_ratio && !q->selfdist) return fail(ctx, FM_EINVAL, std::string(who) + ": query bank has no self distances (fm_bank_set_selfdist)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // outputs: qbest u64[nq] | tidx i32[nq] | dist f32[nq] | ratio f64[nq] | pass u8[nq] | count u64
+    const size_t o_qbest = 0, o_tidx = (size_t)nq * 8, o_dist = o_tidx + (size_t)nq * 4;
+    const size_t o_ratio = (o_dist + (size_t)nq * 4 + 7) & ~(size_t)7, o_pass = o_ratio + (size_t)nq * 8;
+    const size_t o_cnt = (o_pass + (size_t)nq + 15) & ~(size_t)15;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_cnt + 16)) != FM_OK) return rc;
+    char* base = (char*)ctx->ws_out;
+    unsigned long long* d_qbest = (unsigned long long*)(base + o_qbest);
+    int32_t* d_tidx = (int32_t*)(base + o_tidx);
+    float* d_dist = (float*)(base + o_dist);
+    double* d_ratio = (double*)(base + o_ratio);
+    uint8_t* d_pass = (uint8_t*)(base + o_pass);
+    unsigned long long* d_cnt = (unsigned long long*)(base + o_cnt);
+
+    // reverse NN: output rows = train rows, reduced over the query rows
+    RowReducePlan pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit);
+    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1))) != FM_OK) return rc;
+
+    CallScope cs(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    if (nt > 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, ctx->use_glds, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        ctx->kernel_timed = true;
+        ctx->pending_pairs += nq * nt;
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)d_qbest, nq, with_ratio ? (const double*)q->selfdist : (const double*)nullptr,
+                       tau, d_tidx, d_dist, with_ratio ? d_ratio : (double*)nullptr,
+                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(tidx, d_tidx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long cnt = 0;
+    if (with_ratio) {
+        if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, d_ratio, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pass) HIP_TRY(ctx, hipMemcpyAsync(pass, d_pass, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    rc = cs.finish();
+    if (rc != FM_OK) return rc;
+    if (n_pass) *n_pass = (int64_t)cnt;
+    return FM_OK;
+}
+
+extern "C" int fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t* tidx, float* dist)
+{
+    return xcheck_common(ctx, q, t, false, 0.0, tidx, dist, nullptr, nullptr, nullptr, "fm_xcheck1");
+}
+
+extern "C" int fm_match_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int32_t* tidx,
+                              float* dist, double* ratio, uint8_t* pass, int64_t* n_pass)
+{
+    return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, pass, n_pass, "fm_match_ratio");
+}
+
+extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* selfdist, const int32_t* qrows,
+                               int64_t n, double tau, double* ratio, uint8_t* pass, int64_t* n_pass)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_ratio_filter: ctx is NULL");
+    if (n_pass) *n_pass = 0;
+    if (n < 0) return fail(ctx, FM_EINVAL, "fm_ratio_filter: n < 0");
+    if (n == 0) return FM_OK;
+    if (!dist || !selfdist) return fail(ctx, FM_EINVAL, "fm_ratio_filter: NULL input");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // selfdist is indexed by qrows (or by i): upload max(qrows)+1 entries
+    int64_t nsd = n;
+    if (qrows) { nsd = 0; for (int64_t i = 0; i < n; ++i) { if (qrows[i] < 0) return fail(ctx, FM_EINVAL, "fm_ratio_filter: negative qrow"); if (qrows[i] + 1 > nsd) nsd = qrows[i] + 1; } }
+    const size_t i_dist = 0, i_sd = ((size_t)n * 4 + 7) & ~(size_t)7, i_qr = i_sd + (size_t)nsd * 8;
+    const size_t in_bytes = i_qr + (qrows ? (size_t)n * 4 : 0);
+    int rc;
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, in_bytes + 16)) != FM_OK) return rc;
+    const size_t o_ratio = 0, o_pass = (size_t)n * 8, o_cnt = (o_pass + (size_t)n + 15) & ~(size_t)15;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_cnt + 16)) != FM_OK) return rc;
+    char* ib = (char*)ctx->ws_in;
+    char* ob = (char*)ctx->ws_out;
+    CallScope cs(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ib + i_dist, dist, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ib + i_sd, selfdist, (size_t)nsd * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (qrows) HIP_TRY(ctx, hipMemcpyAsync(ib + i_qr, qrows, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ob + o_cnt, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(ratio_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float*)(ib + i_dist), (const double*)(ib + i_sd),
+                       qrows ? (const int32_t*)(ib + i_qr) : (const int32_t*)nullptr, n, tau,
+                       (double*)(ob + o_ratio), (uint8_t*)(ob + o_pass), (unsigned long long*)(ob + o_cnt));
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long cnt = 0;
+    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ob + o_ratio, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (pass) HIP_TRY(ctx, hipMemcpyAsync(pass, ob + o_pass, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&cnt, ob + o_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    rc = cs.finish();
+    if (rc != FM_OK) return rc;
+    if (n_pass) *n_pass = (int64_t)cnt;
+    return FM_OK;
+}
+
+extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank*, const int32_t*, const int64_t*, const fm_bank*,
+                                  const int64_t*, int64_t, int32_t*, float*, double*)
+{
+    return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: not implemented yet");
+}

@@ -1,0 +1,58 @@
+// Internal declarations shared by the HIP translation units of libfastmatch_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/fastmatch_hip.h"
+
+namespace fm {
+
+// ---- bank layout in HBM -------------------------------------------------------------
+// rows8 : int8 [n_pad][128]   descriptor bytes XOR 0x80 (u8 -> i8 shift by 128; L2 is
+//                             shift invariant), zero rows for padding, n_pad % 128 == 0
+// norm  : int32 [n_pad]       nm = sum of squares of the int8 row (<= 2^21)
+// aux   : int32 [n_pad/32][64] per 32-row tile, permuted into MFMA accumulator order:
+//           aux[tile][      16*h + r] = -(nm >> 1)      (accumulator init "cinit")
+//           aux[tile][32 +  16*h + r] = 1 - (nm & 1)    ("npar", tie-break parity)
+//         for tile row mm = (r&3) + 8*(r>>2) + 4*h   (r = accumulator register 0..15,
+//         h = lane>>5), i.e. the C/D map of v_mfma_i32_32x32x32_i8.
+//         Padding rows carry cinit = -2^29 so they can never win a reduction.
+constexpr int kDim        = 128;
+constexpr int kStageRows  = 128;                 // rows staged into LDS per pipeline step
+constexpr int kTileRows   = 32;                  // one MFMA M-tile
+constexpr int kAuxPerTile = 64;
+constexpr int kPadCinit   = -(1 << 29);
+
+struct Bank {
+    int      kind   = 0;       // FM_BANK_I8 / FM_BANK_F32
+    int64_t  n      = 0;
+    int      dim    = 0;
+    int64_t  n_pad  = 0;       // multiple of kStageRows (>= kStageRows so empty banks stage)
+    int8_t*  rows8  = nullptr;
+    int32_t* norm   = nullptr;
+    int32_t* aux    = nullptr;
+    float*   rowsf  = nullptr; // FM_BANK_F32: [n_pad][128] float32, zero padded
+    double*  selfdist = nullptr;
+};
+
+// ---- K1: row-reduce kernel launcher ---------------------------------------------------
+// For every row c of bank `cols`, reduce over all rows m of bank `red` the key
+// (d2(c,m), m) lexicographically and keep the KTOP smallest.  Writes, per split of the
+// reduction range, packed candidates  (uint64)d2 << 32 | m  (~0 = none) to
+// partial[(split*ncols_alloc + c)*KTOP + k].
+struct RowReducePlan {
+    int nb;            // 32-column blocks per wave (1, 2 or 4)
+    int ncols_alloc;   // columns covered by the grid (multiple of 128*nb)
+    int nchunks;
+    int nsplit;
+    int stages_per_split;
+    size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
+};
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit);
+hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
+                            unsigned long long* partial, bool use_glds, hipStream_t stream);
+
+}  // namespace fm
+
+struct fm_bank : fm::Bank {};

@@ -1,0 +1,327 @@
+// K1 -- int8-MFMA pairwise squared-L2 tile kernel with a fused reduce-over-M epilogue.
+//
+// Replaces the arithmetic of cv::batchDistance behind
+//   cv2.BFMatcher(NORM_L2, crossCheck).knnMatch        (fastmatch.pyx:122-123, 161-162;
+//                                                       matchutil.py:42-43)
+// for uint8 / integer-valued descriptors: d2(c, m) = |c|^2 + |m|^2 - 2 c.m exactly in
+// int32 on bytes shifted by -128.
+//
+// Mapping onto v_mfma_i32_32x32x32_i8 (D[M x N] += A[M x K] B[K x N]):
+//   N (lane & 31)        = the output row ("column" c) whose nearest neighbours we want;
+//                          its four 32-byte K-chunks stay in VGPRs for the whole sweep.
+//   M (accumulator regs) = the rows being reduced over, streamed through LDS.
+//   Accumulator init     = -(|m|^2 >> 1) from the bank's aux array, so the accumulator is
+//                          acc = c.m - (|m|^2 >> 1) and  |m|^2 - 2 c.m = 1 - (2 acc + npar).
+// A lane therefore holds 16 candidates of ONE output row per tile and reduces them
+// in-lane: the fast path is a v_max3 tree and one compare against the lane's current
+// K-th best accumulator value; only tiles that can change a lane's top-K take the exact
+// (hi = 2 acc + npar, index) update.  The two lane halves and the four waves of a block
+// never exchange data until the single cross-half merge after the sweep.
+//
+// Grid: blockIdx -> (chunk of 128*NB output rows, split of the reduction range).
+// split = blockIdx % nsplit, and nsplit is a multiple of 8 when > 1, so the blocks that
+// share an XCD (blockIdx % 8) sweep the same slice of the reduced bank out of that XCD's
+// L2.  Staging: 128 rows (16 KiB) + 1 KiB aux per step, global_load_lds_dwordx4 into a
+// double buffer, XOR swizzle applied on the source address so that the ds_read_b128
+// A-fragment reads are bank-conflict free.
+#include "fm_internal.h"
+
+namespace fm {
+
+typedef int v4i  __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kStageRowBytes = kStageRows * kDim;           // 16384
+constexpr int kStageAuxBytes = (kStageRows / kTileRows) * kAuxPerTile * 4;  // 1024
+constexpr int kStageBytes    = kStageRowBytes + kStageAuxBytes;             // 17408
+
+struct RRParams {
+    const int8_t*  col_rows;
+    const int32_t* col_norm;
+    int            ncols_pad;
+    const int8_t*  red_rows;
+    const int32_t* red_aux;
+    int            nred;          // real rows of the reduced bank
+    int            nstages;       // nred_pad / 128
+    int            nsplit;
+    int            stages_per_split;
+    int            ncols_alloc;
+    unsigned long long* partial;
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <bool GLDS>
+__device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* buf, int wave, int lane)
+{
+    const int8_t* src_rows = p.red_rows + (size_t)stage * kStageRowBytes;
+    const int slot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g   = wave * 4 + i;              // 1-KiB piece = 8 rows
+        const int row = g * 8 + (lane >> 3);
+        const int8_t* src = src_rows + row * kDim + 16 * (slot ^ ((row >> 1) & 7));
+        if constexpr (GLDS) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(buf + g * 1024), 16, 0, 0);
+        } else {
+            *(v4i*)(buf + g * 1024 + lane * 16) = *(const v4i*)src;
+        }
+    }
+    if (wave == 0) {
+        const int32_t* src = p.red_aux + (size_t)stage * (kStageAuxBytes / 4) + lane * 4;
+        if constexpr (GLDS) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(buf + kStageRowBytes), 16, 0, 0);
+        } else {
+            *(v4i*)(buf + kStageRowBytes + lane * 16) = *(const v4i*)src;
+        }
+    }
+}
+
+__device__ __forceinline__ int max16(const v16i& a)
+{
+    int m0 = max(max(a[0], a[1]), a[2]);
+    int m1 = max(max(a[3], a[4]), a[5]);
+    int m2 = max(max(a[6], a[7]), a[8]);
+    int m3 = max(max(a[9], a[10]), a[11]);
+    int m4 = max(max(a[12], a[13]), a[14]);
+    int m5 = max(max(m0, m1), m2);
+    int m6 = max(max(m3, m4), a[15]);
+    return max(m5, m6);
+}
+
+// Exact update of a lane's top-KTOP with the 16 candidates of one tile.
+// hi = 2*acc + npar orders candidates by descending (d2 ascending); candidates arrive in
+// ascending row index within a lane, so strict '>' keeps the lower index on ties
+// (cv::batchDistance insertion rule).
+template <int KTOP>
+__device__ __forceinline__ void exact_update(const v16i& acc, const v16i& np, int idx_base, int nred,
+                                             int (&bh)[KTOP], int (&bi)[KTOP])
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int hi  = (acc[r] << 1) | np[r];
+        const int idx = idx_base + (r & 3) + 8 * (r >> 2);
+        const bool ok = idx < nred;
+        if constexpr (KTOP == 1) {
+            if (ok && hi > bh[0]) { bh[0] = hi; bi[0] = idx; }
+        } else {
+            if (ok && hi > bh[1]) {
+                if (hi > bh[0]) { bh[1] = bh[0]; bi[1] = bi[0]; bh[0] = hi; bi[0] = idx; }
+                else            { bh[1] = hi;    bi[1] = idx; }
+            }
+        }
+    }
+}
+
+// (hi, idx) a is better than b: larger hi, then lower index.  idx < 0 means "none".
+__device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
+{
+    if (ai < 0) return false;
+    if (bi_ < 0) return true;
+    return ah > bh_ || (ah == bh_ && ai < bi_);
+}
+
+template <int NB, int KTOP, bool GLDS>
+__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 3))
+void rowreduce_kernel(RRParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h    = lane >> 5;
+    const int split = blockIdx.x % p.nsplit;
+    const int chunk = blockIdx.x / p.nsplit;
+    const int cb    = chunk * (128 * NB) + wave * (32 * NB);
+
+    // Stationary operand: this wave's NB x 32 output rows, 4 K-chunks of 32 bytes each.
+    v4i bf[NB][4];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = cb + 32 * j + (lane & 31);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (n < p.ncols_pad)
+                bf[j][c] = *(const v4i*)(p.col_rows + (size_t)n * kDim + 32 * c + 16 * h);
+            else
+                bf[j][c] = v4i{0, 0, 0, 0};
+        }
+    }
+
+    int bh[NB][KTOP], bi[NB][KTOP], thr[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        thr[j] = INT32_MIN;
+#pragma unroll
+        for (int k = 0; k < KTOP; ++k) { bh[j][k] = INT32_MIN; bi[j][k] = -1; }
+    }
+
+    const int st0 = split * p.stages_per_split;
+    const int st1 = min(st0 + p.stages_per_split, p.nstages);
+
+    // Per-lane LDS offsets of the A fragments (swizzled) and of the aux words.
+    const int sw = ((lane & 31) >> 1) & 7;
+    int aoff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aoff[c] = (lane & 31) * kDim + 16 * ((2 * c + h) ^ sw);
+    const int xoff = kStageRowBytes + h * 64;
+
+    if (st0 < st1) issue_stage<GLDS>(p, st0, smem, wave, lane);
+
+    for (int st = st0; st < st1; ++st) {
+        char* buf = smem + ((st - st0) & 1) * kStageBytes;
+        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // stage st landed; every wave is done with the other buffer
+        if (st + 1 < st1) issue_stage<GLDS>(p, st + 1, smem + ((st + 1 - st0) & 1) * kStageBytes, wave, lane);
+
+#pragma unroll
+        for (int tt = 0; tt < kStageRows / kTileRows; ++tt) {
+            v4i af[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(buf + tt * (kTileRows * kDim) + aoff[c]);
+            v16i ci;
+            {
+                const v4i* ax = (const v4i*)(buf + xoff + tt * (kAuxPerTile * 4));
+                const v4i c0 = ax[0], c1 = ax[1], c2 = ax[2], c3 = ax[3];
+                ci = v16i{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3],
+                          c2[0], c2[1], c2[2], c2[3], c3[0], c3[1], c3[2], c3[3]};
+            }
+            v16i acc[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[j][0], ci, 0, 0, 0);
+#pragma unroll
+            for (int c = 1; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[c], bf[j][c], acc[j], 0, 0, 0);
+
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int tmax = max16(acc[j]);
+                if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
+                    const v4i* nx = (const v4i*)(buf + xoff + tt * (kAuxPerTile * 4) + 128);
+                    const v4i n0 = nx[0], n1 = nx[1], n2 = nx[2], n3 = nx[3];
+                    const v16i np = v16i{n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3],
+                                         n2[0], n2[1], n2[2], n2[3], n3[0], n3[1], n3[2], n3[3]};
+                    exact_update<KTOP>(acc[j], np, st * kStageRows + tt * kTileRows + 4 * h, p.nred, bh[j], bi[j]);
+                    // A candidate enters the top-K only if 2*acc+npar > bh[K-1], possible iff acc >= ceil(bh[K-1]/2).
+                    thr[j] = (bi[j][KTOP - 1] >= 0) ? ((bh[j][KTOP - 1] + 1) >> 1) : INT32_MIN;
+                }
+            }
+        }
+    }
+
+    // Merge the two lane halves (same output row, interleaved reduced rows), then emit.
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int oh[KTOP], oi[KTOP];
+#pragma unroll
+        for (int k = 0; k < KTOP; ++k) {
+            oh[k] = __shfl_xor(bh[j][k], 32);
+            oi[k] = __shfl_xor(bi[j][k], 32);
+        }
+        int rh[KTOP], ri[KTOP];
+        if constexpr (KTOP == 1) {
+            const bool mine = !better(oh[0], oi[0], bh[j][0], bi[j][0]);
+            rh[0] = mine ? bh[j][0] : oh[0];
+            ri[0] = mine ? bi[j][0] : oi[0];
+        } else {
+            const bool m0 = !better(oh[0], oi[0], bh[j][0], bi[j][0]);
+            rh[0] = m0 ? bh[j][0] : oh[0];
+            ri[0] = m0 ? bi[j][0] : oi[0];
+            // runner-up: the loser of the first comparison against the winner side's 2nd
+            const int ah = m0 ? bh[j][1] : bh[j][0], ai = m0 ? bi[j][1] : bi[j][0];
+            const int ch = m0 ? oh[0] : oh[1],       cidx = m0 ? oi[0] : oi[1];
+            const bool m1 = !better(ch, cidx, ah, ai);
+            rh[1] = m1 ? ah : ch;
+            ri[1] = m1 ? ai : cidx;
+        }
+        const int n = cb + 32 * j + (lane & 31);
+        if (h == 0 && n < p.ncols_alloc) {
+            const int cn = (n < p.ncols_pad) ? p.col_norm[n] : 0;
+            unsigned long long* out = p.partial + ((size_t)split * p.ncols_alloc + n) * KTOP;
+#pragma unroll
+            for (int k = 0; k < KTOP; ++k) {
+                unsigned long long key = ~0ull;
+                if (ri[k] >= 0 && n < p.ncols_pad) {
+                    const unsigned d2 = (unsigned)(cn + 1 - rh[k]);
+                    key = ((unsigned long long)d2 << 32) | (unsigned)ri[k];
+                }
+                out[k] = key;
+            }
+        }
+    }
+}
+
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit)
+{
+    RowReducePlan pl;
+    const int64_t nstages = nred_pad / kStageRows;
+    int nb = 4;
+    // Small column counts: narrower wave tiles keep more waves busy.
+    if (ncols_pad <= 128 * 256) nb = 2;
+    if (ncols_pad <= 128 * 64) nb = 1;
+    if (force_nb == 1 || force_nb == 2 || force_nb == 4) nb = force_nb;
+    pl.nb = nb;
+    const int cb = 128 * nb;
+    pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
+    if (pl.nchunks < 1) pl.nchunks = 1;
+    pl.ncols_alloc = pl.nchunks * cb;
+    int64_t want = 4096;                         // ~8 waves of 512 resident blocks
+    int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
+    if (nsplit > nstages / 8) nsplit = nstages / 8;   // keep >= 8 stages (1024 rows) per split
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 1) nsplit = (nsplit + 7) / 8 * 8;    // XCD-aligned
+    if (force_nsplit > 0) nsplit = force_nsplit;
+    if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
+    int64_t per = (nstages + nsplit - 1) / nsplit;
+    if (per < 1) per = 1;
+    nsplit = (nstages + per - 1) / per;
+    if (nsplit < 1) nsplit = 1;
+    pl.nsplit = (int)nsplit;
+    pl.stages_per_split = (int)per;
+    return pl;
+}
+
+template <int NB, int KTOP>
+static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
+{
+    if (glds) hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, true>), dim3(grid), dim3(256), 0, stream, p);
+    else      hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, false>), dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
+                            unsigned long long* partial, bool use_glds, hipStream_t stream)
+{
+    RRParams p;
+    p.col_rows = cols.rows8;
+    p.col_norm = cols.norm;
+    p.ncols_pad = (int)cols.n_pad;
+    p.red_rows = red.rows8;
+    p.red_aux = red.aux;
+    p.nred = (int)red.n;
+    p.nstages = (int)(red.n_pad / kStageRows);
+    p.nsplit = plan.nsplit;
+    p.stages_per_split = plan.stages_per_split;
+    p.ncols_alloc = plan.ncols_alloc;
+    p.partial = partial;
+    const int grid = plan.nchunks * plan.nsplit;
+    if (ktop == 1) {
+        switch (plan.nb) {
+            case 1: return launch_t<1, 1>(p, grid, use_glds, stream);
+            case 2: return launch_t<2, 1>(p, grid, use_glds, stream);
+            default: return launch_t<4, 1>(p, grid, use_glds, stream);
+        }
+    } else {
+        switch (plan.nb) {
+            case 1: return launch_t<1, 2>(p, grid, use_glds, stream);
+            case 2: return launch_t<2, 2>(p, grid, use_glds, stream);
+            default: return launch_t<4, 2>(p, grid, use_glds, stream);
+        }
+    }
+}
+
+}  // namespace fm

@@ -1,0 +1,136 @@
+/*
+ * fastmatch_hip.h -- C-ABI of libfastmatch_hip.so: the MI355X (gfx950) drop-in for the
+ * arithmetic behind Fast-Match's descriptor-matching hot path.
+ *
+ * The reference (arnfred/Fast-Match) has no native FFI of its own: its Cython modules
+ * call OpenCV's cv2.BFMatcher from Python.  Each entry point below therefore names the
+ * reference call site whose arithmetic it replaces (file:line in the reference tree);
+ * INTEGRATION.md shows the ctypes binding a maintainer would add at those sites.
+ *
+ * Conventions: plain C, no exceptions.  Every function returns 0 on success and a
+ * negative FM_E* code on failure; fm_last_error() returns the message of the last
+ * failure on that context (or the last context-less failure when ctx == NULL).
+ * The caller owns every host buffer; the library owns device memory behind the opaque
+ * handles.  One fm_ctx per device; calls on one ctx are serialised on its HIP stream
+ * (not re-entrant per ctx; distinct ctxs are independent).  All calls are synchronous:
+ * host outputs are valid on return.  There is no CPU fallback: without a usable
+ * gfx950 device fm_ctx_create fails.
+ */
+#ifndef FASTMATCH_HIP_H
+#define FASTMATCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_OK            0
+#define FM_EINVAL       -1   /* bad argument (null handle, dim mismatch, k unsupported ...)  */
+#define FM_EDEVICE      -2   /* HIP runtime error; message carries hipGetErrorString          */
+#define FM_ENOMEM       -3   /* device or host allocation failed                              */
+#define FM_EUNSUPPORTED -4   /* valid request this build cannot serve (e.g. dim > 128)        */
+
+/* Bank kinds (fm_bank_info) */
+#define FM_BANK_I8   1       /* uint8 / integer-valued float32 rows: exact int8-MFMA route    */
+#define FM_BANK_F32  2       /* general float32 rows: fp32 fma-chain route                    */
+
+typedef struct fm_ctx  fm_ctx;
+typedef struct fm_bank fm_bank;
+
+typedef struct fm_stats {
+    double   kernel_ms;      /* HIP-event time of the distance kernels since fm_reset_stats   */
+    double   total_ms;       /* HIP-event time of whole calls (all kernels + copies)          */
+    int64_t  kernel_launches;/* number of distance-kernel launches in kernel_ms               */
+    int64_t  pairs;          /* descriptor pairs evaluated by those launches                  */
+    int64_t  calls;          /* API calls accounted in total_ms                               */
+} fm_stats;
+
+/* ---- context ---------------------------------------------------------------------- */
+int  fm_ctx_create(int device_id, fm_ctx** ctx);
+int  fm_ctx_destroy(fm_ctx* ctx);
+const char* fm_last_error(const fm_ctx* ctx);
+int  fm_sync(fm_ctx* ctx);
+int  fm_get_stats(fm_ctx* ctx, fm_stats* out);
+int  fm_reset_stats(fm_ctx* ctx);
+/* Name of the device the context runs on (e.g. "gfx950:..."), written NUL-terminated.  */
+int  fm_device_name(fm_ctx* ctx, char* buf, int buflen);
+
+/* ---- descriptor banks --------------------------------------------------------------
+ * A bank is a device-resident [n, dim] descriptor matrix plus what the kernels need
+ * (bytes XOR 0x80 as int8, row norms).  It replaces the ndarray arguments the reference
+ * hands to cv2 at every matcher call: Metric_Cache.original/thumb["descriptors"]
+ * (cache.pyx:255-260, 278-284) and the Grid_Cache cell descriptors (cache.pyx:134-137).
+ * dim must be <= 128 (SIFT = 128); shorter rows are zero-padded, which leaves every L2
+ * distance unchanged.  n may be 0.
+ *   fm_bank_create_u8  : rows are uint8 (CV_8U descriptors).
+ *   fm_bank_create_f32 : rows are float32 (what cv2 SIFT emits).  If every value is an
+ *       integer in [0,255] the bank takes the exact int8 route (kind FM_BANK_I8),
+ *       otherwise it stays float32 (kind FM_BANK_F32).
+ * A query/train pair must have the same kind and dim (cv2 raises on dtype mismatch).    */
+int  fm_bank_create_u8 (fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, fm_bank** bank);
+int  fm_bank_create_f32(fm_ctx* ctx, const float*   rows, int64_t n, int dim, fm_bank** bank);
+int  fm_bank_destroy(fm_ctx* ctx, fm_bank* bank);
+int  fm_bank_info(const fm_bank* bank, int64_t* n, int* dim, int* kind);
+/* Attach per-row self distances (Metric_Cache.*["distances"], float64, cache.pyx:252,273)
+ * to a query bank so that fm_match_ratio can run the ratio test on the device.          */
+int  fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* selfdist /*[n]*/);
+
+/* ---- K2: brute-force 2-NN ------------------------------------------------------------
+ * Replaces cv2.BFMatcher(cv2.NORM_L2, crossCheck=False).knnMatch(q, t, k=2)
+ *   matchutil.py:39-43 (bf_match), called from cache.pyx:250; Classic Matching.ipynb:63.
+ * idx[2*i+r], dist[2*i+r] = r-th nearest train row of query row i (ascending distance,
+ * lower train index first on ties); idx -1 / dist +inf where t has fewer than 2 rows.   */
+int  fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
+             int32_t* idx /*[nq*2]*/, float* dist /*[nq*2]*/);
+
+/* Replaces bf_match(d, d, k=2) + [r[1].distance] (cache.pyx:250-252; exact substitute
+ * for the approximate flann_match at cache.pyx:271-273).  selfdist[i] = distance from
+ * row i to its 2nd entry of the self 2-NN list, as float64 of the float32 value.         */
+int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
+
+/* ---- X1: cross-checked 1-NN ----------------------------------------------------------
+ * Replaces cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).knnMatch(q, t, k=1)
+ *   fastmatch.pyx:122-123 (match_thumbs) and fastmatch.pyx:161-162 (match_position).
+ * tidx[i] = train index matched to query row i or -1 (empty inner list), dist[i] its
+ * float32 distance (+inf when unmatched).  OpenCV semantics: reverse-NN + scatter-min
+ * with lowest-index tie-breaks.                                */
+int  fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
+                int32_t* tidx /*[nq]*/, float* dist /*[nq]*/);
+
+/* ---- R1: ratio + threshold -----------------------------------------------------------
+ * Replaces  ratios = m.distance / query_dis[m.queryIdx]   (fastmatch.pyx:124, 165)
+ *      and  ratios < tau                                   (fastmatch.pyx:50, 75, 82)
+ * in float64 on the device.  qrows == NULL means row i uses selfdist[i].
+ * ratio and pass may each be NULL.                                                      */
+int  fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* selfdist,
+                     const int32_t* qrows, int64_t n, double tau,
+                     double* ratio /*[n] or NULL*/, uint8_t* pass /*[n] or NULL*/,
+                     int64_t* n_pass /*or NULL*/);
+
+/* X1 + R1 fused on the device for banks that stay resident (one match_position /
+ * match_thumbs round: fastmatch.pyx:161-165, 122-124).  q must carry self distances
+ * (fm_bank_set_selfdist).  Outputs as fm_xcheck1 plus ratio[i] (nan when unmatched)
+ * and pass[i] = ratio[i] < tau; *n_pass = number of accepted matches.                   */
+int  fm_match_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau,
+                    int32_t* tidx /*[nq]*/, float* dist /*[nq]*/,
+                    double* ratio /*[nq] or NULL*/, uint8_t* pass /*[nq] or NULL*/,
+                    int64_t* n_pass /*or NULL*/);
+
+/* ---- K4: many match_position rounds in one launch ------------------------------------
+ * Round b matches the query rows  q_rows[q_off[b] .. q_off[b+1])  of bank q (the radius
+ * subset Metric_Cache.get returns, cache.pyx:173-188, in its order) against the train
+ * rows [t_off[b], t_off[b+1]) of bank t (cells of a Grid_Cache packed back to back).
+ * Output is per query slot i in [0, q_off[B]):  tidx[i] = train row index LOCAL to the
+ * round's cell (-1 = none), dist[i], and ratio[i] = dist / selfdist[q_rows[i]] when q
+ * carries self distances (else nan).  Semantics per round are exactly fm_xcheck1 on the
+ * gathered sub-matrices.                                                                */
+int  fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows,
+                        const int64_t* q_off /*[B+1]*/, const fm_bank* t,
+                        const int64_t* t_off /*[B+1]*/, int64_t n_rounds,
+                        int32_t* tidx, float* dist, double* ratio /*or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTMATCH_HIP_H */

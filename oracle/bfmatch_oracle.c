@@ -1,0 +1,226 @@
+/*
+ * oracle/bfmatch_oracle.c -- CPU restatement of the arithmetic on Fast-Match's
+ * descriptor-matching hot path.  TEST INFRASTRUCTURE ONLY: nothing in the product
+ * path (fast-match_amd/) may call, link or import this file; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * PARITY UNPINNED: the reference has no tests / golden vectors for this path and
+ * its arithmetic lives in an un-vendored, un-pinned third-party dependency
+ * (OpenCV cv2.BFMatcher).  The reference's own .so files are
+ * CPython-2.7 modules that cannot be loaded here.  This file restates OpenCV's
+ * published BFMatcher::knnMatch / cv::batchDistance algorithm (SURVEY.md
+ * Appendix A) as used at the reference's call sites:
+ *
+ *   fastmatch.pyx:122-123, 161-162   BFMatcher(NORM_L2, crossCheck=True).knnMatch(q, t, k=1)
+ *   matchutil.py:39-43 (cache.pyx:250) BFMatcher(NORM_L2, False).knnMatch(d, d, k=2)
+ *   fastmatch.pyx:124, 165           ratio = m.distance / query_dis[m.queryIdx]     (float64)
+ *   fastmatch.pyx:50, 75, 82         accepted = ratio < tau                          (float64)
+ *   Classic Matching.ipynb cell 3    knnMatch(q, t, k=2); m[0].distance / m[1].distance
+ *
+ * It is anchored by hand-derived known-answer tests (tests/test_oracle_kat.py)
+ * and by the Grid_Cache golden vectors generated from the importable
+ * bak/cache.py (tests/golden/).
+ *
+ * Build: see oracle/Makefile  (gcc -O3 -march=x86-64-v3 -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---- distance kernels ---------------------------------------------------- */
+
+/* OpenCV normL2Sqr<float,float>: squared differences accumulated in float32.
+ * Two accumulation orders are restated:
+ *   order 0 ("unrolled4"): OpenCV's generic C++ loop, s += v0*v0+v1*v1+v2*v2+v3*v3
+ *                           per group of four (core/stat.cpp, CV_ENABLE_UNROLLED);
+ *   order 1 ("fma chain"): s = fmaf(v_k, v_k, s), k ascending.  This is the order
+ *                           our device fp32 kernel executes (v_sub_f32 + v_fma_f32),
+ *                           fixed so that non-integer descriptors are bit-comparable.
+ * For integer-valued inputs 0..255 (what OpenCV SIFT emits) every partial sum is an
+ * exact integer <= 8 323 200 < 2^24, so both orders (and any SIMD order OpenCV may
+ * use) give the same bits.                                       */
+static inline float l2sqr_f32_unrolled4(const float* a, const float* b, int n)
+{
+    float s = 0.f;
+    int i = 0;
+    for (; i <= n - 4; i += 4) {
+        float v0 = a[i] - b[i], v1 = a[i + 1] - b[i + 1];
+        float v2 = a[i + 2] - b[i + 2], v3 = a[i + 3] - b[i + 3];
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; i < n; i++) { float v = a[i] - b[i]; s += v * v; }
+    return s;
+}
+
+static inline float l2sqr_f32_fmachain(const float* a, const float* b, int n)
+{
+    float s = 0.f;
+    for (int i = 0; i < n; i++) { float v = a[i] - b[i]; s = fmaf(v, v, s); }
+    return s;
+}
+
+/* OpenCV normL2Sqr<uchar,float> equivalent for CV_8U inputs: integer exact.        */
+static inline float l2sqr_u8(const uint8_t* a, const uint8_t* b, int n)
+{
+    int32_t s = 0;
+    for (int i = 0; i < n; i++) { int32_t v = (int32_t)a[i] - (int32_t)b[i]; s += v * v; }
+    return (float)s;
+}
+
+typedef struct { const void* base; int dim; int kind; /*0=f32 unrolled4, 1=f32 fma, 2=u8*/ } orc_mat;
+
+static inline float dist_row(const orc_mat* A, int64_t i, const orc_mat* B, int64_t j)
+{
+    float d2;
+    if (A->kind == 2)
+        d2 = l2sqr_u8((const uint8_t*)A->base + i * A->dim, (const uint8_t*)B->base + j * B->dim, A->dim);
+    else if (A->kind == 1)
+        d2 = l2sqr_f32_fmachain((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
+    else
+        d2 = l2sqr_f32_unrolled4((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
+    return sqrtf(d2);      /* batchDistance: dist = std::sqrt(normL2Sqr) -- Appendix A.1 */
+}
+
+/* ---- k-NN insertion (cv::batchDistance, Appendix A.2) -------------------- */
+/* For query row i scan train rows j ascending; dist[] pre-filled FLT_MAX, idx[] -1.
+ *   if (d < dist[K-1]) { k = K-2; while (k >= 0 && dist[k] > d) shift; insert at k+1 }
+ * Strict '<' on entry and strict '>' while shifting: among equal distances the lower
+ * train index stays first.                                                          */
+static void knn_rows(const orc_mat* Q, int64_t nq, const orc_mat* T, int64_t nt, int K,
+                     int32_t* idx, float* dist, int threads)
+{
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t i = 0; i < nq; i++) {
+        float* bd = dist + i * K;
+        int32_t* bi = idx + i * K;
+        for (int k = 0; k < K; k++) { bd[k] = FLT_MAX; bi[k] = -1; }
+        for (int64_t j = 0; j < nt; j++) {
+            float d = dist_row(Q, i, T, j);
+            if (d < bd[K - 1]) {
+                int k = K - 2;
+                for (; k >= 0 && bd[k] > d; k--) { bd[k + 1] = bd[k]; bi[k + 1] = bi[k]; }
+                bd[k + 1] = d;
+                bi[k + 1] = (int32_t)j;
+            }
+        }
+        /* entries with idx < 0 are dropped by OpenCV (inner list shorter than k);
+         * we report them as idx -1 / dist +inf                                       */
+        for (int k = 0; k < K; k++) if (bi[k] < 0) bd[k] = INFINITY;
+    }
+}
+
+static orc_mat mk(const void* p, int dim, int kind) { orc_mat m; m.base = p; m.dim = dim; m.kind = kind; return m; }
+
+static int nthreads(int threads)
+{
+#ifdef _OPENMP
+    return threads > 0 ? threads : omp_get_max_threads();
+#else
+    (void)threads; return 1;
+#endif
+}
+
+/* cv2.BFMatcher(NORM_L2, crossCheck=False).knnMatch(Q, T, k)  -- matchutil.py:39-43 */
+ORC_API int orc_bf_knn_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim, int k,
+                           int order, int32_t* idx, float* dist, int threads)
+{
+    if (k < 1 || dim < 1 || (order != 0 && order != 1)) return -1;
+    orc_mat q = mk(Q, dim, order), t = mk(T, dim, order);
+    knn_rows(&q, nq, &t, nt, k, idx, dist, nthreads(threads));
+    return 0;
+}
+
+ORC_API int orc_bf_knn_u8(const uint8_t* Q, int64_t nq, const uint8_t* T, int64_t nt, int dim, int k,
+                          int32_t* idx, float* dist, int threads)
+{
+    if (k < 1 || dim < 1) return -1;
+    orc_mat q = mk(Q, dim, 2), t = mk(T, dim, 2);
+    knn_rows(&q, nq, &t, nt, k, idx, dist, nthreads(threads));
+    return 0;
+}
+
+/* cv2.BFMatcher(NORM_L2, crossCheck=True).knnMatch(Q, T, k=1) -- Appendix A.3:
+ *   batchDistance(T, Q, k=1): for each train row i, tidx[i] = argmin_q d(q, i)
+ *   (lowest q on ties), tdist[i];
+ *   then dist[q] = FLT_MAX, nidx[q] = -1;
+ *   for i in 0..nt-1: q = tidx[i]; if tdist[i] < dist[q]: dist[q] = tdist[i]; nidx[q] = i
+ * Output per query row: train index or -1 (empty inner list, filtered out by the
+ * reference at fastmatch.pyx:123,162), and the distance (+inf when unmatched).       */
+static void xcheck(const orc_mat* Q, int64_t nq, const orc_mat* T, int64_t nt,
+                   int32_t* tidx_out, float* dist_out, int threads)
+{
+    int32_t* rq = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+    float* rd = (float*)malloc(sizeof(float) * (size_t)(nt > 0 ? nt : 1));
+    knn_rows(T, nt, Q, nq, 1, rq, rd, threads);   /* reverse NN: rows = train, scan = query */
+    for (int64_t q = 0; q < nq; q++) { dist_out[q] = FLT_MAX; tidx_out[q] = -1; }
+    for (int64_t i = 0; i < nt; i++) {
+        int32_t q = rq[i];
+        if (q < 0) continue;
+        if (rd[i] < dist_out[q]) { dist_out[q] = rd[i]; tidx_out[q] = (int32_t)i; }
+    }
+    for (int64_t q = 0; q < nq; q++) if (tidx_out[q] < 0) dist_out[q] = INFINITY;
+    free(rq); free(rd);
+}
+
+ORC_API int orc_bf_xcheck1_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim,
+                               int order, int32_t* tidx, float* dist, int threads)
+{
+    if (dim < 1 || (order != 0 && order != 1)) return -1;
+    orc_mat q = mk(Q, dim, order), t = mk(T, dim, order);
+    xcheck(&q, nq, &t, nt, tidx, dist, nthreads(threads));
+    return 0;
+}
+
+ORC_API int orc_bf_xcheck1_u8(const uint8_t* Q, int64_t nq, const uint8_t* T, int64_t nt, int dim,
+                              int32_t* tidx, float* dist, int threads)
+{
+    if (dim < 1) return -1;
+    orc_mat q = mk(Q, dim, 2), t = mk(T, dim, 2);
+    xcheck(&q, nq, &t, nt, tidx, dist, nthreads(threads));
+    return 0;
+}
+
+/* ratio + threshold -- fastmatch.pyx:124,165 (ratio) and :50,75,82 (threshold).
+ * ratio = float64(float32 distance) / float64 selfdist[queryIdx]; accepted = ratio < tau.
+ * NumPy-scalar semantics: x/0 -> inf, 0/0 -> nan, both rejected by '<'.
+ * qrows == NULL means queryIdx == position.                                          */
+ORC_API int orc_ratio_filter(const float* dist, const double* selfdist, const int32_t* qrows,
+                             int64_t n, double tau, double* ratio, uint8_t* pass, int64_t* n_pass)
+{
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t q = qrows ? qrows[i] : i;
+        double r = (double)dist[i] / selfdist[q];
+        if (ratio) ratio[i] = r;
+        uint8_t p = (r < tau) ? 1 : 0;
+        if (pass) pass[i] = p;
+        c += p;
+    }
+    if (n_pass) *n_pass = c;
+    return 0;
+}
+
+/* Classic Ratio-Match (Classic Matching.ipynb cell 3): m[0].distance / m[1].distance
+ * in Python floats (float64).  The notebook would raise ZeroDivisionError when
+ * d2 == 0; we report +inf (d1 > 0) or nan (d1 == 0) instead, both rejected.          */
+ORC_API int orc_lowe_ratio(const float* dist2 /*[n*2]*/, int64_t n, double* ratio)
+{
+    for (int64_t i = 0; i < n; i++) ratio[i] = (double)dist2[2 * i] / (double)dist2[2 * i + 1];
+    return 0;
+}
+
+ORC_API int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
