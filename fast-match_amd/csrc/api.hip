@@ -685,8 +685,51 @@ extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* sel
     return FM_OK;
 }
 
-extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank*, const int32_t*, const int64_t*, const fm_bank*,
-                                  const int64_t*, int64_t, int32_t*, float*, double*)
+extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows, const int64_t* q_off,
+                                  const fm_bank* t, const int64_t* t_off, int64_t n_rounds,
+                                  int32_t* tidx, float* dist, double* ratio)
 {
-    return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: not implemented yet");
+    int rc = check_pair(ctx, q, t, "fm_xcheck1_batched");
+    if (rc != FM_OK) return rc;
+    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: float32 (non-integer) banks are not supported yet");
+    if (n_rounds < 0) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: n_rounds < 0");
+    if (n_rounds == 0) return FM_OK;
+    if (!q_off || !t_off) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: NULL offsets");
+    if (q_off[0] != 0) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: q_off[0] must be 0");
+    int64_t pairs = 0;
+    for (int64_t b = 0; b < n_rounds; ++b) {
+        const int64_t nq = q_off[b + 1] - q_off[b], nt = t_off[b + 1] - t_off[b];
+        if (nq < 0 || nt < 0 || t_off[b] < 0 || t_off[b + 1] > t->n)
+            return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: bad round offsets");
+        if (nq > round_qcap())
+            return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: a round has more than 4096 query rows; use fm_xcheck1 on gathered banks");
+        pairs += nq * nt;
+    }
+    const int64_t tot = q_off[n_rounds];
+    if (tot == 0) return FM_OK;
+    if (!q_rows || !tidx || !dist) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: NULL rows/outputs");
+    for (int64_t i = 0; i < tot; ++i)
+        if (q_rows[i] < 0 || q_rows[i] >= q->n) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: q_rows index out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t i_qoff = 0, i_toff = (size_t)(n_rounds + 1) * 8, i_rows = i_toff + (size_t)(n_rounds + 1) * 8;
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, i_rows + (size_t)tot * 4 + 16)) != FM_OK) return rc;
+    const size_t o_tidx = 0, o_dist = (size_t)tot * 4, o_ratio = ((size_t)tot * 8 + 7) & ~(size_t)7;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_ratio + (size_t)tot * 8 + 16)) != FM_OK) return rc;
+    char* ib = (char*)ctx->ws_in;
+    char* ob = (char*)ctx->ws_out;
+    CallScope cs(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ib + i_qoff, q_off, (size_t)(n_rounds + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ib + i_toff, t_off, (size_t)(n_rounds + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ib + i_rows, q_rows, (size_t)tot * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_rounds(*q, *t, (const int32_t*)(ib + i_rows), (const int64_t*)(ib + i_qoff),
+                               (const int64_t*)(ib + i_toff), n_rounds, (int32_t*)(ob + o_tidx),
+                               (float*)(ob + o_dist), (double*)(ob + o_ratio), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    ctx->pending_pairs += pairs;
+    HIP_TRY(ctx, hipMemcpyAsync(tidx, ob + o_tidx, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dist, ob + o_dist, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ob + o_ratio, (size_t)tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return cs.finish();
 }

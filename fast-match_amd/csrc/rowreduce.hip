@@ -24,16 +24,9 @@
 // L2.  Staging: 128 rows (16 KiB) + 1 KiB aux per step, global_load_lds_dwordx4 into a
 // double buffer, XOR swizzle applied on the source address so that the ds_read_b128
 // A-fragment reads are bank-conflict free.
-#include "fm_internal.h"
+#include "tile_ops.h"
 
 namespace fm {
-
-typedef int v4i  __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-constexpr int kStageRowBytes = kStageRows * kDim;           // 16384
-constexpr int kStageAuxBytes = (kStageRows / kTileRows) * kAuxPerTile * 4;  // 1024
-constexpr int kStageBytes    = kStageRowBytes + kStageAuxBytes;             // 17408
 
 struct RRParams {
     const int8_t*  col_rows;
@@ -76,50 +69,6 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
             *(v4i*)(buf + kStageRowBytes + lane * 16) = *(const v4i*)src;
         }
     }
-}
-
-__device__ __forceinline__ int max16(const v16i& a)
-{
-    int m0 = max(max(a[0], a[1]), a[2]);
-    int m1 = max(max(a[3], a[4]), a[5]);
-    int m2 = max(max(a[6], a[7]), a[8]);
-    int m3 = max(max(a[9], a[10]), a[11]);
-    int m4 = max(max(a[12], a[13]), a[14]);
-    int m5 = max(max(m0, m1), m2);
-    int m6 = max(max(m3, m4), a[15]);
-    return max(m5, m6);
-}
-
-// Exact update of a lane's top-KTOP with the 16 candidates of one tile.
-// hi = 2*acc + npar orders candidates by descending (d2 ascending); candidates arrive in
-// ascending row index within a lane, so strict '>' keeps the lower index on ties
-// (cv::batchDistance insertion rule).
-template <int KTOP>
-__device__ __forceinline__ void exact_update(const v16i& acc, const v16i& np, int idx_base, int nred,
-                                             int (&bh)[KTOP], int (&bi)[KTOP])
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int hi  = (acc[r] << 1) | np[r];
-        const int idx = idx_base + (r & 3) + 8 * (r >> 2);
-        const bool ok = idx < nred;
-        if constexpr (KTOP == 1) {
-            if (ok && hi > bh[0]) { bh[0] = hi; bi[0] = idx; }
-        } else {
-            if (ok && hi > bh[1]) {
-                if (hi > bh[0]) { bh[1] = bh[0]; bi[1] = bi[0]; bh[0] = hi; bi[0] = idx; }
-                else            { bh[1] = hi;    bi[1] = idx; }
-            }
-        }
-    }
-}
-
-// (hi, idx) a is better than b: larger hi, then lower index.  idx < 0 means "none".
-__device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
-{
-    if (ai < 0) return false;
-    if (bi_ < 0) return true;
-    return ah > bh_ || (ah == bh_ && ai < bi_);
 }
 
 template <int NB, int KTOP, bool GLDS>
@@ -181,13 +130,7 @@ void rowreduce_kernel(RRParams p)
             v4i af[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(buf + tt * (kTileRows * kDim) + aoff[c]);
-            v16i ci;
-            {
-                const v4i* ax = (const v4i*)(buf + xoff + tt * (kAuxPerTile * 4));
-                const v4i c0 = ax[0], c1 = ax[1], c2 = ax[2], c3 = ax[3];
-                ci = v16i{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3],
-                          c2[0], c2[1], c2[2], c2[3], c3[0], c3[1], c3[2], c3[3]};
-            }
+            const v16i ci = lds_read16(buf + xoff + tt * (kAuxPerTile * 4));
             v16i acc[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[j][0], ci, 0, 0, 0);
@@ -201,10 +144,7 @@ void rowreduce_kernel(RRParams p)
             for (int j = 0; j < NB; ++j) {
                 const int tmax = max16(acc[j]);
                 if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                    const v4i* nx = (const v4i*)(buf + xoff + tt * (kAuxPerTile * 4) + 128);
-                    const v4i n0 = nx[0], n1 = nx[1], n2 = nx[2], n3 = nx[3];
-                    const v16i np = v16i{n0[0], n0[1], n0[2], n0[3], n1[0], n1[1], n1[2], n1[3],
-                                         n2[0], n2[1], n2[2], n2[3], n3[0], n3[1], n3[2], n3[3]};
+                    const v16i np = lds_read16(buf + xoff + tt * (kAuxPerTile * 4) + 128);
                     exact_update<KTOP>(acc[j], np, st * kStageRows + tt * kTileRows + 4 * h, p.nred, bh[j], bi[j]);
                     // A candidate enters the top-K only if 2*acc+npar > bh[K-1], possible iff acc >= ceil(bh[K-1]/2).
                     thr[j] = (bi[j][KTOP - 1] >= 0) ? ((bh[j][KTOP - 1] + 1) >> 1) : INT32_MIN;

@@ -1,0 +1,221 @@
+"""Fast-Match on the MI355X: ``match(query_cache, target_img, options)(tau)``.
+
+Mirrors ``fastmatch.pyx`` of the reference (same function names, option keys, return
+shapes and log schema):
+
+* ``match``          reference ``fastmatch.pyx:32-53``  -- options, Grid_Cache, seeding,
+                     returns the closure ``get_matches(tau)``
+* ``match_thumbs``   reference ``fastmatch.pyx:107-141`` -- thumbnail seeding
+* ``do_iter``        reference ``fastmatch.pyx:56-89``  -- depth-first cell expansion
+* ``get_neighbors``  reference ``fastmatch.pyx:92-103``
+* ``match_position`` reference ``fastmatch.pyx:145-169`` -- one expansion round
+* ``log_round``      reference ``fastmatch.pyx:172-180``
+
+What runs where: the descriptor arithmetic of every round -- OpenCV's
+``BFMatcher(NORM_L2, crossCheck=True).knnMatch`` plus the float64 ratio -- is one launch
+of the HIP round kernel on banks that stay resident on the device (the query bank with
+its self distances, one bank per computed grid cell).  Only the query-row indices of the
+radius subset go up and the per-slot (train index, distance, ratio) triples come back.
+The expansion loop itself is replayed on the host in the reference's exact depth-first
+order, because the match set depends on that order.
+
+``target_img`` is either the reference's ``uint8[H, W, 3]`` array (SIFT through OpenCV on
+the host, needs ``cv2``) or a ``cache.Feature_Image`` carrying pre-extracted features.
+Extra option keys (additions): ``"context"``/``"device"`` select the GPU,
+``"stats"`` (a dict) receives round/pair counters.
+"""
+from collections import deque
+
+import numpy as np
+
+from . import matchutil
+from .cache import Grid_Cache, Metric_Cache, Feature_Image, keypoint_positions   # noqa: F401
+from .imaging import get_thumbnail, get_size
+
+
+def match(query_cache, target_img, options={}):
+    thumb_x, thumb_y = options.get("thumb_size", (400, 400))
+    grid_x, grid_y = options.get("grid_size", (50, 50))
+    thumb_strategy = options.get("thumb_strategy", lambda n: n)
+    log = options.get("log", None)
+    grid_margin = options.get("grid_margin", 25)
+    radius = options.get("radius", 100)
+    stats = options.get("stats", None)
+    context = matchutil._context(options)
+
+    if isinstance(target_img, Feature_Image):
+        cell_features = target_img
+    else:
+        cell_features = options.get("feature_function", matchutil.get_features)
+    target_cache = Grid_Cache(target_img, (grid_x, grid_y), cell_features, margin=grid_margin)
+    thumb_positions, thumb_ratios = match_thumbs(target_img, query_cache, thumb_x=thumb_x, thumb_y=thumb_y,
+                                                 context=context)
+
+    # A function where tau can be varied to get different results
+    def get_matches(tau):
+        thumb_tau = thumb_strategy(tau)
+        seeds = thumb_positions[thumb_ratios < thumb_tau]
+        return do_iter(iter(seeds), query_cache, target_cache, tau=tau, thumb_tau=thumb_tau,
+                       radius=radius, log=log, context=context, stats=stats)
+
+    return get_matches
+
+
+def do_iter(positions, cache, target_grid, tau, thumb_tau=None, radius=100, log=None, context=None,
+            stats=None):
+    """Depth-first expansion.  ``positions`` yields [2,2] arrays (query_pos, target_pos);
+    neighbours found in a round are visited before the remaining seeds, in the order the
+    accepted matches produced them (reference fastmatch.pyx:75-77)."""
+    context = context or matchutil._context({})
+    pending = deque()
+    seeds = iter(positions)
+    matches = []
+    has_matched = set()
+    found_matches = {}
+    n_rounds = n_pairs = 0
+    while True:
+        if pending:
+            query_pos, target_pos = pending.popleft()
+        else:
+            try:
+                query_pos, target_pos = next(seeds)
+            except StopIteration:
+                break
+        col, row = target_grid.block(target_pos[0], target_pos[1])
+        query_col, query_row = target_grid.block(query_pos[0], query_pos[1])
+        key = (col, row, query_col, query_row)
+        if key in has_matched:
+            continue
+        has_matched.add(key)
+        result_pos, ratios, query_idx, pairs = _match_position((query_pos, target_pos), cache, target_grid,
+                                                               radius, context)
+        n_rounds += 1
+        n_pairs += pairs
+        accepted = ratios < tau
+        acc_pos = result_pos[accepted]
+        # For each match we keep, the neighbouring cell on its side is examined next
+        neighbors = get_neighbors(target_pos, acc_pos, target_grid)
+        if len(neighbors) > 0:
+            pending.extendleft(reversed(neighbors))
+        if log is not None:
+            log.append(log_round(query_pos, target_pos, result_pos, target_grid, ratios, tau, radius))
+        for p, r, index in zip(acc_pos, ratios[accepted], query_idx[accepted]):
+            p_tuple = [int(p[0, 0]), int(p[0, 1]), int(p[1, 0]), int(p[1, 1])]
+            r = float(r)
+            seen = found_matches.get(r)
+            if seen is None:
+                found_matches[r] = [p_tuple]
+            elif p_tuple in seen:
+                continue
+            else:
+                seen.append(p_tuple)
+            matches.append((int(index), {"positions": p, "ratio": r}))
+    if stats is not None:
+        stats["rounds"] = stats.get("rounds", 0) + n_rounds
+        stats["pairs"] = stats.get("pairs", 0) + n_pairs
+    return matches
+
+
+def get_neighbors(target_pos, result_pos, target_grid):
+    col, row = target_grid.block(target_pos[0], target_pos[1])
+    neighbors = []
+    for p_query, p_target in result_pos:
+        neighbor_pos = target_grid.get_neighbor(col, row, p_target[0], p_target[1])
+        if neighbor_pos[0] != -1:
+            neighbors.append(np.array((p_query, neighbor_pos), dtype=np.float64))
+    return neighbors
+
+
+def _thumb_features(img, thumb_x, thumb_y):
+    """(thumbnail positions [n,2], descriptors, (thumb_w, thumb_h)) of the target."""
+    if isinstance(img, Feature_Image):
+        if img.thumb is None:
+            raise ValueError("Feature_Image has no thumbnail features (thumb_positions/thumb_descriptors)")
+        return img.thumb["positions"], img.thumb["descriptors"], img.thumb["size"]
+    target = get_thumbnail(img, (thumb_x, thumb_y))
+    t_keypoints, t_descriptors = matchutil.get_features(target)
+    return keypoint_positions(t_keypoints), t_descriptors, (target.shape[1], target.shape[0])
+
+
+def match_thumbs(img, query_cache, thumb_x=400, thumb_y=400, context=None):
+    """Seeding: cross-checked 1-NN between the thumbnail banks, ratio against the query
+    thumbnail's self distances, positions scaled to full resolution, sorted by ratio
+    (stable sort; the reference's quicksort leaves equal ratios in unspecified order)."""
+    context = context or matchutil._context({})
+    t_orig_x, t_orig_y = get_size(img)
+    t_thumb_pos, t_descriptors, t_size = _thumb_features(img, thumb_x, thumb_y)
+    q_thumb_pos = query_cache.thumb["positions"]
+    if t_descriptors is None or len(t_descriptors) == 0 or len(q_thumb_pos) == 0:
+        return np.zeros((0, 2, 2), dtype=np.float64), np.zeros(0, dtype=np.float64)
+
+    t_bank = context.bank(np.asarray(t_descriptors))
+    try:
+        tidx, dist, ratio, _, _ = context.match_ratio(query_cache.thumb_bank(context), t_bank, np.inf)
+    finally:
+        t_bank.close()
+    m = tidx >= 0                                 # non-empty inner lists, query order
+    ratios = ratio[m]
+    t_pos = np.asarray(t_thumb_pos, dtype=np.float64)[tidx[m]]
+    q_pos = np.asarray(q_thumb_pos, dtype=np.float64)[m]
+
+    t_ratio = np.array([t_orig_x / float(t_size[0]), t_orig_y / float(t_size[1])])
+    q_ratio = np.array([query_cache.original["size"][0] / float(query_cache.thumb["size"][0]),
+                        query_cache.original["size"][1] / float(query_cache.thumb["size"][1])])
+    pos_scaled = np.stack([q_pos * q_ratio, t_pos * t_ratio], axis=1) if len(ratios) else \
+        np.zeros((0, 2, 2), dtype=np.float64)
+    indices = np.argsort(ratios, kind="stable")
+    return pos_scaled[indices], ratios[indices]
+
+
+def _match_position(pos, query_cache, target, radius, context):
+    """One round; returns (positions [m,2,2], ratios [m], indices [m], pairs evaluated)."""
+    # the reference declares these as C ints: truncation toward zero (fastmatch.pyx:147-150)
+    query_x, query_y = int(pos[0][0]), int(pos[0][1])
+    target_x, target_y = int(pos[1][0]), int(pos[1][1])
+    empty = (np.array([]), np.array([]), np.array([]), 0)
+
+    query_idx = query_cache.radius_indices(query_x, query_y, radius)
+    target_kp, target_ds = target.get(target_x, target_y)
+    if target_ds is None or len(target_ds) == 0:
+        return empty
+    col, row = target.block(target_x, target_y)
+    t_bank = target.cell_bank(col, row, context)
+    nq, nt = len(query_idx), len(target_ds)
+    if nq == 0:
+        return (np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64), 0)
+    offset_x, offset_y = target.offset(target_x, target_y)
+
+    q_bank = query_cache.bank(context)
+    if nq <= 4096:
+        tidx, dist, ratio = context.xcheck1_batched(q_bank, query_idx, [0, nq], t_bank, [0, nt])
+    else:
+        # oversize radius subset: gather it into a bank of its own and use the dense path
+        sub = context.bank(query_cache.original["descriptors"][query_idx])
+        try:
+            sub.set_selfdist(query_cache.original["distances"][query_idx])
+            tidx, dist, ratio, _, _ = context.match_ratio(sub, t_bank, np.inf)
+        finally:
+            sub.close()
+    m = tidx >= 0
+    target_pos = keypoint_positions(target_kp) + np.array([offset_x, offset_y], dtype=np.float64)
+    positions = np.stack([query_cache.original["positions"][query_idx[m]], target_pos[tidx[m]]], axis=1) \
+        if m.any() else np.zeros((0, 2, 2))
+    return positions, ratio[m], query_idx[m], nq * nt
+
+
+def match_position(pos, query_cache, target, radius=100, context=None):
+    context = context or matchutil._context({})
+    positions, ratios, indices, _ = _match_position(pos, query_cache, target, radius, context)
+    return positions, ratios, indices
+
+
+def log_round(query_pos, target_pos, result_pos, target_grid, ratios, tau, radius):
+    keep = ratios < tau
+    return {
+        "query_pos": query_pos,
+        "target_pos": target_pos,
+        "target_grid": target_grid.last,
+        "matches": result_pos[keep],
+        "radius": radius,
+        "ratios": ratios[keep],
+        "margin": target_grid.margin}

@@ -39,3 +39,61 @@ def planted_pair(nq, nt, seed, p=0.3, sigma=6.0, dim=128):
         Q[qsel] = np.clip(T[tsel].astype(np.float64) + noise, 0, 255).astype(np.uint8)
         planted[qsel] = tsel
     return Q, T, planted
+
+
+def _thumb_dims(size, box):
+    s = min(float(box[0]) / size[0], float(box[1]) / size[1], 1.0)
+    return (max(1, int(size[0] * s)), max(1, int(size[1] * s)))
+
+
+def image_pair(size, n_keypoints, seed, p=0.3, sigma=6.0, shift=(37.0, -21.0), jitter=2.0,
+               n_thumb=600, q_thumb_box=(600, 600), t_thumb_box=(400, 400)):
+    """A synthetic query/target image pair as pre-extracted features.
+
+    Keypoint positions are uniform in the image; a fraction p of the query keypoints are
+    planted copies of distinct target keypoints: descriptor = noisy copy, position =
+    target position - shift + N(0, jitter), so accepted matches propagate the expansion.
+    Thumbnail banks are a subset of the keypoints (planted pairs first) with positions
+    scaled to the thumbnail sizes and freshly perturbed descriptors.
+
+    Returns (query, target) dicts:
+      query : descriptors u8[n,128], positions f64[n,2], size, thumb_descriptors,
+              thumb_positions, thumb_size
+      target: same keys; plus 'planted' int64[n] on the query (target row or -1)."""
+    w, h = size
+    rng = np.random.default_rng(seed)
+    T = synth_sift(n_keypoints, rng)
+    Q = synth_sift(n_keypoints, rng)
+    t_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
+    q_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
+    planted = np.full(n_keypoints, -1, dtype=np.int64)
+    k = int(round(p * n_keypoints))
+    qsel = rng.choice(n_keypoints, size=k, replace=False)
+    tsel = rng.choice(n_keypoints, size=k, replace=False)
+    Q[qsel] = np.clip(T[tsel].astype(np.float64) + np.rint(rng.normal(0.0, sigma, (k, 128))), 0, 255).astype(np.uint8)
+    qp = t_pos[tsel] - np.array(shift) + rng.normal(0.0, jitter, (k, 2))
+    q_pos[qsel] = np.clip(qp, 0.0, [w - 1.0, h - 1.0])
+    planted[qsel] = tsel
+    # thumbnails: planted pairs first, then unrelated keypoints on both sides
+    n_thumb = min(n_thumb, n_keypoints)
+    kp = min(k, n_thumb // 2)
+    pick = rng.choice(k, size=kp, replace=False) if kp else np.zeros(0, dtype=np.int64)
+    rest_q = rng.choice(n_keypoints, size=n_thumb - kp, replace=False)
+    rest_t = rng.choice(n_keypoints, size=n_thumb - kp, replace=False)
+    q_rows = np.concatenate([qsel[pick], rest_q])
+    t_rows = np.concatenate([tsel[pick], rest_t])
+    q_ts, t_ts = _thumb_dims(size, q_thumb_box), _thumb_dims(size, t_thumb_box)
+
+    def thumb(desc, pos, rows, tsize):
+        d = np.clip(desc[rows].astype(np.float64) + np.rint(rng.normal(0.0, 3.0, (len(rows), 128))), 0, 255)
+        scale = np.array([tsize[0] / float(w), tsize[1] / float(h)])
+        o = rng.permutation(len(rows))
+        return d.astype(np.uint8)[o], (pos[rows] * scale)[o]
+
+    qtd, qtp = thumb(Q, q_pos, q_rows, q_ts)
+    ttd, ttp = thumb(T, t_pos, t_rows, t_ts)
+    query = {"descriptors": Q, "positions": q_pos, "size": (w, h), "thumb_descriptors": qtd,
+             "thumb_positions": qtp, "thumb_size": q_ts, "planted": planted}
+    target = {"descriptors": T, "positions": t_pos, "size": (w, h), "thumb_descriptors": ttd,
+              "thumb_positions": ttp, "thumb_size": t_ts}
+    return query, target

@@ -96,6 +96,13 @@ static inline float dist_row(const orc_mat* A, int64_t i, const orc_mat* B, int6
 static void knn_rows(const orc_mat* Q, int64_t nq, const orc_mat* T, int64_t nt, int K,
                      int32_t* idx, float* dist, int threads)
 {
+    /* small problems (expansion rounds are ~400 x 125) run on one thread: a fork-join
+     * over every host core costs more than the work itself                              */
+    {
+        int64_t cap = (nq * nt) / 400000 + 1;
+        if (cap < threads) threads = (int)cap;
+        if (threads < 1) threads = 1;
+    }
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int64_t i = 0; i < nq; i++) {
         float* bd = dist + i * K;

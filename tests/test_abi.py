@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fastmatch_hip.h declares;
+without a GPU the product path fails loudly instead of falling back."""
+import os
+import re
+
+import pytest
+
+import fastmatch_amd
+from fastmatch_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "fastmatch_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(fm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 15
+    lib = _ffi.load_library()
+    for n in names:
+        assert hasattr(lib, n), "libfastmatch_hip.so does not export %s" % n
+        assert n in _ffi.SYMBOLS, "ctypes binding lacks %s" % n
+    assert sorted(_ffi.SYMBOLS) == names, "binding declares symbols the header does not"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(fastmatch_amd.FastMatchHipError) as e:
+        fastmatch_amd.Context(0)
+    assert "no CPU fallback" in str(e.value)
+    from fastmatch_amd import matchutil
+    import numpy as np
+    with pytest.raises(fastmatch_amd.FastMatchHipError):
+        matchutil.bf_match(np.zeros((2, 128), np.uint8), np.zeros((2, 128), np.uint8), k=2)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "fast-match_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src, f

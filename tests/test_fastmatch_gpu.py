@@ -1,0 +1,77 @@
+"""GPU: the product fastmatch.match()/Metric_Cache/Grid_Cache surface (HIP rounds, host
+expansion loop) against the oracle's restatement of fastmatch.pyx on synthetic image pairs:
+identical match lists (indices, positions, ratios), round counts and logs."""
+import numpy as np
+import pytest
+
+from fastmatch_amd import fastmatch, cache, synth
+from oracle import fastmatch_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(size, n, seed, ctx, **kw):
+    q, t = synth.image_pair(size, n, seed, **kw)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"],
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"],
+                          "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"],
+                    "size": t["thumb_size"]}}
+    return mc, fi, oq, ot
+
+
+def _same_matches(a, b):
+    assert len(a) == len(b)
+    for (ia, da), (ib, db) in zip(a, b):
+        assert ia == ib and da["ratio"] == db["ratio"]
+        assert np.array_equal(da["positions"], db["positions"])
+
+
+@pytest.mark.parametrize("size,n,opts", [
+    ((800, 640), 3000, {}),                                                    # graf-sized, default options
+    ((800, 640), 3000, {"grid_size": (75, 75), "grid_margin": 30, "radius": 50}),  # Fast Matching.ipynb options
+    ((1000, 1000), 12500, {}),                                                 # one C4 pair
+    ((611, 389), 2500, {"grid_size": (64, 48), "grid_margin": 0, "radius": 75, "thumb_strategy": lambda t: t * 1.2}),
+])
+def test_match_equals_oracle(ctx, size, n, opts):
+    mc, fi, oq, ot = _build(size, n, seed=size[0] + n, ctx=ctx)
+    assert np.array_equal(mc.original["distances"], oq.distances)
+    assert np.array_equal(mc.thumb["distances"], oq.thumb["distances"])
+    log, olog, stats = [], [], {}
+    o = dict(opts, log=log, context=ctx, stats=stats)
+    get = fastmatch.match(mc, fi, o)
+    oget = fo.o_match(oq, ot, dict(opts, log=olog))
+    for tau in (0.7, 0.9, 0.5):
+        del log[:], olog[:]
+        stats.clear()
+        got, exp = get(tau), oget(tau)
+        _same_matches(got, exp)
+        assert stats["rounds"] == oget.rounds == len(log) == len(olog)
+        for a, b in zip(log, olog):
+            assert np.array_equal(a["query_pos"], b["query_pos"]) and np.array_equal(a["target_pos"], b["target_pos"])
+            assert a["target_grid"] == b["target_grid"] and a["radius"] == b["radius"] and a["margin"] == b["margin"]
+            assert np.array_equal(a["matches"], b["matches"]) and np.array_equal(a["ratios"], b["ratios"])
+    assert len(got) > 0
+
+
+def test_seeds_equal_oracle(ctx):
+    mc, fi, oq, ot = _build((800, 640), 3000, seed=5, ctx=ctx)
+    pos, ratios = fastmatch.match_thumbs(fi, mc, context=ctx)
+    opos, oratios = fo.o_match_thumbs(oq, ot["thumb"], ot["size"])
+    assert np.array_equal(pos, opos) and np.array_equal(ratios, oratios)
+    assert np.all(np.diff(ratios) >= 0) and len(ratios) > 50
+
+
+def test_match_position_round(ctx):
+    mc, fi, oq, ot = _build((800, 640), 3000, seed=6, ctx=ctx)
+    grid = cache.Grid_Cache(fi, (50, 50), fi, margin=25)
+    ogrid = fo.OGrid(ot["size"], (50, 50), 25, ot["positions"], ot["descriptors"])
+    for pos in [((400.7, 300.2), (420.9, 280.1)), ((10.0, 10.0), (0.0, 0.0)), ((799.0, 639.0), (800.0, 640.0))]:
+        p, r, i = fastmatch.match_position(pos, mc, grid, radius=100, context=ctx)
+        op, orr, oi = fo.o_match_position(pos, oq, ogrid, 100)
+        assert np.array_equal(p, op) and np.array_equal(r, orr) and np.array_equal(i, oi)

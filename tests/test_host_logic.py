@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the product package against brute-force restatements."""
+import os
+
+import numpy as np
+import pytest
+
+from fastmatch_amd import cache, matchutil, synth
+from oracle.fastmatch_oracle import OGrid, OQuery
+
+
+def test_position_index_matches_bruteforce_order_and_boundary():
+    rng = np.random.default_rng(5)
+    pos = np.floor(rng.uniform(0, 300, (3000, 2)))          # integer coords: many exact ties
+    pos[10] = pos[11] = pos[12]                              # coincident keypoints (SIFT orientations)
+    idx = cache.Position_Index(pos, bucket=37.0)
+    oq = OQuery(np.zeros((3000, 4), np.uint8), pos, (300, 300), distances=np.ones(3000))
+    for (x, y, r) in [(150, 150, 100), (0, 0, 50), (299, 10, 75), (pos[10, 0], pos[10, 1], 0),
+                      (150.7, 20.2, 5), (1000, 1000, 10)]:
+        got, d2 = idx.radius(int(x), int(y), int(r))
+        exp = oq.get(x, y, r)[3]
+        assert np.array_equal(got, exp)
+        assert np.all(d2 <= int(r) ** 2)
+    # inclusive boundary: a point at distance exactly r
+    p = np.array([[0.0, 0.0], [3.0, 4.0], [3.0, 4.1]])
+    got, _ = cache.Position_Index(p).radius(0, 0, 5)
+    assert got.tolist() == [0, 1]
+
+
+def test_query_radius_sklearn_like_shape():
+    pos = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 2.0], [5.0, 5.0]])
+    tree = cache.Position_Index(pos)
+    inds, dists = tree.query_radius(np.array((0, 0)), r=2, return_distance=True, sort_results=True)
+    assert inds[0].tolist() == [0, 1, 2] and dists[0].tolist() == [0.0, 1.0, 2.0]
+
+
+def test_metric_cache_get_truncates_and_orders():
+    q, _ = synth.image_pair((400, 300), 500, seed=3)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"],
+                                        distances=np.ones(500))
+    oq = OQuery(q["descriptors"], q["positions"], q["size"], distances=np.ones(500))
+    ds, ps, dis, idx = mc.get(120.9, 80.9, 60.9)              # C-int truncation: (120, 80, 60)
+    eds, eps, edis, eidx = oq.get(120, 80, 60)
+    assert np.array_equal(idx, eidx) and np.array_equal(ds, eds) and np.array_equal(ps, eps)
+    assert len(idx) > 0
+
+
+def test_feature_image_cells_match_oracle_grid():
+    _, t = synth.image_pair((500, 333), 2000, seed=9)
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"])
+    g = cache.Grid_Cache(fi, (50, 50), fi, margin=25)
+    o = OGrid(t["size"], (50, 50), 25, t["positions"], t["descriptors"])
+    for (x, y) in [(0, 0), (499, 332), (500, 333), (260, 170), (75, 25), (30, 310)]:
+        kp, ds = g.get(x, y)
+        okp, ods = o.get(x, y)
+        assert np.array_equal(kp, okp)
+        assert (ds is None and ods is None) or np.array_equal(ds, ods)
+        assert g.last == o.last
+
+
+def test_ripemd160_known_answers():
+    import hashlib
+    orig = hashlib.new
+    try:
+        def boom(*a, **k):
+            raise ValueError("unsupported")
+        hashlib.new = boom                                    # force the pure-Python path
+        assert cache._ripemd160(b"") == "9c1185a5c5e9fc54612808977ee8f548b2258d31"
+        assert cache._ripemd160(b"abc") == "8eb208f7e05d987a9b044a8e98c6b087f15a0bfc"
+        assert cache._ripemd160(b"message digest") == "5d0689ef49d2fae572b881b123a85ffa21595f36"
+        assert cache._ripemd160(b"a" * 1000000)[:8] == "52783243"
+    finally:
+        hashlib.new = orig
+
+
+def test_metric_cache_save_load_roundtrip(tmp_path):
+    q, _ = synth.image_pair((200, 200), 300, seed=4, n_thumb=50)
+    sd = np.linspace(1, 2, 300)
+    tsd = np.linspace(2, 3, 50)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], distances=sd,
+                                        thumb_distances=tsd, path=b"images/graf/img4.ppm")
+    name = mc.save(str(tmp_path))
+    assert name == cache._ripemd160(b"images/graf/img4.ppm")
+    assert os.path.isfile(os.path.join(str(tmp_path), name + ".npz"))
+    assert os.path.isfile(os.path.join(str(tmp_path), name + "_thumb.npz"))
+    with np.load(os.path.join(str(tmp_path), name + ".npz")) as z:   # the reference's key set
+        assert set(z.files) == {"descriptors", "positions", "distances", "position_tree", "size"}
+    mc2 = cache.Metric_Cache(None)
+    mc2.path = b"images/graf/img4.ppm"
+    assert mc2.load(str(tmp_path))
+    for k in ("descriptors", "positions", "distances"):
+        assert np.array_equal(mc2.original[k], mc.original[k])
+        assert np.array_equal(mc2.thumb[k], mc.thumb[k])
+    assert mc2.original["size"] == (200, 200) and mc2.thumb["size"] == mc.thumb["size"]
+    assert np.array_equal(mc2.get(100, 100, 50)[3], mc.get(100, 100, 50)[3])
+    mc3 = cache.Metric_Cache(None)
+    mc3.path = b"some/other/path"
+    assert mc3.load(str(tmp_path)) is False
+
+
+def test_matches_from_arrays_drops_missing():
+    idx = np.array([[2, -1], [0, 1]], dtype=np.int32)
+    dist = np.array([[1.5, np.inf], [0.0, 2.0]], dtype=np.float32)
+    m = matchutil.matches_from_arrays(idx, dist)
+    assert [len(r) for r in m] == [1, 2]
+    assert (m[0][0].queryIdx, m[0][0].trainIdx, m[0][0].distance, m[0][0].imgIdx) == (0, 2, 1.5, 0)
+    m1 = matchutil.matches_from_arrays(np.array([-1, 3]), np.array([np.inf, 2.0], dtype=np.float32))
+    assert m1[0] == [] and m1[1][0].trainIdx == 3
+
+
+def test_synth_is_deterministic_and_sift_like():
+    a = synth.planted_pair(200, 300, seed=1)
+    b = synth.planted_pair(200, 300, seed=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    Q, T, planted = a
+    assert Q.dtype == np.uint8 and Q.shape == (200, 128) and (planted >= 0).sum() == 60
+    norms = np.linalg.norm(T.astype(np.float64), axis=1)
+    assert 400 < norms.mean() < 620                             # ~512 like OpenCV SIFT

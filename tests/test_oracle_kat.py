@@ -1,0 +1,94 @@
+"""CPU: pins the oracle to hand-derived OpenCV-semantics known answers (the reference
+holds no golden vectors for the matcher: SURVEY.md 8(c), 'parity unpinned')."""
+import numpy as np
+import pytest
+
+import oracle
+from kat import xcheck_cases, knn2_cases, selfdist_case
+
+
+@pytest.mark.parametrize("case", xcheck_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("as_f32", [False, True])
+def test_xcheck_kat(case, as_f32):
+    _, Q, T, etidx, edist = case
+    if as_f32:
+        Q, T = Q.astype(np.float32), T.astype(np.float32)
+    tidx, dist = oracle.bf_xcheck1(Q, T)
+    assert tidx.tolist() == etidx
+    assert np.array_equal(dist, np.array(edist, dtype=np.float32))
+
+
+@pytest.mark.parametrize("case", knn2_cases(), ids=lambda c: c[0])
+def test_knn2_kat(case):
+    _, Q, T, eidx, edist = case
+    idx, dist = oracle.bf_knn(Q, T, 2)
+    assert idx.tolist() == eidx
+    assert np.array_equal(dist, np.array(edist, dtype=np.float32))
+
+
+def test_selfdist_kat():
+    D, exp = selfdist_case()
+    assert oracle.self_dist(D).tolist() == exp
+
+
+def test_empty_query():
+    tidx, dist = oracle.bf_xcheck1(np.zeros((0, 128), np.uint8), np.zeros((5, 128), np.uint8))
+    assert tidx.shape == (0,) and dist.shape == (0,)
+    idx, d = oracle.bf_knn(np.zeros((0, 128), np.uint8), np.zeros((5, 128), np.uint8), 2)
+    assert idx.shape == (0, 2)
+
+
+def test_ratio_filter_semantics():
+    # float64 division of float32 distance by float64 self distance; x/0 -> inf, 0/0 -> nan;
+    # both rejected by '<' (fastmatch.pyx:165, :75)
+    dist = np.array([3.0, 0.0, 2.0, 7.0], dtype=np.float32)
+    selfd = np.array([4.0, 0.0, 0.0, 10.0], dtype=np.float64)
+    ratio, passed = oracle.ratio_filter(dist, selfd, 0.75)
+    assert ratio[0] == 0.75 and np.isnan(ratio[1]) and np.isinf(ratio[2]) and ratio[3] == 0.7
+    assert passed.tolist() == [False, False, False, True]      # 0.75 < 0.75 is False
+    # float64, not float32: a ratio that differs from tau only beyond float32 precision
+    d = np.float32(0.7) * np.float32(3.0)
+    r, p = oracle.ratio_filter(np.array([d], np.float32), np.array([3.0]), 0.7)
+    assert r[0] == float(d) / 3.0 and bool(p[0]) == (float(d) / 3.0 < 0.7)
+    # qrows indirection
+    r, p = oracle.ratio_filter(np.array([5.0], np.float32), np.array([1.0, 10.0]), 0.7, qrows=[1])
+    assert r[0] == 0.5 and p[0]
+
+
+def test_accumulation_orders_agree_on_integer_valued_input():
+    rng = np.random.default_rng(3)
+    Q = rng.integers(0, 256, (64, 128)).astype(np.float32)
+    T = rng.integers(0, 256, (80, 128)).astype(np.float32)
+    a = oracle.bf_knn(Q, T, 2, order=0)
+    b = oracle.bf_knn(Q, T, 2, order=1)
+    c = oracle.bf_knn(Q.astype(np.uint8), T.astype(np.uint8), 2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_against_numpy_bruteforce():
+    rng = np.random.default_rng(11)
+    Q = rng.integers(0, 256, (150, 128), dtype=np.uint8)
+    T = rng.integers(0, 256, (97, 128), dtype=np.uint8)
+    T[5] = T[9]                                     # duplicate train rows: index tie-break
+    Q[3] = T[9]
+    d2 = ((Q[:, None, :].astype(np.int64) - T[None].astype(np.int64)) ** 2).sum(-1)
+    idx, dist = oracle.bf_knn(Q, T, 2)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, order)
+    assert np.array_equal(dist, np.sqrt(np.take_along_axis(d2, order, 1).astype(np.float32)))
+    assert idx[3].tolist() == [5, 9]
+    tidx, xd = oracle.bf_xcheck1(Q, T)
+    rq = np.argmin(d2, axis=0)                      # first minimum = lowest q
+    exp = np.full(len(Q), -1)
+    best = np.full(len(Q), np.inf)
+    for t in range(len(T)):
+        if d2[rq[t], t] < best[rq[t]]:
+            best[rq[t]], exp[rq[t]] = d2[rq[t], t], t
+    assert np.array_equal(tidx, exp)
+    assert np.array_equal(xd[exp >= 0], np.sqrt(best[exp >= 0].astype(np.float32)))
+
+
+def test_dtype_mismatch_raises():
+    with pytest.raises(TypeError):
+        oracle.bf_xcheck1(np.zeros((2, 4), np.uint8), np.zeros((2, 4), np.float32))

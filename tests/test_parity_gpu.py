@@ -1,0 +1,278 @@
+"""GPU: the HIP path (through the C-ABI) against the oracle -- bit-exact indices,
+distances (float32 bits) and ratio pass/fail on the same seeded inputs -- plus
+size-independent properties at BASELINE.json's full 100k x 100k size."""
+import numpy as np
+import pytest
+
+import oracle
+from fastmatch_amd import synth, matchutil, _ffi
+from kat import xcheck_cases, knn2_cases, selfdist_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.parametrize("case", xcheck_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("as_f32", [False, True])
+def test_xcheck_kat(ctx, case, as_f32):
+    _, Q, T, etidx, edist = case
+    if as_f32:
+        Q, T = Q.astype(np.float32), T.astype(np.float32)
+    tidx, dist = ctx.xcheck1(ctx.bank(Q), ctx.bank(T))
+    assert tidx.tolist() == etidx
+    assert _eq(dist, np.array(edist, dtype=np.float32))
+
+
+@pytest.mark.parametrize("case", knn2_cases(), ids=lambda c: c[0])
+def test_knn2_kat(ctx, case):
+    _, Q, T, eidx, edist = case
+    idx, dist = ctx.knn2(ctx.bank(Q), ctx.bank(T))
+    assert idx.tolist() == eidx
+    assert _eq(dist, np.array(edist, dtype=np.float32))
+
+
+def test_selfdist_kat(ctx):
+    D, exp = selfdist_case()
+    assert ctx.self_dist(ctx.bank(D)).tolist() == exp
+
+
+def test_empty_inputs(ctx):
+    e = ctx.bank(np.zeros((0, 128), np.uint8))
+    t = ctx.bank(np.ones((5, 128), np.uint8))
+    tidx, dist = ctx.xcheck1(e, t)
+    assert tidx.shape == (0,) and dist.shape == (0,)
+    idx, d = ctx.knn2(e, t)
+    assert idx.shape == (0, 2)
+    tidx, dist = ctx.xcheck1(t, e)                     # empty train: all unmatched
+    assert tidx.tolist() == [-1] * 5 and np.all(np.isinf(dist))
+    idx, d = ctx.knn2(t, e)
+    assert idx.tolist() == [[-1, -1]] * 5 and np.all(np.isinf(d))
+    assert ctx.self_dist(e).shape == (0,)
+
+
+SIZES = [(1, 1), (2, 1), (1, 2), (31, 33), (32, 32), (33, 31), (127, 129), (128, 128), (129, 127),
+         (393, 125), (125, 393), (1000, 1), (1, 1000), (640, 513), (2049, 1027), (5000, 4096)]
+
+
+@pytest.mark.parametrize("nq,nt", SIZES)
+def test_dense_parity_u8(ctx, nq, nt):
+    Q, T, _ = synth.planted_pair(nq, nt, seed=1000 + 7 * nq + nt)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    tidx, dist = ctx.xcheck1(qb, tb)
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    idx, d2 = ctx.knn2(qb, tb)
+    oidx, od2 = oracle.bf_knn(Q, T, 2)
+    assert _eq(idx, oidx) and _eq(d2, od2)
+    assert _eq(ctx.self_dist(qb), oracle.self_dist(Q))
+
+
+def test_dense_parity_integer_valued_f32_routes_to_int8(ctx):
+    Q, T, _ = synth.planted_pair(700, 900, seed=5)
+    qb, tb = ctx.bank(Q.astype(np.float32)), ctx.bank(T.astype(np.float32))
+    assert qb.kind == _ffi.FM_BANK_I8 and tb.kind == _ffi.FM_BANK_I8
+    tidx, dist = ctx.xcheck1(qb, tb)
+    otidx, odist = oracle.bf_xcheck1(Q.astype(np.float32), T.astype(np.float32))
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+
+
+def test_many_ties_and_duplicates(ctx):
+    # low-entropy descriptors: masses of exact distance ties and duplicate rows exercise
+    # every lowest-index tie-break (in-lane order, lane halves, waves, splits)
+    rng = np.random.default_rng(42)
+    Q = rng.integers(0, 2, (3000, 128), dtype=np.uint8) * 255
+    T = rng.integers(0, 2, (2500, 128), dtype=np.uint8) * 255
+    Q[:, 8:] = 0
+    T[:, 8:] = 0                                         # only 256 distinct rows
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    tidx, dist = ctx.xcheck1(qb, tb)
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    idx, d2 = ctx.knn2(qb, tb)
+    oidx, od2 = oracle.bf_knn(Q, T, 2)
+    assert _eq(idx, oidx) and _eq(d2, od2)
+
+
+def test_extreme_values_and_short_dim(ctx):
+    rng = np.random.default_rng(8)
+    Q = rng.choice(np.array([0, 255], dtype=np.uint8), (300, 128))
+    T = rng.choice(np.array([0, 255], dtype=np.uint8), (200, 128))
+    tidx, dist = ctx.xcheck1(ctx.bank(Q), ctx.bank(T))
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    # dim < 128 (zero padded on the device)
+    Q64 = rng.integers(0, 256, (150, 64), dtype=np.uint8)
+    T64 = rng.integers(0, 256, (170, 64), dtype=np.uint8)
+    idx, d = ctx.knn2(ctx.bank(Q64), ctx.bank(T64))
+    oidx, od = oracle.bf_knn(Q64, T64, 2)
+    assert _eq(idx, oidx) and _eq(d, od)
+
+
+@pytest.mark.parametrize("nsplit,nb", [(1, 1), (1, 4), (3, 2), (8, 4), (16, 1)])
+def test_split_and_tile_shapes_give_identical_results(nsplit, nb, monkeypatch):
+    import fastmatch_amd
+    monkeypatch.setenv("FM_NSPLIT", str(nsplit))
+    monkeypatch.setenv("FM_NB", str(nb))
+    c = fastmatch_amd.Context(0)
+    Q, T, _ = synth.planted_pair(3000, 2600, seed=77)
+    qb, tb = c.bank(Q), c.bank(T)
+    tidx, dist = c.xcheck1(qb, tb)
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    idx, d2 = c.knn2(qb, tb)
+    oidx, od2 = oracle.bf_knn(Q, T, 2)
+    assert _eq(idx, oidx) and _eq(d2, od2)
+    c.close()
+
+
+def test_ratio_filter_and_fused_match_ratio(ctx):
+    Q, T, _ = synth.planted_pair(2000, 2400, seed=13)
+    Q[5] = Q[6]                                           # duplicate query rows: selfdist 0
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    sd = ctx.self_dist(qb)
+    osd = oracle.self_dist(Q)
+    assert _eq(sd, osd) and sd[5] == 0.0 and sd[6] == 0.0
+    qb.set_selfdist(sd)
+    tidx, dist, ratio, passed, npass = ctx.match_ratio(qb, tb, 0.7)
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    m = otidx >= 0
+    oratio, opass = oracle.ratio_filter(odist[m], osd, 0.7, qrows=np.nonzero(m)[0])
+    assert _eq(ratio[m], oratio) and np.array_equal(passed[m], opass)
+    assert np.all(np.isnan(ratio[~m])) and not passed[~m].any()
+    assert npass == int(opass.sum()) and npass > 100
+    # stand-alone R1 on host arrays, with and without row indirection; x/0 and 0/0 rejected
+    d = np.array([3.0, 0.0, 2.0, 7.0], dtype=np.float32)
+    s = np.array([4.0, 0.0, 0.0, 10.0])
+    r, p, n = ctx.ratio_filter(d, s, 0.75)
+    orr, opp = oracle.ratio_filter(d, s, 0.75)
+    assert _eq(r, orr) and np.array_equal(p, opp) and n == 1
+    rows = np.nonzero(m)[0].astype(np.int32)
+    r, p, n = ctx.ratio_filter(odist[m], osd, 0.7, qrows=rows)
+    assert _eq(r, oratio) and np.array_equal(p, opass) and n == int(opass.sum())
+
+
+def test_batched_rounds_match_oracle_per_round(ctx):
+    rng = np.random.default_rng(21)
+    Q, T, _ = synth.planted_pair(6000, 5000, seed=31)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    sd = oracle.self_dist(Q)
+    qb.set_selfdist(sd)
+    q_rows, q_off, t_off_pairs = [], [0], []
+    sizes = [(393, 125), (1, 1), (0, 40), (50, 0), (130, 257), (1000, 33), (4096, 100), (37, 300)]
+    t_off = [0]
+    for nq, nt in sizes:
+        q_rows.append(rng.choice(6000, nq, replace=False))
+        q_off.append(q_off[-1] + nq)
+        t_off.append(t_off[-1] + nt)                     # cells packed back to back
+    q_rows = np.concatenate(q_rows).astype(np.int32)
+    tidx, dist, ratio = ctx.xcheck1_batched(qb, q_rows, q_off, tb, t_off)
+    for b, (nq, nt) in enumerate(sizes):
+        rows = q_rows[q_off[b]:q_off[b + 1]]
+        ot, od = oracle.bf_xcheck1(Q[rows], T[t_off[b]:t_off[b + 1]])
+        sl = slice(q_off[b], q_off[b + 1])
+        assert _eq(tidx[sl], ot) and _eq(dist[sl], od), "round %d" % b
+        m = ot >= 0
+        orat, _ = oracle.ratio_filter(od[m], sd, 0.7, qrows=rows[m])
+        assert _eq(ratio[sl][m], orat) and np.all(np.isnan(ratio[sl][~m]))
+    # overlapping / repeated rounds on the same cell are independent
+    tidx2, dist2, _ = ctx.xcheck1_batched(qb, np.concatenate([q_rows[:393], q_rows[:393]]), [0, 393, 786],
+                                          tb, [0, 125, 125 + 0], )
+    assert _eq(tidx2[:393], tidx[:393]) and np.all(tidx2[393:] == -1)
+
+
+def test_matchutil_surface(ctx):
+    Q, T, _ = synth.planted_pair(300, 280, seed=3)
+    opts = {"context": ctx}
+    m = matchutil.bf_match(Q, T, k=1, options={"crossCheck": True, "context": ctx})
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert len(m) == 300
+    for qi, row in enumerate(m):
+        if otidx[qi] < 0:
+            assert row == []
+        else:
+            assert len(row) == 1 and row[0].queryIdx == qi and row[0].trainIdx == otidx[qi]
+            assert row[0].distance == float(odist[qi]) and row[0].imgIdx == 0
+    # crossCheck is ignored unless k == 1 (matchutil.py:41)
+    m2 = matchutil.bf_match(Q, T, k=2, options={"crossCheck": True, "context": ctx})
+    oidx, od = oracle.bf_knn(Q, T, 2)
+    assert [[d.trainIdx for d in r] for r in m2] == oidx.tolist()
+    assert [[d.distance for d in r] for r in m2] == od.astype(np.float64).tolist()
+    m1 = matchutil.bf_match(Q, T, k=1, options=opts)
+    assert [r[0].trainIdx for r in m1] == oidx[:, 0].tolist()
+    mf = matchutil.flann_match(Q, Q, k=2, options=opts)          # exact substitute for FLANN
+    assert [r[1].distance for r in mf] == oracle.self_dist(Q).tolist()
+    with pytest.raises(ValueError):
+        matchutil.bf_match(Q, T, k=3, options=opts)
+    with pytest.raises(_ffi.FastMatchHipError):                   # width mismatch (cv2.error there)
+        matchutil.bf_match(Q, T[:, :64], k=2, options=opts)
+
+
+def test_deterministic_replay(ctx):
+    Q, T, _ = synth.planted_pair(4000, 4000, seed=99)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    a = ctx.xcheck1(qb, tb)
+    b = ctx.xcheck1(qb, tb)
+    assert _eq(a[0], b[0]) and _eq(a[1], b[1])
+
+
+@pytest.fixture(scope="module")
+def full_size(ctx):
+    Q, T, planted = synth.planted_pair(100000, 100000, seed=20250002)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    return Q, T, planted, qb, tb
+
+
+def test_full_size_properties_100k(ctx, full_size):
+    """BASELINE.json config 2 (100k x 100k): properties that need no full CPU run."""
+    Q, T, planted, qb, tb = full_size
+    idx, dist = ctx.knn2(qb, tb)
+    tidx, xd = ctx.xcheck1(qb, tb)
+    # (a) sortedness and validity of the 2-NN lists
+    assert idx.min() >= 0 and idx.max() < 100000
+    assert np.all(dist[:, 0] <= dist[:, 1]) and np.all(idx[:, 0] != idx[:, 1])
+    tie = dist[:, 0] == dist[:, 1]
+    assert np.all(idx[tie, 0] < idx[tie, 1])
+    # (b) reported distances are the true distances of the reported pairs (exact int math)
+    rows = np.random.default_rng(0).choice(100000, 4000, replace=False)
+    for col in (0, 1):
+        d2 = ((Q[rows].astype(np.int64) - T[idx[rows, col]].astype(np.int64)) ** 2).sum(1)
+        assert _eq(dist[rows, col], np.sqrt(d2.astype(np.float32)))
+    # (c) oracle agreement on a row sample of K2 (each row is independent of the others)
+    srows = rows[:96]
+    oidx, od = oracle.bf_knn(Q[srows], T, 2)
+    assert _eq(idx[srows], oidx) and _eq(dist[srows], od)
+    # (d) cross-check structure: matched train rows are distinct, each match is the
+    #     reverse nearest neighbour (t elects q), and a cross-checked match can never be
+    #     closer than q's own nearest train row
+    mt = tidx[tidx >= 0]
+    assert len(np.unique(mt)) == len(mt)
+    mq = np.nonzero(tidx >= 0)[0]
+    assert np.all(xd[mq] >= dist[mq, 0])
+    # transposed problem: reverse NN of T over Q from the K2 kernel with roles swapped
+    ridx, rdist = ctx.knn2(tb, qb)
+    assert np.array_equal(ridx[mt, 0], mq) and _eq(rdist[mt, 0], xd[mq])
+    # scatter-min replay on the host from the reverse-NN table == device result
+    exp = np.full(100000, -1, dtype=np.int32)
+    best = np.full(100000, np.inf, dtype=np.float32)
+    order = np.lexsort((np.arange(100000), rdist[:, 0]))          # ascending (dist, t)
+    q_of = ridx[order, 0]
+    first = np.unique(q_of, return_index=True)[1]
+    exp[q_of[first]] = order[first]
+    best[q_of[first]] = rdist[order[first], 0]
+    assert _eq(tidx, exp) and _eq(xd, best)
+    # (e) planted pairs are overwhelmingly recovered and survive the ratio test at 0.7
+    sd = ctx.self_dist(qb)
+    qb.set_selfdist(sd)
+    t2, d2_, ratio, passed, npass = ctx.match_ratio(qb, tb, 0.7)
+    assert _eq(t2, tidx) and _eq(d2_, xd)
+    pl = planted >= 0
+    assert (tidx[pl] == planted[pl]).mean() > 0.99
+    assert npass == int(passed.sum()) and passed[pl].mean() > 0.9 and passed[~pl].mean() < 0.01
+    # (f) idempotence / determinism
+    t3, d3 = ctx.xcheck1(qb, tb)
+    assert _eq(t3, tidx) and _eq(d3, xd)

@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: pair sharding and the variable-length match all-gather
+that bench.py / multi-GPU callers use (RCCL on GPUs, same code path)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from fastmatch_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from fastmatch_amd import sharding
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+pairs = sharding.shard_items(7, rank, world)
+rows = []
+for p in pairs:                                  # fake per-pair match lists, sizes differ by rank
+    m = 3 + 2 * p
+    rows.append(sharding.pack_matches(np.arange(m) + 1000 * p, np.arange(m)[::-1] + 10 * p,
+                                      (np.arange(m, dtype=np.float32) + 0.5) * (p + 1)))
+mine = np.concatenate(rows) if rows else np.zeros((0, 3), np.int32)
+for cap in (None, 64):
+    got = sharding.all_gather_matches(mine, capacity=cap)
+    assert len(got) == world
+    for r in range(world):
+        exp = []
+        for p in sharding.shard_items(7, r, world):
+            m = 3 + 2 * p
+            exp.append(sharding.pack_matches(np.arange(m) + 1000 * p, np.arange(m)[::-1] + 10 * p,
+                                             (np.arange(m, dtype=np.float32) + 0.5) * (p + 1)))
+        exp = np.concatenate(exp)
+        assert np.array_equal(got[r], exp), (rank, r)
+        q, t, d = sharding.unpack_matches(got[r])
+        assert d.dtype == np.float32 and np.array_equal(d.view(np.int32), exp[:, 2])
+empty = sharding.all_gather_matches(np.zeros((0, 3), np.int32) if rank == 0 else mine[:2])
+assert len(empty[0]) == 0 and len(empty[1]) == 2
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''' % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_items_partition():
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 8):
+            parts = [sharding.shard_items(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_pack_roundtrip_and_single_process_gather():
+    d = np.array([1.5, np.inf, 0.0], dtype=np.float32)
+    p = sharding.pack_matches([1, 2, 3], [9, 8, 7], d)
+    q, t, dd = sharding.unpack_matches(p)
+    assert q.tolist() == [1, 2, 3] and t.tolist() == [9, 8, 7] and np.array_equal(dd, d)
+    assert np.array_equal(sharding.all_gather_matches(p)[0], p)
+
+
+def test_all_gather_matches_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
