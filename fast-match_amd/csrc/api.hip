@@ -34,6 +34,7 @@ struct fm_ctx {
     // configuration (env overridable, for experiments)
     int force_nb = 0, force_nsplit = 0;
     bool use_glds = true;
+    bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
     fm_stats stats{};
     bool kernel_timed = false;
     int64_t pending_pairs = 0;
@@ -123,11 +124,11 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
         if (row < n) {
             norm[row] = sumsq;
             a[16 * hh + reg]      = -(sumsq >> 1);
-            a[32 + 16 * hh + reg] = 1 - (sumsq & 1);
+            a[32 + 16 * hh + reg] = ((1 - (sumsq & 1)) << 4) | (15 - reg);
         } else {
             norm[row] = 0;
             a[16 * hh + reg]      = kPadCinit;
-            a[32 + 16 * hh + reg] = 0;
+            a[32 + 16 * hh + reg] = 15 - reg;
         }
     }
     if constexpr (SRC_F32) {
@@ -299,6 +300,7 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
     if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
     if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
     if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
+    if (const char* s = getenv("FM_COOP")) ctx->use_coop = atoi(s) != 0;
     *out = ctx;
     return FM_OK;
 }
@@ -517,10 +519,15 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     const int64_t nq = q->n;
     if (nq == 0) return FM_OK;
     RowReducePlan pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit);
-    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2));
+    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes());
     if (rc != FM_OK) return rc;
+    int* d_bound = nullptr;
+    if (ctx->use_coop && pl.nsplit > 1) {
+        d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, ctx->use_glds, ctx->stream));
+    HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += nq * t->n;
@@ -600,14 +607,17 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
 
     // reverse NN: output rows = train rows, reduced over the query rows
     RowReducePlan pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit);
-    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1))) != FM_OK) return rc;
+    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
+    int* d_bound = (ctx->use_coop && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pl.partial_bytes(1)) : nullptr;
 
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nt > 0) {
+        if (d_bound)
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, ctx->use_glds, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;

@@ -14,15 +14,17 @@ namespace fm {
 // norm  : int32 [n_pad]       nm = sum of squares of the int8 row (<= 2^21)
 // aux   : int32 [n_pad/32][64] per 32-row tile, permuted into MFMA accumulator order:
 //           aux[tile][      16*h + r] = -(nm >> 1)      (accumulator init "cinit")
-//           aux[tile][32 +  16*h + r] = 1 - (nm & 1)    ("npar", tie-break parity)
+//           aux[tile][32 +  16*h + r] = (1 - (nm & 1)) << 4 | (15 - r)   ("low": tie-break
+//                                       parity npar and inverted register index)
 //         for tile row mm = (r&3) + 8*(r>>2) + 4*h   (r = accumulator register 0..15,
 //         h = lane>>5), i.e. the C/D map of v_mfma_i32_32x32x32_i8.
-//         Padding rows carry cinit = -2^29 so they can never win a reduction.
+//         Padding rows carry cinit = -2^25 (far below any real accumulator value, and
+//         (cinit << 5) still fits int32) so they never beat a real row.
 constexpr int kDim        = 128;
 constexpr int kStageRows  = 128;                 // rows staged into LDS per pipeline step
 constexpr int kTileRows   = 32;                  // one MFMA M-tile
 constexpr int kAuxPerTile = 64;
-constexpr int kPadCinit   = -(1 << 29);
+constexpr int kPadCinit   = -(1 << 25);
 
 struct Bank {
     int      kind   = 0;       // FM_BANK_I8 / FM_BANK_F32
@@ -48,10 +50,11 @@ struct RowReducePlan {
     int nsplit;
     int stages_per_split;
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
+    size_t bound_bytes() const { return (size_t)ncols_alloc * 4; }
 };
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit);
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                            unsigned long long* partial, bool use_glds, hipStream_t stream);
+                            unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream);
 
 // ---- K4: one workgroup per expansion round (rounds.hip) --------------------------------
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,

@@ -74,9 +74,10 @@ void round_kernel(RoundParams p)
                 else        bf[j][c] = v4i{0, 0, 0, 0};
             }
         }
-        int bh[NB][1], bi[NB][1], thr[NB];
+        TopK<1> top[NB];
+        int thr[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; bh[j][0] = INT32_MIN; bi[j][0] = -1; }
+        for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; top[j].init(); }
 
         for (int st = 0; st < nstages; ++st) {
             __syncthreads();                       // previous stage fully consumed
@@ -95,17 +96,17 @@ void round_kernel(RoundParams p)
             }
             if (tid < kStageRows) {
                 const int slot = st * kStageRows + tid;
-                int cinit = kPadCinit, npar = 0;
+                const int tile = tid >> 5, mm = tid & 31;
+                const int hh = (mm >> 2) & 1, reg = (mm & 3) + 4 * (mm >> 3);
+                int cinit = kPadCinit, low = 15 - reg;
                 if (slot < nq) {
                     const int nm = p.q_norm[p.q_rows[q0 + slot]];
                     cinit = -(nm >> 1);
-                    npar = 1 - (nm & 1);
+                    low = ((1 - (nm & 1)) << 4) | (15 - reg);
                 }
-                const int tile = tid >> 5, mm = tid & 31;
-                const int hh = (mm >> 2) & 1, reg = (mm & 3) + 4 * (mm >> 3);
                 int* aux = (int*)(smem + kStageRowBytes) + tile * kAuxPerTile;
                 aux[16 * hh + reg] = cinit;
-                aux[32 + 16 * hh + reg] = npar;
+                aux[32 + 16 * hh + reg] = low;
             }
             __syncthreads();
             const int ntiles = min(kStageRows / kTileRows, (nq - st * kStageRows + kTileRows - 1) / kTileRows);
@@ -126,9 +127,9 @@ void round_kernel(RoundParams p)
                 for (int j = 0; j < NB; ++j) {
                     const int tmax = max16(acc[j]);
                     if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                        const v16i np = lds_read16(smem + xoff + tt * (kAuxPerTile * 4) + 128);
-                        exact_update<1>(acc[j], np, st * kStageRows + tt * kTileRows + 4 * h, nq, bh[j], bi[j]);
-                        thr[j] = (bi[j][0] >= 0) ? ((bh[j][0] + 1) >> 1) : INT32_MIN;
+                        const v16i low = lds_read16(smem + xoff + tt * (kAuxPerTile * 4) + 128);
+                        top[j].update(acc[j], low, st * (kStageRows / kTileRows) + tt);
+                        thr[j] = top[j].own_threshold();
                     }
                 }
             }
@@ -136,11 +137,14 @@ void round_kernel(RoundParams p)
         // cross-half merge, then scatter-min into the per-slot table
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int oh = __shfl_xor(bh[j][0], 32);
-            const int oi = __shfl_xor(bi[j][0], 32);
-            const bool mine = !better(oh, oi, bh[j][0], bi[j][0]);
-            const int rh = mine ? bh[j][0] : oh;
-            const int ri = mine ? bi[j][0] : oi;
+            const int mh = top[j].hi(0);
+            int mi = (top[j].tile[0] >= 0) ? top[j].index(0, h) : -1;
+            if (mi >= nq) mi = -1;                  // padding slot
+            const int oh = __shfl_xor(mh, 32);
+            const int oi = __shfl_xor(mi, 32);
+            const bool mine = !better(oh, oi, mh, mi);
+            const int rh = mine ? mh : oh;
+            const int ri = mine ? mi : oi;
             const int n = cb + 32 * j + (lane & 31);
             if (h == 0 && n < nt && ri >= 0) {
                 const unsigned d2 = (unsigned)(p.t_norm[t0 + n] + 1 - rh);

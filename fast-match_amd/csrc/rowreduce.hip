@@ -40,6 +40,7 @@ struct RRParams {
     int            stages_per_split;
     int            ncols_alloc;
     unsigned long long* partial;
+    int*           bound;         // [ncols_alloc] shared K-th-best bounds (INT32_MIN filled) or null
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -72,7 +73,7 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 }
 
 template <int NB, int KTOP, bool GLDS>
-__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 3))
+__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 4))
 void rowreduce_kernel(RRParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
@@ -99,13 +100,11 @@ void rowreduce_kernel(RRParams p)
         }
     }
 
-    int bh[NB][KTOP], bi[NB][KTOP], thr[NB];
+    TopK<KTOP> top[NB];
+    int thr[NB];          // a tile is examined exactly only if some acc >= thr
+    int gthr[NB];         // part of thr that comes from the other blocks' published bounds
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        thr[j] = INT32_MIN;
-#pragma unroll
-        for (int k = 0; k < KTOP; ++k) { bh[j][k] = INT32_MIN; bi[j][k] = -1; }
-    }
+    for (int j = 0; j < NB; ++j) { top[j].init(); thr[j] = INT32_MIN; gthr[j] = INT32_MIN; }
 
     const int st0 = split * p.stages_per_split;
     const int st1 = min(st0 + p.stages_per_split, p.nstages);
@@ -124,6 +123,22 @@ void rowreduce_kernel(RRParams p)
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // stage st landed; every wave is done with the other buffer
         if (st + 1 < st1) issue_stage<GLDS>(p, st + 1, smem + ((st + 1 - st0) & 1) * kStageBytes, wave, lane);
+
+        // Bounds published by the blocks that reduce other slices for the same output rows:
+        // bound[n] is the K-th best hi some block has reached, so the final K-th best is
+        // >= bound[n] and a candidate with hi < bound[n] can be dropped.  Stale values are
+        // merely weaker bounds, so relaxed agent-scope loads suffice; the comparison is
+        // non-strict (hi >= bound) because the owner of the bound may have a higher index.
+        if (p.bound) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int n = cb + 32 * j + (lane & 31);
+                const int g = (n < p.ncols_alloc)
+                    ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
+                gthr[j] = g >> 1;                       // hi >= g possible iff acc >= floor(g / 2)
+                thr[j] = max(thr[j], gthr[j]);
+            }
+        }
 
 #pragma unroll
         for (int tt = 0; tt < kStageRows / kTileRows; ++tt) {
@@ -144,10 +159,14 @@ void rowreduce_kernel(RRParams p)
             for (int j = 0; j < NB; ++j) {
                 const int tmax = max16(acc[j]);
                 if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                    const v16i np = lds_read16(buf + xoff + tt * (kAuxPerTile * 4) + 128);
-                    exact_update<KTOP>(acc[j], np, st * kStageRows + tt * kTileRows + 4 * h, p.nred, bh[j], bi[j]);
-                    // A candidate enters the top-K only if 2*acc+npar > bh[K-1], possible iff acc >= ceil(bh[K-1]/2).
-                    thr[j] = (bi[j][KTOP - 1] >= 0) ? ((bh[j][KTOP - 1] + 1) >> 1) : INT32_MIN;
+                    const v16i low = lds_read16(buf + xoff + tt * (kAuxPerTile * 4) + 128);
+                    const bool improved = top[j].update(acc[j], low, st * (kStageRows / kTileRows) + tt);
+                    thr[j] = max(top[j].own_threshold(), gthr[j]);
+                    if (p.bound && improved && top[j].full()) {
+                        const int n = cb + 32 * j + (lane & 31);
+                        if (n < p.ncols_alloc)
+                            __hip_atomic_fetch_max(p.bound + n, top[j].kth_hi(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
@@ -156,24 +175,35 @@ void rowreduce_kernel(RRParams p)
     // Merge the two lane halves (same output row, interleaved reduced rows), then emit.
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+        int bh[KTOP], bi[KTOP];
+#pragma unroll
+        for (int k = 0; k < KTOP; ++k) {
+            bh[k] = top[j].hi(k);
+            bi[k] = (top[j].tile[k] >= 0) ? top[j].index(k, h) : -1;
+            if (bi[k] >= p.nred) bi[k] = -1;          // a padding row is not a candidate
+        }
+        if constexpr (KTOP == 2) {
+            // a padding row can only sit in a slot when fewer real rows exist; keep real first
+            if (bi[0] < 0 && bi[1] >= 0) { bh[0] = bh[1]; bi[0] = bi[1]; bi[1] = -1; }
+        }
         int oh[KTOP], oi[KTOP];
 #pragma unroll
         for (int k = 0; k < KTOP; ++k) {
-            oh[k] = __shfl_xor(bh[j][k], 32);
-            oi[k] = __shfl_xor(bi[j][k], 32);
+            oh[k] = __shfl_xor(bh[k], 32);
+            oi[k] = __shfl_xor(bi[k], 32);
         }
         int rh[KTOP], ri[KTOP];
         if constexpr (KTOP == 1) {
-            const bool mine = !better(oh[0], oi[0], bh[j][0], bi[j][0]);
-            rh[0] = mine ? bh[j][0] : oh[0];
-            ri[0] = mine ? bi[j][0] : oi[0];
+            const bool mine = !better(oh[0], oi[0], bh[0], bi[0]);
+            rh[0] = mine ? bh[0] : oh[0];
+            ri[0] = mine ? bi[0] : oi[0];
         } else {
-            const bool m0 = !better(oh[0], oi[0], bh[j][0], bi[j][0]);
-            rh[0] = m0 ? bh[j][0] : oh[0];
-            ri[0] = m0 ? bi[j][0] : oi[0];
+            const bool m0 = !better(oh[0], oi[0], bh[0], bi[0]);
+            rh[0] = m0 ? bh[0] : oh[0];
+            ri[0] = m0 ? bi[0] : oi[0];
             // runner-up: the loser of the first comparison against the winner side's 2nd
-            const int ah = m0 ? bh[j][1] : bh[j][0], ai = m0 ? bi[j][1] : bi[j][0];
-            const int ch = m0 ? oh[0] : oh[1],       cidx = m0 ? oi[0] : oi[1];
+            const int ah = m0 ? bh[1] : bh[0], ai = m0 ? bi[1] : bi[0];
+            const int ch = m0 ? oh[0] : oh[1], cidx = m0 ? oi[0] : oi[1];
             const bool m1 = !better(ch, cidx, ah, ai);
             rh[1] = m1 ? ah : ch;
             ri[1] = m1 ? ai : cidx;
@@ -199,9 +229,9 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
 {
     RowReducePlan pl;
     const int64_t nstages = nred_pad / kStageRows;
-    int nb = 4;
-    // Small column counts: narrower wave tiles keep more waves busy.
-    if (ncols_pad <= 128 * 256) nb = 2;
+    // NB = 2 (64 output rows per wave, 4 waves/SIMD resident) measured fastest on MI355X;
+    // small column counts use NB = 1 so that more workgroups exist.
+    int nb = 2;
     if (ncols_pad <= 128 * 64) nb = 1;
     if (force_nb == 1 || force_nb == 2 || force_nb == 4) nb = force_nb;
     pl.nb = nb;
@@ -209,11 +239,14 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
-    int64_t want = 4096;                         // ~8 waves of 512 resident blocks
+    // ~6 rounds of the 1024 workgroups the chip holds (4 per CU): enough to balance the
+    // tail, few enough that every workgroup sweeps a long slice (per-block warm-up of the
+    // top-K state and the stationary-operand loads are amortised).
+    int64_t want = 6144;
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nstages / 8) nsplit = nstages / 8;   // keep >= 8 stages (1024 rows) per split
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > 1) nsplit = (nsplit + 7) / 8 * 8;    // XCD-aligned
+    if (nsplit > 4) nsplit = (nsplit + 3) / 4 * 4;
     if (force_nsplit > 0) nsplit = force_nsplit;
     if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
     int64_t per = (nstages + nsplit - 1) / nsplit;
@@ -234,9 +267,10 @@ static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t s
 }
 
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                            unsigned long long* partial, bool use_glds, hipStream_t stream)
+                            unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream)
 {
     RRParams p;
+    p.bound = (plan.nsplit > 1) ? bound : nullptr;
     p.col_rows = cols.rows8;
     p.col_norm = cols.norm;
     p.ncols_pad = (int)cols.n_pad;

@@ -1,6 +1,6 @@
 // Device helpers shared by the dense row-reduce kernel (rowreduce.hip) and the per-round
 // kernel (rounds.hip): MFMA vector types, stage geometry, the in-lane max tree and the
-// exact top-K update.
+// exact top-K state of one lane.
 #pragma once
 #include "fm_internal.h"
 
@@ -9,10 +9,11 @@ namespace fm {
 typedef int v4i  __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kStageRowBytes = kStageRows * kDim;           // 16384
+constexpr int kStageRowBytes = kStageRows * kDim;                           // 16384
 constexpr int kStageAuxBytes = (kStageRows / kTileRows) * kAuxPerTile * 4;  // 1024
 constexpr int kStageBytes    = kStageRowBytes + kStageAuxBytes;             // 17408
 
+// v_max3_i32 tree over the 16 accumulator registers of one 32x32 tile.
 __device__ __forceinline__ int max16(const v16i& a)
 {
     int m0 = max(max(a[0], a[1]), a[2]);
@@ -25,29 +26,108 @@ __device__ __forceinline__ int max16(const v16i& a)
     return max(m5, m6);
 }
 
-// Exact update of a lane's top-KTOP with the 16 candidates of one tile.
-// hi = 2*acc + npar orders candidates by descending (d2 ascending); candidates arrive in
-// ascending row index within a lane, so strict '>' keeps the lower index on ties
-// (cv::batchDistance insertion rule).
-template <int KTOP>
-__device__ __forceinline__ void exact_update(const v16i& acc, const v16i& np, int idx_base, int nred,
-                                             int (&bh)[KTOP], int (&bi)[KTOP])
+// Read the 16 accumulator-order words (cinit or low) of one tile from LDS.
+__device__ __forceinline__ v16i lds_read16(const char* p)
 {
+    const v4i* ax = (const v4i*)p;
+    const v4i c0 = ax[0], c1 = ax[1], c2 = ax[2], c3 = ax[3];
+    return v16i{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3],
+                c2[0], c2[1], c2[2], c2[3], c3[0], c3[1], c3[2], c3[3]};
+}
+
+// Row of a tile that accumulator register r of lane half h holds (C/D map of
+// v_mfma_i32_32x32x32_i8): (r & 3) + 8 (r >> 2) + 4 h.
+__device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- exact top-K state of one lane for one output row -----------------------------------
+// A candidate is the packed key  (acc << 5) | (npar << 4) | (15 - r):
+//   key >> 4 = hi = 2*acc + npar, and |m|^2 - 2 c.m = 1 - hi, so larger hi = smaller d2;
+//   the low nibble makes the lowest register (= lowest row in this lane's tile share)
+//   win ties inside a tile.  Across tiles candidates arrive in ascending row order, so the
+//   comparison against the running state uses hi only and is strict: the earlier (lower
+//   index) candidate is kept -- cv::batchDistance's rule.
+// tile < 0: -1 = empty slot.
+constexpr int kNoKey = INT32_MIN;
+
+template <int KTOP>
+struct TopK {
+    int key[KTOP];
+    int tile[KTOP];
+
+    __device__ __forceinline__ void init()
+    {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int hi  = (acc[r] << 1) | np[r];
-        const int idx = idx_base + (r & 3) + 8 * (r >> 2);
-        const bool ok = idx < nred;
+        for (int k = 0; k < KTOP; ++k) { key[k] = kNoKey; tile[k] = -1; }
+    }
+    // hi of the K-th best, or kNoKey>>4 when fewer than K candidates were seen
+    __device__ __forceinline__ int kth_hi() const { return key[KTOP - 1] >> 4; }
+    __device__ __forceinline__ bool full() const { return tile[KTOP - 1] >= 0; }
+
+    // Smallest accumulator value that can still enter: needs 2*acc + npar > kth_hi,
+    // possible iff acc >= ceil(kth_hi / 2).
+    __device__ __forceinline__ int own_threshold() const
+    {
+        return full() ? ((kth_hi() + 1) >> 1) : INT32_MIN;
+    }
+
+    // Exact update with the 16 candidates of tile `t`.  Returns true if the K-th best
+    // improved (the caller may then publish the new bound).
+    __device__ __forceinline__ bool update(const v16i& acc, const v16i& low, int t)
+    {
+        int k[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k[r] = (acc[r] << 5) | low[r];
         if constexpr (KTOP == 1) {
-            if (ok && hi > bh[0]) { bh[0] = hi; bi[0] = idx; }
+            const int m0 = max(max(k[0], k[1]), k[2]);
+            const int m1 = max(max(k[3], k[4]), k[5]);
+            const int m2 = max(max(k[6], k[7]), k[8]);
+            const int m3 = max(max(k[9], k[10]), k[11]);
+            const int m4 = max(max(k[12], k[13]), k[14]);
+            const int km = max(max(max(m0, m1), m2), max(max(m3, m4), k[15]));
+            const bool up = (km >> 4) > (key[0] >> 4);
+            key[0] = up ? km : key[0];
+            tile[0] = up ? t : tile[0];
+            return up;
         } else {
-            if (ok && hi > bh[1]) {
-                if (hi > bh[0]) { bh[1] = bh[0]; bi[1] = bi[0]; bh[0] = hi; bi[0] = idx; }
-                else            { bh[1] = hi;    bi[1] = idx; }
+            // tile top-2 by a merge tree of sorted pairs (keys inside a tile are unique)
+            int a1[8], a2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a1[i] = max(k[2 * i], k[2 * i + 1]); a2[i] = min(k[2 * i], k[2 * i + 1]); }
+            int b1[4], b2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                b1[i] = max(a1[2 * i], a1[2 * i + 1]);
+                b2[i] = max(max(min(a1[2 * i], a1[2 * i + 1]), a2[2 * i]), a2[2 * i + 1]);
             }
+            int c1[2], c2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                c1[i] = max(b1[2 * i], b1[2 * i + 1]);
+                c2[i] = max(max(min(b1[2 * i], b1[2 * i + 1]), b2[2 * i]), b2[2 * i + 1]);
+            }
+            const int k1 = max(c1[0], c1[1]);
+            const int k2 = max(max(min(c1[0], c1[1]), c2[0]), c2[1]);
+            const int h1 = k1 >> 4, h2 = k2 >> 4, g1 = key[0] >> 4, g2 = key[1] >> 4;
+            const bool enter = h1 > g2;          // k1 beats the running 2nd
+            const bool first = h1 > g1;          // k1 beats the running 1st
+            const bool both  = h2 > g1;          // k2 also beats the running 1st
+            // new (1st, 2nd):  first & both -> (k1,k2);  first -> (k1, old1);  enter -> (old1, k1)
+            const int n0k = first ? k1 : key[0];
+            const int n0t = first ? t : tile[0];
+            const int n1k = first ? (both ? k2 : key[0]) : (enter ? k1 : key[1]);
+            const int n1t = first ? (both ? t : tile[0]) : (enter ? t : tile[1]);
+            key[0] = n0k; tile[0] = n0t; key[1] = n1k; tile[1] = n1t;
+            return enter;
         }
     }
-}
+
+    // Decode slot k: hi and the reduced-bank row index (valid only if tile[k] >= 0).
+    __device__ __forceinline__ int hi(int k) const { return key[k] >> 4; }
+    __device__ __forceinline__ int index(int k, int h) const
+    {
+        return tile[k] * kTileRows + tile_row(15 - (key[k] & 15), h);
+    }
+};
 
 // (hi, idx) a is better than b: larger hi, then lower index.  idx < 0 means "none".
 __device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
@@ -55,16 +135,6 @@ __device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
     if (ai < 0) return false;
     if (bi_ < 0) return true;
     return ah > bh_ || (ah == bh_ && ai < bi_);
-}
-
-
-// Read the 16 accumulator-order words (cinit or npar) of one tile from LDS.
-__device__ __forceinline__ v16i lds_read16(const char* p)
-{
-    const v4i* ax = (const v4i*)p;
-    const v4i c0 = ax[0], c1 = ax[1], c2 = ax[2], c3 = ax[3];
-    return v16i{c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3],
-                c2[0], c2[1], c2[2], c2[3], c3[0], c3[1], c3[2], c3[3]};
 }
 
 }  // namespace fm

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of
+# the default bench workload.  Outputs under gpurun_out/prof_$1/ ; summaries are copied to
+# profiles/ by hand afterwards.
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python3 $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq1 -- $BENCH > /dev/null 2> $OUT/pmc_sq1.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- $BENCH > /dev/null 2> $OUT/pmc_sq2.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_tcc -- $BENCH > /dev/null 2> $OUT/pmc_tcc.err
+cd $OUT
+# keep the outputs small: per-kernel stats + aggregated counters only
+python3 - <<'PY'
+import csv, glob, os, collections
+out = os.getcwd()
+for d in sorted(glob.glob("pmc_*")):
+    if not os.path.isdir(d): continue
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for row in csv.DictReader(open(f)):
+            k = (row["Kernel_Name"][:60], row["Counter_Name"])
+            agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
+        with open(os.path.join(out, d + "_summary.csv"), "w") as w:
+            w.write("kernel,counter,mean_per_dispatch,dispatches\n")
+            for (k, c), (s, n) in sorted(agg.items()):
+                w.write('"%s",%s,%.1f,%d\n' % (k, c, s / n, n))
+for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
+    os.system("cp %s %s/kernel_stats.csv" % (f, out))
+PY
+rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc
+find $OUT/trace -name "*kernel_trace.csv" -size +2M -delete
+ls -la $OUT
+cat $OUT/kernel_stats.csv | head -20
+cat $OUT/*_summary.csv | grep -i rowreduce
+tail -3 $OUT/*.err | head -40
