@@ -39,6 +39,8 @@ SYMBOLS = {
     "fm_get_stats": (_INT, [_P, ctypes.POINTER(fm_stats)]),
     "fm_reset_stats": (_INT, [_P]),
     "fm_device_name": (_INT, [_P, ctypes.c_char_p, _INT]),
+    "fm_host_alloc": (_INT, [_P, _I64, ctypes.POINTER(_P)]),
+    "fm_host_free": (_INT, [_P, _P]),
     "fm_bank_create_u8": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
     "fm_bank_create_f32": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
     "fm_bank_destroy": (_INT, [_P, _P]),
@@ -130,6 +132,9 @@ class Context(object):
 
     def close(self):
         if self.handle is not None:
+            for p in getattr(self, "_pinned", []):
+                self.lib.fm_host_free(self.handle, p)
+            self._pinned = []
             self.lib.fm_ctx_destroy(self.handle)
             self.handle = None
 
@@ -138,6 +143,20 @@ class Context(object):
             self.close()
         except Exception:
             pass
+
+    def pinned_empty(self, shape, dtype):
+        """ndarray in page-locked host memory (lives as long as the context): pass it as an
+        ``out=`` buffer so results arrive by direct DMA."""
+        dt = np.dtype(dtype)
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = _P()
+        self._check(self.lib.fm_host_alloc(self.handle, nbytes, ctypes.byref(p)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     # -- banks -------------------------------------------------------------------------
     def bank(self, rows):
@@ -175,7 +194,19 @@ class Context(object):
         self._check(self.lib.fm_xcheck1(self.handle, q.handle, t.handle, _ptr(tidx), _ptr(dist)))
         return tidx, dist
 
-    def match_ratio(self, q, t, tau):
+    def match_ratio(self, q, t, tau, out=None):
+        """X1 + R1 fused.  ``out`` = optional (tidx i32[nq], dist f32[nq], ratio f64[nq],
+        passed u8[nq]) buffers to fill (e.g. from ``pinned_empty``); then ``passed`` is
+        returned as that uint8 array instead of a bool copy."""
+        if out is not None:
+            tidx, dist, ratio, passed = out
+            for a, dt in ((tidx, np.int32), (dist, np.float32), (ratio, np.float64), (passed, np.uint8)):
+                if a.dtype != dt or a.shape != (q.n,) or not a.flags.c_contiguous:
+                    raise ValueError("out buffers must be contiguous [nq] int32/float32/float64/uint8")
+            npass = _I64(0)
+            self._check(self.lib.fm_match_ratio(self.handle, q.handle, t.handle, float(tau), _ptr(tidx),
+                                                _ptr(dist), _ptr(ratio), _ptr(passed), ctypes.byref(npass)))
+            return tidx, dist, ratio, passed, npass.value
         tidx = np.empty(q.n, dtype=np.int32)
         dist = np.empty(q.n, dtype=np.float32)
         ratio = np.empty(q.n, dtype=np.float64)

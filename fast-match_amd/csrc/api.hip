@@ -152,9 +152,17 @@ __global__ void bank_copy_f32_kernel(const float* __restrict__ src, int64_t n, i
 // ---------------------------------------------------------------------------------------
 // knnMatch(k=2): merge nsplit partial top-2 lists per query row (keys are (d2<<32)|idx,
 // ascending = cv::batchDistance order) and emit idx / sqrtf(d2).
+// Partial keys carry the exact integer d2 (int8 route) or the float32 bits of the distance
+// itself (float32 route) in their high word; both orders are the distance order.
+__device__ __forceinline__ float key_dist(unsigned long long key, int f32)
+{
+    const unsigned hi = (unsigned)(key >> 32);
+    return f32 ? __uint_as_float(hi) : sqrtf((float)hi);
+}
+
 __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial, int nsplit,
                                   int ncols_alloc, int64_t n, int32_t* __restrict__ idx,
-                                  float* __restrict__ dist)
+                                  float* __restrict__ dist, int f32)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -170,8 +178,8 @@ __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial
     }
     idx[2 * i]     = (b0 == ~0ull) ? -1 : (int32_t)(unsigned)b0;
     idx[2 * i + 1] = (b1 == ~0ull) ? -1 : (int32_t)(unsigned)b1;
-    dist[2 * i]     = (b0 == ~0ull) ? INFINITY : sqrtf((float)(unsigned)(b0 >> 32));
-    dist[2 * i + 1] = (b1 == ~0ull) ? INFINITY : sqrtf((float)(unsigned)(b1 >> 32));
+    dist[2 * i]     = (b0 == ~0ull) ? INFINITY : key_dist(b0, f32);
+    dist[2 * i + 1] = (b1 == ~0ull) ? INFINITY : key_dist(b1, f32);
 }
 
 // Cross-check step 2: train row t elects rq = argmin_q d(q,t)
@@ -202,7 +210,7 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qb
                                        const double* __restrict__ selfdist, double tau,
                                        int32_t* __restrict__ tidx, float* __restrict__ dist,
                                        double* __restrict__ ratio, uint8_t* __restrict__ pass,
-                                       unsigned long long* __restrict__ npass)
+                                       unsigned long long* __restrict__ npass, int f32)
 {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool p = false;
@@ -213,7 +221,7 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qb
         double r = NAN;
         if (key != ~0ull) {
             ti = (int32_t)(unsigned)key;
-            d = sqrtf((float)(unsigned)(key >> 32));
+            d = key_dist(key, f32);
             if (selfdist) { r = (double)d / selfdist[q]; p = r < tau; }
         }
         tidx[q] = ti;
@@ -348,6 +356,24 @@ extern "C" int fm_device_name(fm_ctx* ctx, char* buf, int buflen)
 {
     if (!ctx || !buf || buflen <= 0) return fail(ctx, FM_EINVAL, "fm_device_name: bad argument");
     snprintf(buf, (size_t)buflen, "%s", ctx->devname.c_str());
+    return FM_OK;
+}
+
+extern "C" int fm_host_alloc(fm_ctx* ctx, int64_t bytes, void** out)
+{
+    if (!ctx || !out || bytes < 0) return fail(ctx, FM_EINVAL, "fm_host_alloc: bad argument");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+    return FM_OK;
+}
+
+extern "C" int fm_host_free(fm_ctx* ctx, void* p)
+{
+    if (!p) return FM_OK;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, FM_EDEVICE, std::string("fm_host_free: ") + hipGetErrorString(e)); }
     return FM_OK;
 }
 
@@ -515,24 +541,26 @@ static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const cha
 // Device-side knn2 into d_idx/d_dist (device pointers).
 static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t* d_idx, float* d_dist)
 {
-    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_knn2: float32 (non-integer) banks are not supported yet");
     const int64_t nq = q->n;
     if (nq == 0) return FM_OK;
-    RowReducePlan pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit);
+    const int f32 = q->kind == FM_BANK_F32;
+    RowReducePlan pl = f32 ? plan_rowreduce_f32(q->n_pad, t->n_pad, ctx->force_nsplit)
+                           : plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit);
     int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes());
     if (rc != FM_OK) return rc;
     int* d_bound = nullptr;
-    if (ctx->use_coop && pl.nsplit > 1) {
+    if (!f32 && ctx->use_coop && pl.nsplit > 1) {
         d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+    if (f32) HIP_TRY(ctx, launch_rowreduce_f32(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, ctx->stream));
+    else     HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += nq * t->n;
     hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nq, d_idx, d_dist);
+                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nq, d_idx, d_dist, f32);
     HIP_TRY(ctx, hipGetLastError());
     return FM_OK;
 }
@@ -585,7 +613,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
 {
     int rc = check_pair(ctx, q, t, who);
     if (rc != FM_OK) return rc;
-    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, std::string(who) + ": float32 (non-integer) banks are not supported yet");
+    const int f32 = q->kind == FM_BANK_F32;
     const int64_t nq = q->n, nt = t->n;
     if (n_pass) *n_pass = 0;
     if (nq == 0) return FM_OK;
@@ -606,9 +634,10 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     unsigned long long* d_cnt = (unsigned long long*)(base + o_cnt);
 
     // reverse NN: output rows = train rows, reduced over the query rows
-    RowReducePlan pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit);
+    RowReducePlan pl = f32 ? plan_rowreduce_f32(t->n_pad, q->n_pad, ctx->force_nsplit)
+                           : plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit);
     if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
-    int* d_bound = (ctx->use_coop && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pl.partial_bytes(1)) : nullptr;
+    int* d_bound = (!f32 && ctx->use_coop && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pl.partial_bytes(1)) : nullptr;
 
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
@@ -617,7 +646,8 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         if (d_bound)
             HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+        if (f32) HIP_TRY(ctx, launch_rowreduce_f32(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, ctx->stream));
+        else     HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
@@ -628,7 +658,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)d_qbest, nq, with_ratio ? (const double*)q->selfdist : (const double*)nullptr,
                        tau, d_tidx, d_dist, with_ratio ? d_ratio : (double*)nullptr,
-                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr);
+                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr, f32);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(tidx, d_tidx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -701,7 +731,7 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
 {
     int rc = check_pair(ctx, q, t, "fm_xcheck1_batched");
     if (rc != FM_OK) return rc;
-    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: float32 (non-integer) banks are not supported yet");
+    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: float32 (non-integer) banks take the dense path (fm_xcheck1 / fm_match_ratio)");
     if (n_rounds < 0) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: n_rounds < 0");
     if (n_rounds == 0) return FM_OK;
     if (!q_off || !t_off) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: NULL offsets");

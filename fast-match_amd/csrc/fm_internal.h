@@ -56,6 +56,11 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
                             unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream);
 
+// ---- K5: float32 route (dist_f32.hip); partial keys carry float32 distance bits ----------
+RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_nsplit);
+hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
+                                unsigned long long* partial, hipStream_t stream);
+
 // ---- K4: one workgroup per expansion round (rounds.hip) --------------------------------
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,
                          const int64_t* d_t_off, int64_t n_rounds, int32_t* d_tidx, float* d_dist,

@@ -56,6 +56,11 @@ int  fm_reset_stats(fm_ctx* ctx);
 /* Name of the device the context runs on (e.g. "gfx950:..."), written NUL-terminated.  */
 int  fm_device_name(fm_ctx* ctx, char* buf, int buflen);
 
+/* Page-locked host memory for output buffers (optional): results copied into such a buffer
+ * move by direct DMA instead of through the runtime's pageable staging path.             */
+int  fm_host_alloc(fm_ctx* ctx, int64_t bytes, void** ptr);
+int  fm_host_free(fm_ctx* ctx, void* ptr);
+
 /* ---- descriptor banks --------------------------------------------------------------
  * A bank is a device-resident [n, dim] descriptor matrix plus what the kernels need
  * (bytes XOR 0x80 as int8, row norms).  It replaces the ndarray arguments the reference

@@ -276,3 +276,52 @@ def test_full_size_properties_100k(ctx, full_size):
     # (f) idempotence / determinism
     t3, d3 = ctx.xcheck1(qb, tb)
     assert _eq(t3, tidx) and _eq(d3, xd)
+
+
+# ---- K5: float32 route (non-integer descriptors) -------------------------------------------
+def _nonint(n, seed):
+    rng = np.random.default_rng(seed)
+    base = synth.synth_sift(n, rng).astype(np.float32)
+    return (base + rng.uniform(-0.5, 0.5, base.shape).astype(np.float32)).astype(np.float32)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (3, 2), (63, 65), (64, 64), (130, 257), (1000, 777), (3000, 4100)])
+def test_f32_route_parity(ctx, nq, nt):
+    Q, T = _nonint(nq, 100 + nq), _nonint(nt, 200 + nt)
+    if nq > 10 and nt > 10:
+        T[7] = T[3]                                       # duplicate train rows: index tie-break
+        Q[5] = T[3]                                       # exact zero distance
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    assert qb.kind == _ffi.FM_BANK_F32 and tb.kind == _ffi.FM_BANK_F32
+    idx, dist = ctx.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)          # the fixed fma-chain order
+    assert _eq(idx, oidx) and _eq(dist, odist)             # bit-exact (tolerance 0 ulp <= 1 ulp)
+    tidx, xd = ctx.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T, order=1)
+    assert _eq(tidx, otidx) and _eq(xd, oxd)
+    sd = ctx.self_dist(qb)
+    assert _eq(sd, oracle.self_dist(Q, order=1))
+    if nq > 10:
+        qb.set_selfdist(sd)
+        t2, d2, ratio, passed, npass = ctx.match_ratio(qb, tb, 0.7)
+        m = otidx >= 0
+        orat, opass = oracle.ratio_filter(oxd[m], sd, 0.7, qrows=np.nonzero(m)[0])
+        assert _eq(t2, otidx) and _eq(ratio[m], orat) and np.array_equal(passed[m], opass)
+
+
+def test_f32_route_close_to_opencv_order(ctx):
+    # OpenCV's own accumulation order (unrolled by 4) differs from the fixed fma chain only
+    # in rounding: distances agree within 1 ulp-scale relative error, indices almost always.
+    Q, T = _nonint(500, 1), _nonint(600, 2)
+    idx, dist = ctx.knn2(ctx.bank(Q), ctx.bank(T))
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=0)
+    assert (idx == oidx).mean() > 0.999
+    same = idx == oidx
+    assert np.max(np.abs(dist[same] - odist[same]) / odist[same]) < 4e-7
+
+
+def test_mixed_kind_pair_is_rejected(ctx):
+    Q = _nonint(10, 3)
+    T = synth.synth_sift(10, np.random.default_rng(4))
+    with pytest.raises(_ffi.FastMatchHipError):
+        ctx.xcheck1(ctx.bank(Q), ctx.bank(T))
