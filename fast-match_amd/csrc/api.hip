@@ -32,7 +32,7 @@ struct fm_ctx {
     void*  ws_out = nullptr;     size_t ws_out_bytes = 0;
     void*  ws_in = nullptr;      size_t ws_in_bytes = 0;
     // configuration (env overridable, for experiments)
-    int force_nb = 0, force_nsplit = 0;
+    int force_nb = 0, force_nsplit = 0, force_nw = 0;
     bool use_glds = true;
     bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
     fm_stats stats{};
@@ -307,6 +307,7 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
     }
     if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
     if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
+    if (const char* s = getenv("FM_NW")) ctx->force_nw = atoi(s);
     if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
     if (const char* s = getenv("FM_COOP")) ctx->use_coop = atoi(s) != 0;
     *out = ctx;
@@ -545,7 +546,7 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     if (nq == 0) return FM_OK;
     const int f32 = q->kind == FM_BANK_F32;
     RowReducePlan pl = f32 ? plan_rowreduce_f32(q->n_pad, t->n_pad, ctx->force_nsplit)
-                           : plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit);
+                           : plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
     int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes());
     if (rc != FM_OK) return rc;
     int* d_bound = nullptr;
@@ -635,7 +636,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
 
     // reverse NN: output rows = train rows, reduced over the query rows
     RowReducePlan pl = f32 ? plan_rowreduce_f32(t->n_pad, q->n_pad, ctx->force_nsplit)
-                           : plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit);
+                           : plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
     if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
     int* d_bound = (!f32 && ctx->use_coop && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pl.partial_bytes(1)) : nullptr;
 

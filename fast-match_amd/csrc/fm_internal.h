@@ -45,14 +45,15 @@ struct Bank {
 // partial[(split*ncols_alloc + c)*KTOP + k].
 struct RowReducePlan {
     int nb;            // 32-column blocks per wave (1, 2 or 4)
-    int ncols_alloc;   // columns covered by the grid (multiple of 128*nb)
+    int nw = 4;        // waves per workgroup (4, 8 or 16)
+    int ncols_alloc;   // columns covered by the grid (multiple of 32*nb*nw)
     int nchunks;
     int nsplit;
     int stages_per_split;
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 4; }
 };
-RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit);
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw);
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
                             unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream);
 

@@ -37,6 +37,7 @@ struct RRParams {
     int            nred;          // real rows of the reduced bank
     int            nstages;       // nred_pad / 128
     int            nsplit;
+    int            nchunks;
     int            stages_per_split;
     int            ncols_alloc;
     unsigned long long* partial;
@@ -46,14 +47,15 @@ struct RRParams {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <bool GLDS>
+template <bool GLDS, int NW>
 __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* buf, int wave, int lane)
 {
     const int8_t* src_rows = p.red_rows + (size_t)stage * kStageRowBytes;
     const int slot = lane & 7;
+    constexpr int kPieces = 16 / NW;              // 1-KiB pieces (8 rows) per wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g   = wave * 4 + i;              // 1-KiB piece = 8 rows
+    for (int i = 0; i < kPieces; ++i) {
+        const int g   = wave * kPieces + i;
         const int row = g * 8 + (lane >> 3);
         const int8_t* src = src_rows + row * kDim + 16 * (slot ^ ((row >> 1) & 7));
         if constexpr (GLDS) {
@@ -62,7 +64,7 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
             *(v4i*)(buf + g * 1024 + lane * 16) = *(const v4i*)src;
         }
     }
-    if (wave == 0) {
+    if (wave == NW - 1) {
         const int32_t* src = p.red_aux + (size_t)stage * (kStageAuxBytes / 4) + lane * 4;
         if constexpr (GLDS) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(buf + kStageRowBytes), 16, 0, 0);
@@ -72,8 +74,11 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
     }
 }
 
-template <int NB, int KTOP, bool GLDS>
-__global__ __launch_bounds__(256, (NB >= 4 ? 2 : 4))
+// NW waves per workgroup share every staged tile: the L2 -> LDS staging traffic per MFMA
+// falls as 1/NW (it, not the MFMA issue rate, limited the 4-wave version: see
+// scripts/ablate/buildup.hip), at the same registers per wave.
+template <int NB, int KTOP, bool GLDS, int NW>
+__global__ __launch_bounds__(64 * NW, (NB >= 4 ? 2 : 4))
 void rowreduce_kernel(RRParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
@@ -82,9 +87,13 @@ void rowreduce_kernel(RRParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int h    = lane >> 5;
-    const int split = blockIdx.x % p.nsplit;
-    const int chunk = blockIdx.x / p.nsplit;
-    const int cb    = chunk * (128 * NB) + wave * (32 * NB);
+    // Split-major order: the first wave of resident workgroups covers EVERY output chunk for
+    // the first few slices, so the bounds it publishes serve all later workgroups (which
+    // reduce other slices for the same output rows) from their first tile on.  Concurrent
+    // workgroups then sweep the same slice, which every XCD serves from its own L2.
+    const int chunk = blockIdx.x % p.nchunks;
+    const int split = blockIdx.x / p.nchunks;
+    const int cb    = chunk * (32 * NB * NW) + wave * (32 * NB);
 
     // Stationary operand: this wave's NB x 32 output rows, 4 K-chunks of 32 bytes each.
     v4i bf[NB][4];
@@ -116,13 +125,13 @@ void rowreduce_kernel(RRParams p)
     for (int c = 0; c < 4; ++c) aoff[c] = (lane & 31) * kDim + 16 * ((2 * c + h) ^ sw);
     const int xoff = kStageRowBytes + h * 64;
 
-    if (st0 < st1) issue_stage<GLDS>(p, st0, smem, wave, lane);
+    if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
 
     for (int st = st0; st < st1; ++st) {
         char* buf = smem + ((st - st0) & 1) * kStageBytes;
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // stage st landed; every wave is done with the other buffer
-        if (st + 1 < st1) issue_stage<GLDS>(p, st + 1, smem + ((st + 1 - st0) & 1) * kStageBytes, wave, lane);
+        if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + ((st + 1 - st0) & 1) * kStageBytes, wave, lane);
 
         // Bounds published by the blocks that reduce other slices for the same output rows:
         // bound[n] is the K-th best hi some block has reached, so the final K-th best is
@@ -225,24 +234,29 @@ void rowreduce_kernel(RRParams p)
     }
 }
 
-RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit)
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw)
 {
     RowReducePlan pl;
     const int64_t nstages = nred_pad / kStageRows;
-    // NB = 2 (64 output rows per wave, 4 waves/SIMD resident) measured fastest on MI355X;
-    // small column counts use NB = 1 so that more workgroups exist.
-    int nb = 2;
+    // NB = 2 (64 output rows per wave, 4 waves/SIMD resident); the more waves share a
+    // workgroup's staged tiles the less L2 -> LDS traffic per MFMA, so big problems use
+    // 8-wave workgroups (512 output rows each), smaller ones 4 so that enough workgroups
+    // exist; tiny column counts use NB = 1.  (16-wave workgroups are available via FM_NW.)
+    int nb = 2, nw = 8;                         // measured best at 100k x 100k (r01 sweep)
+    if (ncols_pad < 512 * 64) nw = 4;
     if (ncols_pad <= 128 * 64) nb = 1;
     if (force_nb == 1 || force_nb == 2 || force_nb == 4) nb = force_nb;
+    if (force_nw == 4 || force_nw == 8 || force_nw == 16) nw = force_nw;
+    if (nb != 2) nw = 4;
     pl.nb = nb;
-    const int cb = 128 * nb;
+    pl.nw = nw;
+    const int cb = 32 * nb * nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
-    // ~6 rounds of the 1024 workgroups the chip holds (4 per CU): enough to balance the
-    // tail, few enough that every workgroup sweeps a long slice (per-block warm-up of the
-    // top-K state and the stationary-operand loads are amortised).
-    int64_t want = 6144;
+    // ~12 rounds of the workgroups the chip holds (16 waves per CU): enough to balance the
+    // tail, few enough that every workgroup sweeps a long slice.
+    int64_t want = 12 * 256 * (16 / nw);
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nstages / 8) nsplit = nstages / 8;   // keep >= 8 stages (1024 rows) per split
     if (nsplit < 1) nsplit = 1;
@@ -258,12 +272,22 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     return pl;
 }
 
-template <int NB, int KTOP>
+template <int NB, int KTOP, int NW>
 static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
 {
-    if (glds) hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, true>), dim3(grid), dim3(256), 0, stream, p);
-    else      hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, false>), dim3(grid), dim3(256), 0, stream, p);
+    if (glds) hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, true, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
+    else      hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, false, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
     return hipGetLastError();
+}
+
+template <int KTOP>
+static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool glds, hipStream_t stream)
+{
+    if (nb == 1) return launch_t<1, KTOP, 4>(p, grid, glds, stream);
+    if (nb == 4) return launch_t<4, KTOP, 4>(p, grid, glds, stream);
+    if (nw == 16) return launch_t<2, KTOP, 16>(p, grid, glds, stream);
+    if (nw == 8) return launch_t<2, KTOP, 8>(p, grid, glds, stream);
+    return launch_t<2, KTOP, 4>(p, grid, glds, stream);
 }
 
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
@@ -279,23 +303,13 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
     p.nred = (int)red.n;
     p.nstages = (int)(red.n_pad / kStageRows);
     p.nsplit = plan.nsplit;
+    p.nchunks = plan.nchunks;
     p.stages_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
     const int grid = plan.nchunks * plan.nsplit;
-    if (ktop == 1) {
-        switch (plan.nb) {
-            case 1: return launch_t<1, 1>(p, grid, use_glds, stream);
-            case 2: return launch_t<2, 1>(p, grid, use_glds, stream);
-            default: return launch_t<4, 1>(p, grid, use_glds, stream);
-        }
-    } else {
-        switch (plan.nb) {
-            case 1: return launch_t<1, 2>(p, grid, use_glds, stream);
-            case 2: return launch_t<2, 2>(p, grid, use_glds, stream);
-            default: return launch_t<4, 2>(p, grid, use_glds, stream);
-        }
-    }
+    return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, stream)
+                     : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, stream);
 }
 
 }  // namespace fm

@@ -96,7 +96,12 @@ def do_iter(positions, cache, target_grid, tau, thumb_tau=None, radius=100, log=
         # For each match we keep, the neighbouring cell on its side is examined next
         neighbors = get_neighbors(target_pos, acc_pos, target_grid)
         if len(neighbors) > 0:
-            pending.extendleft(reversed(neighbors))
+            # a neighbour whose key is already consumed would be skipped when popped (keys are
+            # only ever added), so dropping it here cannot change the visiting order
+            fresh = [nb for nb in neighbors
+                     if target_grid.block(nb[1][0], nb[1][1]) + target_grid.block(nb[0][0], nb[0][1])
+                     not in has_matched]
+            pending.extendleft(reversed(fresh))
         if log is not None:
             log.append(log_round(query_pos, target_pos, result_pos, target_grid, ratios, tau, radius))
         for p, r, index in zip(acc_pos, ratios[accepted], query_idx[accepted]):
@@ -117,13 +122,34 @@ def do_iter(positions, cache, target_grid, tau, thumb_tau=None, radius=100, log=
 
 
 def get_neighbors(target_pos, result_pos, target_grid):
-    col, row = target_grid.block(target_pos[0], target_pos[1])
-    neighbors = []
-    for p_query, p_target in result_pos:
-        neighbor_pos = target_grid.get_neighbor(col, row, p_target[0], p_target[1])
-        if neighbor_pos[0] != -1:
-            neighbors.append(np.array((p_query, neighbor_pos), dtype=np.float64))
-    return neighbors
+    """For every kept match, the centre of the 4-neighbour cell on the side of the current
+    cell its target point lies closest to (reference fastmatch.pyx:92-103 +
+    Grid_Cache.get_neighbor cache.pyx:72-92), vectorised over the matches; order kept."""
+    if len(result_pos) == 0:
+        return []
+    g = target_grid
+    col, row = g.block(target_pos[0], target_pos[1])
+    cx, cy = g.center(col, row)
+    pt = np.asarray(result_pos)[:, 1, :]
+    x_diff = pt[:, 0].astype(np.int64) - int(cx)          # int() truncation (cache.pyx:82-83)
+    y_diff = pt[:, 1].astype(np.int64) - int(cy)
+    up = (y_diff < x_diff) & (y_diff < -x_diff)
+    right = ~up & (x_diff > y_diff)
+    down = ~up & ~right & (y_diff > -x_diff)
+    left = ~up & ~right & ~down
+    ncol = col + np.where(down, 1, 0) - np.where(up, 1, 0)
+    nrow = row + np.where(right, 1, 0) - np.where(left, 1, 0)
+    ok = (ncol >= 0) & (ncol < g.cols) & (nrow >= 0) & (nrow < g.rows)
+    if not ok.any():
+        return []
+    # centre of the neighbour cell, clipped like Grid_Cache.center (cache.pyx:116-121)
+    nx = np.minimum(((nrow + 0.5) * g.cell_width).astype(np.int64), g.width - 1)
+    ny = np.minimum(((ncol + 0.5) * g.cell_height).astype(np.int64), g.height - 1)
+    out = np.empty((int(ok.sum()), 2, 2), dtype=np.float64)
+    out[:, 0, :] = np.asarray(result_pos)[ok, 0, :]
+    out[:, 1, 0] = nx[ok]
+    out[:, 1, 1] = ny[ok]
+    return list(out)
 
 
 def _thumb_features(img, thumb_x, thumb_y):
