@@ -27,6 +27,22 @@ class fm_stats(ctypes.Structure):
                 ("calls", ctypes.c_int64)]
 
 
+class fm_expand_desc(ctypes.Structure):
+    _fields_ = [("query", ctypes.c_void_p), ("query_pos", ctypes.c_void_p),
+                ("index_bucket", ctypes.c_double), ("index_x0", ctypes.c_double), ("index_y0", ctypes.c_double),
+                ("index_nbx", ctypes.c_int32), ("index_nby", ctypes.c_int32),
+                ("index_order", ctypes.c_void_p), ("index_start", ctypes.c_void_p),
+                ("target", ctypes.c_void_p), ("cell_off", ctypes.c_void_p), ("target_pos", ctypes.c_void_p),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("cell_w", ctypes.c_int32), ("cell_h", ctypes.c_int32),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("margin", ctypes.c_int32), ("radius", ctypes.c_int32),
+                ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64)]
+
+
+EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 2048 rows",
+                 3: "target position outside the image", 4: "result list full", 5: "hash table full"}
+
 # name -> (restype, argtypes); every symbol include/fastmatch_hip.h declares
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -52,6 +68,10 @@ SYMBOLS = {
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "fm_expand_create": (_INT, [_P, ctypes.POINTER(fm_expand_desc), ctypes.POINTER(_P)]),
+    "fm_expand_destroy": (_INT, [_P, _P]),
+    "fm_expand_run": (_INT, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fm_expand_fetch": (_INT, [_P, _P, _I64, _P, _P, _P]),
 }
 
 _lib = None
@@ -101,6 +121,53 @@ class Bank(object):
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             self.ctx.lib.fm_bank_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Expander(object):
+    """Device-resident expansion state of one image pair (fm_expand)."""
+
+    def __init__(self, ctx, q_bank, q_pos, index, t_bank, cell_off, t_pos, grid, radius,
+                 match_cap=0, stack_cap=0):
+        self.ctx = ctx
+        self.handle = None
+        # keep every host array alive until fm_expand_create has copied it
+        q_pos = np.ascontiguousarray(q_pos, dtype=np.float64).reshape(-1, 2)
+        order = np.ascontiguousarray(index.order, dtype=np.int32)
+        start = np.ascontiguousarray(index.start, dtype=np.int32)
+        cell_off = np.ascontiguousarray(cell_off, dtype=np.int64)
+        t_pos = np.ascontiguousarray(t_pos, dtype=np.float64).reshape(-1, 2)
+        d = fm_expand_desc()
+        d.query, d.query_pos = q_bank.handle, _ptr(q_pos)
+        d.index_bucket, d.index_x0, d.index_y0 = index.bucket, index.x0, index.y0
+        d.index_nbx, d.index_nby = index.nbx, index.nby
+        d.index_order, d.index_start = _ptr(order), _ptr(start)
+        d.target, d.cell_off, d.target_pos = t_bank.handle, _ptr(cell_off), _ptr(t_pos)
+        d.width, d.height = grid["width"], grid["height"]
+        d.cell_w, d.cell_h = grid["cell_w"], grid["cell_h"]
+        d.rows, d.cols, d.margin, d.radius = grid["rows"], grid["cols"], grid["margin"], int(radius)
+        d.match_cap, d.stack_cap = int(match_cap), int(stack_cap)
+        h = _P()
+        ctx._check(ctx.lib.fm_expand_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
+        self.handle = h
+        self._banks = (q_bank, t_bank)            # the banks must outlive the expander
+
+    def fetch(self, n):
+        index = np.empty(n, dtype=np.int32)
+        pos = np.empty((n, 2, 2), dtype=np.float64)
+        ratio = np.empty(n, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.fm_expand_fetch(self.ctx.handle, self.handle, n, _ptr(index), _ptr(pos), _ptr(ratio)))
+        return index, pos, ratio
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.ctx.lib.fm_expand_destroy(self.ctx.handle, self.handle)
         self.handle = None
 
     def __del__(self):
@@ -251,6 +318,23 @@ class Context(object):
         self._check(self.lib.fm_xcheck1_batched(self.handle, q.handle, _ptr(q_rows), _ptr(q_off), t.handle,
                                                 _ptr(t_off), nb, _ptr(tidx), _ptr(dist), _ptr(ratio)))
         return tidx, dist, ratio
+
+    def expand_run(self, expanders, seeds, taus):
+        """Run the device-resident expansion loop for several pairs in one launch.
+        Returns per pair (n_matches, n_rounds, n_pairs, status)."""
+        n = len(expanders)
+        seeds = [np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 2, 2) for s in seeds]
+        hs = (_P * n)(*[e.handle for e in expanders])
+        sp = (_P * n)(*[s.ctypes.data if s.shape[0] else None for s in seeds])
+        ns = np.array([s.shape[0] for s in seeds], dtype=np.int64)
+        tau = np.ascontiguousarray(taus, dtype=np.float64)
+        nm = np.zeros(n, dtype=np.int64)
+        nr = np.zeros(n, dtype=np.int64)
+        npairs = np.zeros(n, dtype=np.int64)
+        st = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.fm_expand_run(self.handle, n, hs, sp, _ptr(ns), _ptr(tau), _ptr(nm), _ptr(nr),
+                                           _ptr(npairs), _ptr(st)))
+        return [(int(nm[i]), int(nr[i]), int(npairs[i]), int(st[i])) for i in range(n)]
 
     # -- bookkeeping ---------------------------------------------------------------------
     def stats(self):

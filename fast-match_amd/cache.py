@@ -261,6 +261,30 @@ class Grid_Cache(object):
         return bounds
 
     # -- device residency -----------------------------------------------------------------
+    def pack_cells(self):
+        """Every cell's features packed cell after cell (cell id = col * rows + row) for the
+        device-resident loop: (descriptors [nt, dim], positions f64[nt, 2] in full-image
+        coordinates with offset() applied as match_position does (fastmatch.pyx:157-158),
+        cell_off int64[cols*rows + 1]).  Computes every cell (cache.pyx:124-138)."""
+        descs, poss = [], []
+        cell_off = np.zeros(self.cols * self.rows + 1, dtype=np.int64)
+        dim, dtype = None, None
+        for col in range(self.cols):
+            for row in range(self.rows):
+                kp, ds = self.get_cell(col, row)
+                n = 0 if ds is None else len(ds)
+                if n:
+                    ds = np.asarray(ds)
+                    dim, dtype = ds.shape[1], ds.dtype
+                    off = np.array([row * self.cell_width - self.margin, col * self.cell_height - self.margin],
+                                   dtype=np.float64)
+                    descs.append(ds)
+                    poss.append(keypoint_positions(kp) + off)
+                cell_off[col * self.rows + row + 1] = cell_off[col * self.rows + row] + n
+        if descs:
+            return np.concatenate(descs), np.concatenate(poss), cell_off
+        return np.zeros((0, 128), dtype=np.uint8), np.zeros((0, 2), dtype=np.float64), cell_off
+
     def cell_bank(self, col, row, context):
         """Device bank of the cell's descriptors (uploaded once), or None if it has none."""
         key = (col, row)

@@ -5,6 +5,7 @@
 //   top-2 merge of the split partials for knnMatch(k=2)
 // Reference call sites are cited in the header next to each entry point.
 #include "fm_internal.h"
+#include "expand_pair.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -773,4 +774,177 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
     HIP_TRY(ctx, hipMemcpyAsync(dist, ob + o_dist, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ob + o_ratio, (size_t)tot * 8, hipMemcpyDeviceToHost, ctx->stream));
     return cs.finish();
+}
+
+// ---------------------------------------------------------------------------------------
+// K7 entry points
+// ---------------------------------------------------------------------------------------
+struct fm_expand {
+    ExpandPair dev{};              // device pointers + parameters (seeds/tau filled per run)
+    void* blob = nullptr;          // one allocation holding every static + work array
+    double* d_seeds = nullptr;     // grown on demand
+    int64_t seeds_cap = 0;
+    int64_t nq = 0;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int64_t pow2_at_least(int64_t x) { int64_t p = 1; while (p < x) p <<= 1; return p; }
+
+extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_create: ctx is NULL");
+    if (!d || !out) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL argument");
+    *out = nullptr;
+    if (!d->query || !d->target) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL bank");
+    if (d->query->kind != FM_BANK_I8 || d->target->kind != FM_BANK_I8)
+        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: the device loop needs integer-valued (int8 route) banks");
+    if (d->query->dim != d->target->dim) return fail(ctx, FM_EINVAL, "fm_expand_create: dim mismatch");
+    if (!d->query->selfdist) return fail(ctx, FM_EINVAL, "fm_expand_create: query bank has no self distances");
+    const int64_t nq = d->query->n, nt = d->target->n;
+    const int64_t ncells = (int64_t)d->rows * d->cols;
+    if (d->width < 1 || d->height < 1 || d->cell_w < 1 || d->cell_h < 1 || d->rows < 1 || d->cols < 1 || d->radius < 0)
+        return fail(ctx, FM_EINVAL, "fm_expand_create: bad grid parameters");
+    if (d->rows > 65535 || d->cols > 65535 || d->width > 65535 || d->height > 65535)
+        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: image or grid too large for 16-bit cell keys");
+    if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || !d->cell_off || (nt > 0 && !d->target_pos))
+        return fail(ctx, FM_EINVAL, "fm_expand_create: NULL array");
+    const int64_t nb = (int64_t)d->index_nbx * d->index_nby;
+    if (d->index_nbx < 0 || d->index_nby < 0 || d->index_start[nb] != nq || !(d->index_bucket > 0.0))
+        return fail(ctx, FM_EINVAL, "fm_expand_create: inconsistent position index");
+    if (d->cell_off[0] != 0 || d->cell_off[ncells] != nt) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off must cover the target bank");
+    for (int64_t c = 0; c < ncells; ++c)
+        if (d->cell_off[c + 1] < d->cell_off[c]) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off not monotonic");
+    for (int64_t i = 0; i < nq; ++i) {
+        if (d->index_order[i] < 0 || d->index_order[i] >= nq) return fail(ctx, FM_EINVAL, "fm_expand_create: index_order out of range");
+        const double x = d->query_pos[2 * i], y = d->query_pos[2 * i + 1];
+        if (!(x >= 0.0) || !(y >= 0.0) || x / d->cell_w >= 65535.0 || y / d->cell_h >= 65535.0)
+            return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: query position outside the 16-bit cell-key range");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_expand* ex = new (std::nothrow) fm_expand();
+    if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
+    ex->nq = nq;
+    const int64_t match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
+    const int64_t stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
+    const int64_t seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
+    const int64_t found_cap = pow2_at_least(4 * match_cap);
+    // carve one allocation
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
+    const size_t o_qpos = carve((size_t)nq * 16), o_order = carve((size_t)nq * 4), o_start = carve((size_t)(nb + 1) * 4);
+    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16);
+    const size_t o_stack = carve((size_t)stack_cap * 32), o_seen = carve((size_t)seen_cap * 8), o_found = carve((size_t)found_cap * 16);
+    const size_t o_mi = carve((size_t)match_cap * 4), o_mp = carve((size_t)match_cap * 32), o_mr = carve((size_t)match_cap * 8);
+    const size_t o_res = carve(32);
+    hipError_t e = hipMalloc(&ex->blob, off);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
+    char* b = (char*)ex->blob;
+    auto bail = [&](int code) { (void)hipFree(ex->blob); delete ex; return code; };
+#define ETRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); \
+        return bail(fail(ctx, FM_EDEVICE, std::string(#expr " failed: ") + hipGetErrorString(_e))); } } while (0)
+    if (nq) ETRY(hipMemcpyAsync(b + o_qpos, d->query_pos, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nq) ETRY(hipMemcpyAsync(b + o_order, d->index_order, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipMemcpyAsync(b + o_start, d->index_start, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipMemcpyAsync(b + o_coff, d->cell_off, (size_t)(ncells + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) ETRY(hipMemcpyAsync(b + o_tpos, d->target_pos, (size_t)nt * 16, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipStreamSynchronize(ctx->stream));
+#undef ETRY
+    ExpandPair& P = ex->dev;
+    P.q_rows8 = d->query->rows8; P.q_norm = d->query->norm; P.q_selfdist = d->query->selfdist;
+    P.q_pos = (const double*)(b + o_qpos);
+    P.idx_order = (const int32_t*)(b + o_order); P.idx_start = (const int32_t*)(b + o_start);
+    P.idx_bucket = d->index_bucket; P.idx_x0 = d->index_x0; P.idx_y0 = d->index_y0;
+    P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;
+    P.t_rows8 = d->target->rows8; P.t_norm = d->target->norm;
+    P.cell_off = (const int64_t*)(b + o_coff); P.t_pos = (const double*)(b + o_tpos);
+    P.width = d->width; P.height = d->height; P.cell_w = d->cell_w; P.cell_h = d->cell_h;
+    P.rows = d->rows; P.cols = d->cols; P.margin = d->margin; P.radius = d->radius;
+    P.seeds = nullptr; P.n_seeds = 0; P.tau = 0.0;
+    P.stack = (double*)(b + o_stack); P.stack_cap = stack_cap;
+    P.seen = (unsigned long long*)(b + o_seen); P.seen_cap = seen_cap;
+    P.found = (unsigned long long*)(b + o_found); P.found_cap = found_cap;
+    P.m_index = (int32_t*)(b + o_mi); P.m_pos = (double*)(b + o_mp); P.m_ratio = (double*)(b + o_mr);
+    P.match_cap = match_cap;
+    P.result = (long long*)(b + o_res);
+    *out = ex;
+    return FM_OK;
+}
+
+extern "C" int fm_expand_destroy(fm_ctx* ctx, fm_expand* ex)
+{
+    if (!ex) return FM_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ex->blob) (void)hipFree(ex->blob);
+    if (ex->d_seeds) (void)hipFree(ex->d_seeds);
+    delete ex;
+    return FM_OK;
+}
+
+extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
+                             const int64_t* n_seeds, const double* tau, int64_t* n_matches,
+                             int64_t* n_rounds, int64_t* n_pairs, int32_t* status)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_run: ctx is NULL");
+    if (n < 0) return fail(ctx, FM_EINVAL, "fm_expand_run: n < 0");
+    if (n == 0) return FM_OK;
+    if (!pairs || !seeds || !n_seeds || !tau) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<ExpandPair> host((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        fm_expand* ex = pairs[i];
+        if (!ex) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL pair");
+        for (int j = 0; j < i; ++j) if (pairs[j] == ex) return fail(ctx, FM_EINVAL, "fm_expand_run: a pair appears twice in one launch");
+        if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
+        if (n_seeds[i] > ex->seeds_cap) {
+            if (ex->d_seeds) { HIP_TRY(ctx, hipFree(ex->d_seeds)); ex->d_seeds = nullptr; ex->seeds_cap = 0; }
+            const int64_t cap = n_seeds[i] + n_seeds[i] / 2 + 64;
+            HIP_TRY(ctx, hipMalloc((void**)&ex->d_seeds, (size_t)cap * 32));
+            ex->seeds_cap = cap;
+        }
+    }
+    int rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, (size_t)n * sizeof(ExpandPair) + 64);
+    if (rc != FM_OK) return rc;
+    CallScope cs(ctx);
+    for (int i = 0; i < n; ++i) {
+        fm_expand* ex = pairs[i];
+        if (n_seeds[i]) HIP_TRY(ctx, hipMemcpyAsync(ex->d_seeds, seeds[i], (size_t)n_seeds[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ex->dev.seen, 0xff, (size_t)ex->dev.seen_cap * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ex->dev.found, 0xff, (size_t)ex->dev.found_cap * 16, ctx->stream));
+        host[i] = ex->dev;
+        host[i].seeds = ex->d_seeds;
+        host[i].n_seeds = n_seeds[i];
+        host[i].tau = tau[i];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, host.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_expand(ctx->ws_in, n, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    std::vector<long long> res((size_t)n * 4);
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], pairs[i]->dev.result, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
+    rc = cs.finish();
+    if (rc != FM_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (n_matches) n_matches[i] = res[(size_t)i * 4 + 0];
+        if (n_rounds) n_rounds[i] = res[(size_t)i * 4 + 1];
+        if (n_pairs) n_pairs[i] = res[(size_t)i * 4 + 2];
+        if (status) status[i] = (int32_t)res[(size_t)i * 4 + 3];
+    }
+    return FM_OK;
+}
+
+extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index, double* positions, double* ratio)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_fetch: NULL argument");
+    if (n < 0 || n > ex->dev.match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch: n out of range");
+    if (n == 0) return FM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (index) HIP_TRY(ctx, hipMemcpyAsync(index, ex->dev.m_index, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (positions) HIP_TRY(ctx, hipMemcpyAsync(positions, ex->dev.m_pos, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ex->dev.m_ratio, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FM_OK;
 }

@@ -1,0 +1,43 @@
+// Device-side descriptor of one image pair for expand_kernel (expand.hip); filled by api.hip.
+#pragma once
+#include <stdint.h>
+
+namespace fm {
+
+struct ExpandPair {
+    // query side
+    const int8_t*  q_rows8;
+    const int32_t* q_norm;
+    const double*  q_selfdist;
+    const double*  q_pos;          // [nq][2]
+    const int32_t* idx_order;      // keypoints sorted by bucket
+    const int32_t* idx_start;      // [nbx*nby + 1]
+    double idx_bucket, idx_x0, idx_y0;
+    int    idx_nbx, idx_nby;
+    // target side: every grid cell's descriptors packed back to back
+    const int8_t*  t_rows8;
+    const int32_t* t_norm;
+    const int64_t* cell_off;       // [cols*rows + 1], cell id = col * rows + row
+    const double*  t_pos;          // [nt_total][2] full-image coordinates (offset() applied)
+    int width, height, cell_w, cell_h, rows, cols, margin, radius;
+    // run inputs
+    const double* seeds;           // [n_seeds][2][2]
+    int64_t n_seeds;
+    double  tau;
+    // work memory
+    double* stack;                 // [stack_cap][4]
+    int64_t stack_cap;
+    unsigned long long* seen;      // open-addressing set of round keys, capacity seen_cap (pow2)
+    int64_t seen_cap;
+    unsigned long long* found;     // [found_cap][2] (ratio bits, packed int positions)
+    int64_t found_cap;
+    // outputs
+    int32_t* m_index;              // [match_cap]
+    double*  m_pos;                // [match_cap][4]
+    double*  m_ratio;              // [match_cap]
+    int64_t  match_cap;
+    long long* result;             // [4]: n_matches, n_rounds, n_pairs, status
+};
+
+
+}  // namespace fm

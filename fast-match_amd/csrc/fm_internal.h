@@ -68,6 +68,10 @@ hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, 
                          double* d_ratio, hipStream_t stream);
 int round_qcap();
 
+// ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
+hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream);
+int expand_cand_cap();
+
 }  // namespace fm
 
 struct fm_bank : fm::Bank {};

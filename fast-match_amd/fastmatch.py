@@ -51,14 +51,107 @@ def match(query_cache, target_img, options={}):
     thumb_positions, thumb_ratios = match_thumbs(target_img, query_cache, thumb_x=thumb_x, thumb_y=thumb_y,
                                                  context=context)
 
+    # The whole expansion loop runs on the device when every target feature is known up
+    # front (a Feature_Image) and no per-round log is wanted; otherwise (lazy SIFT per cell,
+    # logging) the host replays the loop and only each round's arithmetic runs on the device.
+    use_device_loop = (isinstance(target_img, Feature_Image) and log is None
+                       and options.get("device_loop", True))
+    state = {"expander": None}
+
     # A function where tau can be varied to get different results
     def get_matches(tau):
         thumb_tau = thumb_strategy(tau)
         seeds = thumb_positions[thumb_ratios < thumb_tau]
+        if use_device_loop:
+            if state["expander"] is None:
+                state["expander"] = make_expander(query_cache, target_cache, radius, context)
+            if state["expander"] is not False:
+                res = run_device_loops(context, [state["expander"]], [seeds], [tau], stats=stats,
+                                       as_arrays=options.get("return_arrays", False))[0]
+                if res is not None:
+                    return res
         return do_iter(iter(seeds), query_cache, target_cache, tau=tau, thumb_tau=thumb_tau,
                        radius=radius, log=log, context=context, stats=stats)
 
     return get_matches
+
+
+def make_expander(query_cache, target_grid, radius, context):
+    """Device-resident expansion state for (query_cache, target_grid), or False when the
+    pair cannot use the device loop (non-integer descriptors, oversize geometry)."""
+    from . import _ffi
+    q_bank = query_cache.bank(context)
+    if q_bank.kind != _ffi.FM_BANK_I8:
+        return False
+    descs, t_pos, cell_off = target_grid.pack_cells()
+    t_bank = context.bank(descs)
+    if t_bank.kind != _ffi.FM_BANK_I8 or t_bank.dim != q_bank.dim:
+        return False
+    grid = {"width": target_grid.width, "height": target_grid.height, "cell_w": target_grid.cell_width,
+            "cell_h": target_grid.cell_height, "rows": target_grid.rows, "cols": target_grid.cols,
+            "margin": target_grid.margin}
+    try:
+        return _ffi.Expander(context, q_bank, query_cache.original["positions"],
+                             query_cache.original["position_tree"], t_bank, cell_off, t_pos, grid, radius)
+    except _ffi.FastMatchHipError:
+        return False
+
+
+def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):
+    """One launch of the device-resident loop for several independent pairs.  Returns, per
+    pair, the match list in do_iter's format (or (index, positions, ratio) arrays), or None
+    where the device gave up (caller falls back to the host loop)."""
+    out = []
+    results = context.expand_run(expanders, seeds, taus)
+    for ex, (n_matches, n_rounds, n_pairs, status) in zip(expanders, results):
+        if status != 0:
+            out.append(None)
+            continue
+        if stats is not None:
+            stats["rounds"] = stats.get("rounds", 0) + n_rounds
+            stats["pairs"] = stats.get("pairs", 0) + n_pairs
+        index, pos, ratio = ex.fetch(n_matches)
+        if as_arrays:
+            out.append((index, pos, ratio))
+        else:
+            out.append([(int(i), {"positions": p, "ratio": float(r)}) for i, p, r in zip(index, pos, ratio)])
+    return out
+
+
+def match_many(pairs, tau, options={}):
+    """Match several independent (query_cache, Feature_Image) pairs at one threshold with a
+    single launch of the device-resident loop (one workgroup per pair).  Addition: the
+    reference maps its matcher over pairs one after the other (turntable.py:59)."""
+    context = matchutil._context(options)
+    thumb_strategy = options.get("thumb_strategy", lambda n: n)
+    grid_x, grid_y = options.get("grid_size", (50, 50))
+    thumb_x, thumb_y = options.get("thumb_size", (400, 400))
+    margin, radius = options.get("grid_margin", 25), options.get("radius", 100)
+    prepared = options.get("prepared")
+    if prepared is None:
+        prepared = []
+        for query_cache, target in pairs:
+            grid = Grid_Cache(target, (grid_x, grid_y), target, margin=margin)
+            pos, ratios = match_thumbs(target, query_cache, thumb_x=thumb_x, thumb_y=thumb_y, context=context)
+            prepared.append({"query": query_cache, "grid": grid, "seeds": pos, "ratios": ratios,
+                             "expander": make_expander(query_cache, grid, radius, context)})
+        if "prepared_out" in options:
+            options["prepared_out"].extend(prepared)
+    thumb_tau = thumb_strategy(tau)
+    seeds = [p["seeds"][p["ratios"] < thumb_tau] for p in prepared]
+    on_dev = [i for i, p in enumerate(prepared) if p["expander"] not in (None, False)]
+    results = [None] * len(prepared)
+    stats = options.get("stats")
+    if on_dev:
+        got = run_device_loops(context, [prepared[i]["expander"] for i in on_dev], [seeds[i] for i in on_dev],
+                               [tau] * len(on_dev), stats=stats, as_arrays=options.get("return_arrays", False))
+        for i, g in zip(on_dev, got):
+            results[i] = g
+    for i, p in enumerate(prepared):
+        if results[i] is None:
+            results[i] = do_iter(iter(seeds[i]), p["query"], p["grid"], tau=tau, radius=radius, context=context,
+                                 stats=stats)
+    return results
 
 
 def do_iter(positions, cache, target_grid, tau, thumb_tau=None, radius=100, log=None, context=None,

@@ -135,6 +135,55 @@ int  fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows,
                         const int64_t* t_off /*[B+1]*/, int64_t n_rounds,
                         int32_t* tidx, float* dist, double* ratio /*or NULL*/);
 
+/* ---- K7: device-resident expansion loop ------------------------------------------------
+ * Replaces the whole of do_iter + get_neighbors + match_position (fastmatch.pyx:56-103,
+ * 145-169) for an image pair whose features are all known up front: the query bank with its
+ * keypoint positions and position index (Metric_Cache.original, cache.pyx:278-284) and
+ * every Grid_Cache cell's descriptors packed back to back (cache.pyx:124-138).  One
+ * persistent workgroup per pair replays the reference's depth-first order exactly; many
+ * pairs run concurrently in one launch.  Results come back in discovery order.            */
+typedef struct fm_expand fm_expand;
+
+typedef struct fm_expand_desc {
+    const fm_bank* query;          /* query bank carrying self distances                    */
+    const double*  query_pos;      /* [nq][2] keypoint positions (x, y)                     */
+    double         index_bucket;   /* uniform-grid position index over query_pos:           */
+    double         index_x0, index_y0;   /*   bucket size and origin                         */
+    int32_t        index_nbx, index_nby; /*   buckets along x / y                            */
+    const int32_t* index_order;    /* [nq] keypoints sorted by bucket (by*nbx + bx)         */
+    const int32_t* index_start;    /* [nbx*nby + 1] first entry of each bucket in order[]   */
+    const fm_bank* target;         /* all cells' descriptors, cell after cell               */
+    const int64_t* cell_off;       /* [cols*rows + 1] row range of cell id = col*rows + row */
+    const double*  target_pos;     /* [nt][2] full-image keypoint positions (offset applied)*/
+    int32_t        width, height;  /* target image size                                     */
+    int32_t        cell_w, cell_h; /* Grid_Cache cell size                                  */
+    int32_t        rows, cols;     /* Grid_Cache.rows (cells along x), .cols (along y)      */
+    int32_t        margin, radius;
+    int64_t        match_cap;      /* capacity of the result list (0 = 4 * nq)              */
+    int64_t        stack_cap;      /* capacity of the pending stack (0 = default)           */
+} fm_expand_desc;
+
+#define FM_EXPAND_OK            0
+#define FM_EXPAND_STACK_FULL    1
+#define FM_EXPAND_SUBSET_FULL   2  /* a radius subset exceeded 2048 query rows              */
+#define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
+#define FM_EXPAND_MATCH_FULL    4
+#define FM_EXPAND_TABLE_FULL    5
+
+int  fm_expand_create(fm_ctx* ctx, const fm_expand_desc* desc, fm_expand** out);
+int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
+/* Run n pairs in one launch.  seeds[i] = [n_seeds[i]][2][2] float64 (query_pos, target_pos)
+ * in visiting order (fastmatch.pyx:50), tau[i] the ratio threshold.  Per pair outputs:
+ * number of matches, rounds, descriptor pairs evaluated, and a FM_EXPAND_* status (non-zero
+ * = the device gave up; the caller falls back to the host loop).                          */
+int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
+                   const int64_t* n_seeds, const double* tau, int64_t* n_matches,
+                   int64_t* n_rounds, int64_t* n_pairs, int32_t* status);
+/* Copy the first n results of the last run of `ex`: query row index, positions [n][2][2]
+ * (query x,y then target x,y) and ratio -- the tuples do_iter appends (fastmatch.pyx:86). */
+int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index,
+                     double* positions, double* ratio);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,69 @@ def test_match_position_round(ctx):
         p, r, i = fastmatch.match_position(pos, mc, grid, radius=100, context=ctx)
         op, orr, oi = fo.o_match_position(pos, oq, ogrid, 100)
         assert np.array_equal(p, op) and np.array_equal(r, orr) and np.array_equal(i, oi)
+
+
+# ---- device-resident expansion loop (K7) --------------------------------------------------
+@pytest.mark.parametrize("size,n,opts", [
+    ((800, 640), 3000, {}),
+    ((800, 640), 3000, {"grid_size": (75, 75), "grid_margin": 30, "radius": 50}),
+    ((1000, 1000), 12500, {}),
+    ((611, 389), 2500, {"grid_size": (64, 48), "grid_margin": 0, "radius": 75, "thumb_strategy": lambda t: t * 1.2}),
+    ((300, 200), 40, {}),                                  # nearly empty cells, tiny subsets
+])
+def test_device_loop_equals_oracle_and_host_loop(ctx, size, n, opts, monkeypatch):
+    mc, fi, oq, ot = _build(size, n, seed=7 * size[0] + n, ctx=ctx, n_thumb=min(600, n))
+    stats, hstats = {}, {}
+    ran = []
+    orig = fastmatch.run_device_loops
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        ran.append([x is not None for x in r])
+        return r
+    monkeypatch.setattr(fastmatch, "run_device_loops", spy)
+    get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats))
+    hget = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=hstats, device_loop=False))
+    oget = fo.o_match(oq, ot, dict(opts))
+    for tau in (0.7, 0.95, 0.4):
+        stats.clear()
+        hstats.clear()
+        got, host, exp = get(tau), hget(tau), oget(tau)
+        assert ran and ran[-1] == [True], "device loop did not run"
+        _same_matches(got, exp)
+        _same_matches(host, exp)
+        assert stats["rounds"] == hstats["rounds"] == oget.rounds
+        assert stats["pairs"] == hstats["pairs"]
+
+
+def test_device_loop_return_arrays_and_many_pairs(ctx):
+    pairs, oracles = [], []
+    for k in range(5):
+        mc, fi, oq, ot = _build((640, 480), 2000 + 300 * k, seed=900 + k, ctx=ctx)
+        pairs.append((mc, fi))
+        oracles.append(fo.o_match(oq, ot, {}))
+    prepared, stats = [], {}
+    res = fastmatch.match_many(pairs, 0.7, {"context": ctx, "prepared_out": prepared, "stats": stats})
+    assert len(res) == 5 and all(p["expander"] not in (None, False) for p in prepared)
+    rounds = 0
+    for r, og in zip(res, oracles):
+        _same_matches(r, og(0.7))
+        rounds += og.rounds
+    assert stats["rounds"] == rounds
+    # same prepared state, other threshold, array output
+    res2 = fastmatch.match_many(pairs, 0.9, {"context": ctx, "prepared": prepared, "return_arrays": True})
+    for (index, pos, ratio), og in zip(res2, oracles):
+        exp = og(0.9)
+        assert index.tolist() == [e[0] for e in exp]
+        assert np.array_equal(ratio, np.array([e[1]["ratio"] for e in exp]))
+        assert np.array_equal(pos, np.array([e[1]["positions"] for e in exp]).reshape(-1, 2, 2))
+
+
+def test_device_loop_falls_back_when_it_cannot_run(ctx):
+    # a radius that makes the query subset exceed the device capacity (2048 rows): the device
+    # reports it and match() silently replays the loop on the host with identical results
+    mc, fi, oq, ot = _build((400, 300), 6000, seed=77, ctx=ctx)
+    stats = {}
+    got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.7)
+    exp = fo.o_match(oq, ot, {"radius": 200})(0.7)
+    _same_matches(got, exp)
