@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 NQ = NT = 100000
 TAU = 0.7
 SEED = 20250002
+PROFILE_JSON = os.path.join(ROOT, "profiles", "latest_pmc.json")   # written by scripts/profile.sh
 INT8_DENSE_PEAK_TOPS = 5000.0     # MI355X dense int8 MFMA (2x bf16's ~2.5 PF), MI355X_MICROARCH.md
 OPS_PER_PAIR = 256                # 128 MACs per 128-D descriptor pair
 
@@ -90,10 +91,10 @@ def main():
 
     def step():
         tidx, d, ratio, passed, npass = ctx.match_ratio(qb, tb, TAU, out=outbuf)
-        q_acc = np.nonzero(passed)[0]
+        q_acc = np.nonzero(passed.view(np.bool_))[0]
         packed = sharding.pack_matches(q_acc, tidx[q_acc], d[q_acc])
         if world > 1:
-            sharding.all_gather_matches(packed, device=dev, capacity=NQ)
+            sharding.all_gather_matches(packed, device=dev, capacity=NQ, to_host=False)
         return npass
 
     def barrier():
@@ -129,6 +130,13 @@ def main():
         k_ms = st["kernel_ms"] / max(st["kernel_launches"], 1)
         call_ms = st["total_ms"] / max(st["calls"], 1)
         achieved = pairs_per_step * OPS_PER_PAIR / (k_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per K1 launch from the committed rocprofv3 PMC passes (not live)
+            with open(PROFILE_JSON) as f:
+                pj = json.load(f)
+            traffic, traffic_src = pj["hbm_bytes_per_launch"], pj["source"]
+        except Exception:
+            pass
         out = {
             "metric": "descriptor-pair distances/sec (cross-checked 1-NN + ratio test at 0.7)",
             "value": value,
@@ -149,7 +157,7 @@ def main():
             "matches_per_s": npass_all * args.steps / elapsed,
             "accepted_matches_per_step": npass_all,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fm::rowreduce_kernel<2,1,true>", "kernel_ms": k_ms,
                          "note": "int8 ops: 256 per descriptor pair; HIP-event time of the K1 launch on its own stream"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,

@@ -25,6 +25,7 @@
 // double buffer, XOR swizzle applied on the source address so that the ds_read_b128
 // A-fragment reads are bank-conflict free.
 #include "tile_ops.h"
+#include <type_traits>
 
 namespace fm {
 
@@ -127,25 +128,40 @@ void rowreduce_kernel(RRParams p)
 
     if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
 
-    for (int st = st0; st < st1; ++st) {
-        char* buf = smem + ((st - st0) & 1) * kStageBytes;
+    // Bounds published by the blocks that reduce other slices for the same output rows:
+    // bound[n] is the K-th best hi some block has reached, so the final K-th best is
+    // >= bound[n] and a candidate with hi < bound[n] can be dropped.  Stale values are
+    // merely weaker bounds, so relaxed agent-scope loads suffice; the comparison is
+    // non-strict (hi >= bound) because the owner of the bound may have a higher index.
+    // The loads for stage s+1 are issued during stage s (next to the LDS-DMA prefetch) and
+    // consumed after the wait that retires that prefetch, so they never stall the wave.
+    int gnext[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = cb + 32 * j + (lane & 31);
+        gnext[j] = (p.bound && n < p.ncols_alloc)
+            ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
+    }
+
+    // One pipeline step on LDS buffer BUF (compile-time, so every ds_read address is
+    // base register + immediate); the stage loop below is unrolled by two.
+    auto stage = [&](auto buf_tag, int st) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        char* buf = smem + BUF * kStageBytes;
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // stage st landed; every wave is done with the other buffer
-        if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + ((st + 1 - st0) & 1) * kStageBytes, wave, lane);
-
-        // Bounds published by the blocks that reduce other slices for the same output rows:
-        // bound[n] is the K-th best hi some block has reached, so the final K-th best is
-        // >= bound[n] and a candidate with hi < bound[n] can be dropped.  Stale values are
-        // merely weaker bounds, so relaxed agent-scope loads suffice; the comparison is
-        // non-strict (hi >= bound) because the owner of the bound may have a higher index.
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            gthr[j] = gnext[j] >> 1;                    // hi >= g possible iff acc >= floor(g / 2)
+            thr[j] = max(thr[j], gthr[j]);
+        }
+        if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
         if (p.bound) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int n = cb + 32 * j + (lane & 31);
-                const int g = (n < p.ncols_alloc)
-                    ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
-                gthr[j] = g >> 1;                       // hi >= g possible iff acc >= floor(g / 2)
-                thr[j] = max(thr[j], gthr[j]);
+                if (n < p.ncols_alloc)
+                    gnext[j] = __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 
@@ -179,6 +195,11 @@ void rowreduce_kernel(RRParams p)
                 }
             }
         }
+    };
+
+    for (int st = st0; st < st1; st += 2) {
+        stage(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
     }
 
     // Merge the two lane halves (same output row, interleaved reduced rows), then emit.

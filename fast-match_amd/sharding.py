@@ -26,12 +26,14 @@ def unpack_matches(packed):
     return packed[:, 0].copy(), packed[:, 1].copy(), packed[:, 2].copy().view(np.float32)
 
 
-def all_gather_matches(packed, device=None, group=None, capacity=None):
+def all_gather_matches(packed, device=None, group=None, capacity=None, to_host=True):
     """Gather every rank's [m_r, 3] int32 match rows; returns a list (by rank) of arrays.
 
     One collective for the counts and one for the padded payloads (a match is 12 bytes, a
     100k-row pair yields < 1 MB: latency bound, never link bound).  ``capacity`` fixes the
-    padded row count (e.g. the query count) so no extra size exchange is needed."""
+    padded row count (e.g. the query count) so no extra size exchange is needed.
+    ``to_host=False`` leaves the gathered rows on the device and returns
+    ``(counts int64[world], rows int32[world, capacity, 3])`` tensors instead."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -59,6 +61,8 @@ def all_gather_matches(packed, device=None, group=None, capacity=None):
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf, group=group)
         allbuf = torch.stack(parts)
+    if not to_host:
+        return counts, allbuf
     counts = counts.cpu().numpy()
     host = allbuf.cpu().numpy()
     return [host[r, :int(counts[r])].copy() for r in range(world)]
