@@ -158,7 +158,7 @@ def main():
             "accepted_matches_per_step": npass_all,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "fm::rowreduce_kernel<2,1,true>", "kernel_ms": k_ms,
+                         "kernel": "fm::rowreduce_kernel<4,1,true,8> (v_mfma_i32_16x16x64_i8)", "kernel_ms": k_ms,
                          "note": "int8 ops: 256 per descriptor pair; HIP-event time of the K1 launch on its own stream"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
                          "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},

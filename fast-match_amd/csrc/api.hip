@@ -119,17 +119,19 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
     sumsq += __shfl_xor(sumsq, 2);
     sumsq += __shfl_xor(sumsq, 4);
     if (c == 0) {
-        const int hh = (r >> 2) & 1;
-        const int reg = (r & 3) + 4 * (r >> 3);
-        int32_t* a = aux + tile * kAuxPerTile;
+        // aux words of the 32-row unit in the accumulator order of v_mfma_i32_16x16x64_i8
+        // (two 16-row tiles; tile row rr sits in lane group rr >> 2, register rr & 3)
+        const int sub = r >> 4, rr = r & 15;
+        const int id = 4 * sub + (rr & 3);
+        int32_t* a = aux + tile * kAuxPerTile + 32 * sub;
         if (row < n) {
             norm[row] = sumsq;
-            a[16 * hh + reg]      = -(sumsq >> 1);
-            a[32 + 16 * hh + reg] = ((1 - (sumsq & 1)) << 4) | (15 - reg);
+            a[rr]      = -(sumsq >> 1);
+            a[16 + rr] = ((1 - (sumsq & 1)) << 4) | (15 - id);
         } else {
             norm[row] = 0;
-            a[16 * hh + reg]      = kPadCinit;
-            a[32 + 16 * hh + reg] = 15 - reg;
+            a[rr]      = kPadCinit;
+            a[16 + rr] = 15 - id;
         }
     }
     if constexpr (SRC_F32) {

@@ -12,12 +12,12 @@ namespace fm {
 // rows8 : int8 [n_pad][128]   descriptor bytes XOR 0x80 (u8 -> i8 shift by 128; L2 is
 //                             shift invariant), zero rows for padding, n_pad % 128 == 0
 // norm  : int32 [n_pad]       nm = sum of squares of the int8 row (<= 2^21)
-// aux   : int32 [n_pad/32][64] per 32-row tile, permuted into MFMA accumulator order:
-//           aux[tile][      16*h + r] = -(nm >> 1)      (accumulator init "cinit")
-//           aux[tile][32 +  16*h + r] = (1 - (nm & 1)) << 4 | (15 - r)   ("low": tie-break
-//                                       parity npar and inverted register index)
-//         for tile row mm = (r&3) + 8*(r>>2) + 4*h   (r = accumulator register 0..15,
-//         h = lane>>5), i.e. the C/D map of v_mfma_i32_32x32x32_i8.
+// aux   : int32 [n_pad/32][64] per 32-row unit = two 16-row MFMA tiles (sub = 0, 1), in the
+//         accumulator order of v_mfma_i32_16x16x64_i8 (tile row rr: lane group rr >> 2,
+//         register rr & 3):
+//           aux[unit][32*sub +      rr] = -(nm >> 1)                       ("cinit")
+//           aux[unit][32*sub + 16 + rr] = (1 - (nm & 1)) << 4 | (15 - id)  ("low": parity
+//                                         npar and inverted in-lane order id = 4*sub + (rr&3))
 //         Padding rows carry cinit = -2^25 (far below any real accumulator value, and
 //         (cinit << 5) still fits int32) so they never beat a real row.
 constexpr int kDim        = 128;
@@ -44,9 +44,9 @@ struct Bank {
 // reduction range, packed candidates  (uint64)d2 << 32 | m  (~0 = none) to
 // partial[(split*ncols_alloc + c)*KTOP + k].
 struct RowReducePlan {
-    int nb;            // 32-column blocks per wave (1, 2 or 4)
+    int nb;            // blocks of 16 output rows per wave (4 or 8)
     int nw = 4;        // waves per workgroup (4, 8 or 16)
-    int ncols_alloc;   // columns covered by the grid (multiple of 32*nb*nw)
+    int ncols_alloc;   // columns covered by the grid (multiple of 16*nb*nw)
     int nchunks;
     int nsplit;
     int stages_per_split;

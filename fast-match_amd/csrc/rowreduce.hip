@@ -6,24 +6,24 @@
 // for uint8 / integer-valued descriptors: d2(c, m) = |c|^2 + |m|^2 - 2 c.m exactly in
 // int32 on bytes shifted by -128.
 //
-// Mapping onto v_mfma_i32_32x32x32_i8 (D[M x N] += A[M x K] B[K x N]):
-//   N (lane & 31)        = the output row ("column" c) whose nearest neighbours we want;
-//                          its four 32-byte K-chunks stay in VGPRs for the whole sweep.
-//   M (accumulator regs) = the rows being reduced over, streamed through LDS.
+// Mapping onto v_mfma_i32_16x16x64_i8 (D[16 x 16] += A[16 x 64] B[64 x 16], two per
+// 16 x 16 x 128 tile).  This shape sustains ~80 % of the nominal int8 rate on MI355X where
+// 32x32x32 holds 53-69 % (scripts/ablate/shape.hip: the chip clocks the smaller shape higher).
+//   N (lane & 15)        = the output row ("column" c) whose nearest neighbours we want;
+//                          its two 64-byte K-halves stay in VGPRs for the whole sweep.
+//   M (4 (lane>>4) + reg) = the rows being reduced over, streamed through LDS.
 //   Accumulator init     = -(|m|^2 >> 1) from the bank's aux array, so the accumulator is
 //                          acc = c.m - (|m|^2 >> 1) and  |m|^2 - 2 c.m = 1 - (2 acc + npar).
-// A lane therefore holds 16 candidates of ONE output row per tile and reduces them
-// in-lane: the fast path is a v_max3 tree and one compare against the lane's current
-// K-th best accumulator value; only tiles that can change a lane's top-K take the exact
-// (hi = 2 acc + npar, index) update.  The two lane halves and the four waves of a block
-// never exchange data until the single cross-half merge after the sweep.
+// A lane holds 4 candidates of ONE output row per tile and examines a 32-row unit (two
+// tiles, 8 candidates) at a time: the fast path is a 4-op v_max3 tree and one compare against
+// the lane's current K-th best accumulator value; only units that can change a lane's top-K
+// take the exact (hi = 2 acc + npar, index) update.  Lane groups, waves and blocks never
+// exchange data until one merge after the sweep.
 //
-// Grid: blockIdx -> (chunk of 128*NB output rows, split of the reduction range).
-// split = blockIdx % nsplit, and nsplit is a multiple of 8 when > 1, so the blocks that
-// share an XCD (blockIdx % 8) sweep the same slice of the reduced bank out of that XCD's
-// L2.  Staging: 128 rows (16 KiB) + 1 KiB aux per step, global_load_lds_dwordx4 into a
-// double buffer, XOR swizzle applied on the source address so that the ds_read_b128
-// A-fragment reads are bank-conflict free.
+// Grid: blockIdx -> (chunk of 16*NC*NW output rows, split of the reduction range), split
+// major.  Staging: 128 rows (16 KiB) + 1 KiB aux per step, global_load_lds_dwordx4 into a
+// double buffer shared by the NW waves, XOR swizzle applied on the source address so that
+// the ds_read_b128 A-fragment reads are bank-conflict free.
 #include "tile_ops.h"
 #include <type_traits>
 
@@ -75,11 +75,9 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
     }
 }
 
-// NW waves per workgroup share every staged tile: the L2 -> LDS staging traffic per MFMA
-// falls as 1/NW (it, not the MFMA issue rate, limited the 4-wave version: see
-// scripts/ablate/buildup.hip), at the same registers per wave.
-template <int NB, int KTOP, bool GLDS, int NW>
-__global__ __launch_bounds__(64 * NW, (NB >= 4 ? 2 : 4))
+// NW waves per workgroup share every staged tile; each wave owns NC blocks of 16 output rows.
+template <int NC, int KTOP, bool GLDS, int NW>
+__global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : 4))
 void rowreduce_kernel(RRParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
@@ -87,44 +85,45 @@ void rowreduce_kernel(RRParams p)
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int h    = lane >> 5;
+    const int g    = lane >> 4;          // lane group: rows 4g .. 4g+3 of every 16-row tile
+    const int c16  = lane & 15;
     // Split-major order: the first wave of resident workgroups covers EVERY output chunk for
     // the first few slices, so the bounds it publishes serve all later workgroups (which
     // reduce other slices for the same output rows) from their first tile on.  Concurrent
     // workgroups then sweep the same slice, which every XCD serves from its own L2.
     const int chunk = blockIdx.x % p.nchunks;
     const int split = blockIdx.x / p.nchunks;
-    const int cb    = chunk * (32 * NB * NW) + wave * (32 * NB);
+    const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
-    // Stationary operand: this wave's NB x 32 output rows, 4 K-chunks of 32 bytes each.
-    v4i bf[NB][4];
+    // Stationary operand: this wave's NC x 16 output rows, two 64-byte K-halves each.
+    v4i bf[NC][2];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = cb + 32 * j + (lane & 31);
+    for (int j = 0; j < NC; ++j) {
+        const int n = cb + 16 * j + c16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 2; ++c) {
             if (n < p.ncols_pad)
-                bf[j][c] = *(const v4i*)(p.col_rows + (size_t)n * kDim + 32 * c + 16 * h);
+                bf[j][c] = *(const v4i*)(p.col_rows + (size_t)n * kDim + 64 * c + 16 * g);
             else
                 bf[j][c] = v4i{0, 0, 0, 0};
         }
     }
 
-    TopK<KTOP> top[NB];
-    int thr[NB];          // a tile is examined exactly only if some acc >= thr
-    int gthr[NB];         // part of thr that comes from the other blocks' published bounds
+    TopK8<KTOP> top[NC];
+    int thr[NC];          // a unit is examined exactly only if some acc >= thr
+    int gthr[NC];         // part of thr that comes from the other blocks' published bounds
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { top[j].init(); thr[j] = INT32_MIN; gthr[j] = INT32_MIN; }
+    for (int j = 0; j < NC; ++j) { top[j].init(); thr[j] = INT32_MIN; gthr[j] = INT32_MIN; }
 
     const int st0 = split * p.stages_per_split;
     const int st1 = min(st0 + p.stages_per_split, p.nstages);
 
     // Per-lane LDS offsets of the A fragments (swizzled) and of the aux words.
-    const int sw = ((lane & 31) >> 1) & 7;
-    int aoff[4];
+    const int sw = (c16 >> 1) & 7;
+    int aoff[2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) aoff[c] = (lane & 31) * kDim + 16 * ((2 * c + h) ^ sw);
-    const int xoff = kStageRowBytes + h * 64;
+    for (int c = 0; c < 2; ++c) aoff[c] = c16 * kDim + 16 * ((g + 4 * c) ^ sw);
+    const int xoff = kStageRowBytes + 16 * g;
 
     if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
 
@@ -135,10 +134,10 @@ void rowreduce_kernel(RRParams p)
     // non-strict (hi >= bound) because the owner of the bound may have a higher index.
     // The loads for stage s+1 are issued during stage s (next to the LDS-DMA prefetch) and
     // consumed after the wait that retires that prefetch, so they never stall the wave.
-    int gnext[NB];
+    int gnext[NC];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = cb + 32 * j + (lane & 31);
+    for (int j = 0; j < NC; ++j) {
+        const int n = cb + 16 * j + c16;
         gnext[j] = (p.bound && n < p.ncols_alloc)
             ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
     }
@@ -151,46 +150,57 @@ void rowreduce_kernel(RRParams p)
         if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // stage st landed; every wave is done with the other buffer
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
+        for (int j = 0; j < NC; ++j) {
             gthr[j] = gnext[j] >> 1;                    // hi >= g possible iff acc >= floor(g / 2)
             thr[j] = max(thr[j], gthr[j]);
         }
         if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
         if (p.bound) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int n = cb + 32 * j + (lane & 31);
+            for (int j = 0; j < NC; ++j) {
+                const int n = cb + 16 * j + c16;
                 if (n < p.ncols_alloc)
                     gnext[j] = __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 
 #pragma unroll
-        for (int tt = 0; tt < kStageRows / kTileRows; ++tt) {
-            v4i af[4];
+        for (int u = 0; u < kStageRows / kTileRows; ++u) {          // 32-row units
+            v4i acc[2][NC];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(buf + tt * (kTileRows * kDim) + aoff[c]);
-            const v16i ci = lds_read16(buf + xoff + tt * (kAuxPerTile * 4));
-            v16i acc[NB];
+            for (int s = 0; s < 2; ++s) {
+                const char* rows = buf + (32 * u + 16 * s) * kDim;
+                const v4i af0 = *(const v4i*)(rows + aoff[0]);
+                const v4i af1 = *(const v4i*)(rows + aoff[1]);
+                const v4i ci  = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + s * 128);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[j][0], ci, 0, 0, 0);
+                for (int j = 0; j < NC; ++j) acc[s][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0, bf[j][0], ci, 0, 0, 0);
 #pragma unroll
-            for (int c = 1; c < 4; ++c)
+                for (int j = 0; j < NC; ++j) acc[s][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j][1], acc[s][j], 0, 0, 0);
+            }
+            int tmax[NC];
+            bool any = false;
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[c], bf[j][c], acc[j], 0, 0, 0);
-
+            for (int j = 0; j < NC; ++j) {
+                const int m0 = max(max(acc[0][j][0], acc[0][j][1]), acc[0][j][2]);
+                const int m1 = max(max(acc[0][j][3], acc[1][j][0]), acc[1][j][1]);
+                tmax[j] = max(max(max(acc[1][j][2], acc[1][j][3]), m0), m1);
+                any |= tmax[j] >= thr[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                const v4i low0 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 64);
+                const v4i low1 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 128 + 64);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int tmax = max16(acc[j]);
-                if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                    const v16i low = lds_read16(buf + xoff + tt * (kAuxPerTile * 4) + 128);
-                    const bool improved = top[j].update(acc[j], low, st * (kStageRows / kTileRows) + tt);
-                    thr[j] = max(top[j].own_threshold(), gthr[j]);
-                    if (p.bound && improved && top[j].full()) {
-                        const int n = cb + 32 * j + (lane & 31);
-                        if (n < p.ncols_alloc)
-                            __hip_atomic_fetch_max(p.bound + n, top[j].kth_hi(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < NC; ++j) {
+                    if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
+                        const bool improved = top[j].update(acc[0][j], acc[1][j], low0, low1,
+                                                            st * (kStageRows / kTileRows) + u);
+                        thr[j] = max(top[j].own_threshold(), gthr[j]);
+                        if (p.bound && improved && top[j].full()) {
+                            const int n = cb + 16 * j + c16;
+                            if (n < p.ncols_alloc)
+                                __hip_atomic_fetch_max(p.bound + n, top[j].kth_hi(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
@@ -202,52 +212,50 @@ void rowreduce_kernel(RRParams p)
         if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
     }
 
-    // Merge the two lane halves (same output row, interleaved reduced rows), then emit.
+    // Merge the four lane groups (same output row, interleaved reduced rows), then emit.
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < NC; ++j) {
         int bh[KTOP], bi[KTOP];
 #pragma unroll
         for (int k = 0; k < KTOP; ++k) {
             bh[k] = top[j].hi(k);
-            bi[k] = (top[j].tile[k] >= 0) ? top[j].index(k, h) : -1;
+            bi[k] = (top[j].unit[k] >= 0) ? top[j].index(k, g) : -1;
             if (bi[k] >= p.nred) bi[k] = -1;          // a padding row is not a candidate
         }
-        if constexpr (KTOP == 2) {
-            // a padding row can only sit in a slot when fewer real rows exist; keep real first
-            if (bi[0] < 0 && bi[1] >= 0) { bh[0] = bh[1]; bi[0] = bi[1]; bi[1] = -1; }
-        }
-        int oh[KTOP], oi[KTOP];
 #pragma unroll
-        for (int k = 0; k < KTOP; ++k) {
-            oh[k] = __shfl_xor(bh[k], 32);
-            oi[k] = __shfl_xor(bi[k], 32);
+        for (int mask = 16; mask <= 32; mask <<= 1) {
+            int oh[KTOP], oi[KTOP];
+#pragma unroll
+            for (int k = 0; k < KTOP; ++k) {
+                oh[k] = __shfl_xor(bh[k], mask);
+                oi[k] = __shfl_xor(bi[k], mask);
+            }
+            if constexpr (KTOP == 1) {
+                const bool mine = !better(oh[0], oi[0], bh[0], bi[0]);
+                bh[0] = mine ? bh[0] : oh[0];
+                bi[0] = mine ? bi[0] : oi[0];
+            } else {
+                const bool m0 = !better(oh[0], oi[0], bh[0], bi[0]);
+                const int r0h = m0 ? bh[0] : oh[0], r0i = m0 ? bi[0] : oi[0];
+                // runner-up: the loser of the first comparison against the winner side's 2nd
+                const int ah = m0 ? bh[1] : bh[0], ai = m0 ? bi[1] : bi[0];
+                const int ch = m0 ? oh[0] : oh[1], cidx = m0 ? oi[0] : oi[1];
+                const bool m1 = !better(ch, cidx, ah, ai);
+                bh[0] = r0h; bi[0] = r0i;
+                bh[1] = m1 ? ah : ch;
+                bi[1] = m1 ? ai : cidx;
+            }
         }
-        int rh[KTOP], ri[KTOP];
-        if constexpr (KTOP == 1) {
-            const bool mine = !better(oh[0], oi[0], bh[0], bi[0]);
-            rh[0] = mine ? bh[0] : oh[0];
-            ri[0] = mine ? bi[0] : oi[0];
-        } else {
-            const bool m0 = !better(oh[0], oi[0], bh[0], bi[0]);
-            rh[0] = m0 ? bh[0] : oh[0];
-            ri[0] = m0 ? bi[0] : oi[0];
-            // runner-up: the loser of the first comparison against the winner side's 2nd
-            const int ah = m0 ? bh[1] : bh[0], ai = m0 ? bi[1] : bi[0];
-            const int ch = m0 ? oh[0] : oh[1], cidx = m0 ? oi[0] : oi[1];
-            const bool m1 = !better(ch, cidx, ah, ai);
-            rh[1] = m1 ? ah : ch;
-            ri[1] = m1 ? ai : cidx;
-        }
-        const int n = cb + 32 * j + (lane & 31);
-        if (h == 0 && n < p.ncols_alloc) {
+        const int n = cb + 16 * j + c16;
+        if (g == 0 && n < p.ncols_alloc) {
             const int cn = (n < p.ncols_pad) ? p.col_norm[n] : 0;
             unsigned long long* out = p.partial + ((size_t)split * p.ncols_alloc + n) * KTOP;
 #pragma unroll
             for (int k = 0; k < KTOP; ++k) {
                 unsigned long long key = ~0ull;
-                if (ri[k] >= 0 && n < p.ncols_pad) {
-                    const unsigned d2 = (unsigned)(cn + 1 - rh[k]);
-                    key = ((unsigned long long)d2 << 32) | (unsigned)ri[k];
+                if (bi[k] >= 0 && n < p.ncols_pad) {
+                    const unsigned d2 = (unsigned)(cn + 1 - bh[k]);
+                    key = ((unsigned long long)d2 << 32) | (unsigned)bi[k];
                 }
                 out[k] = key;
             }
@@ -259,25 +267,22 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
 {
     RowReducePlan pl;
     const int64_t nstages = nred_pad / kStageRows;
-    // NB = 2 (64 output rows per wave, 4 waves/SIMD resident); the more waves share a
-    // workgroup's staged tiles the less L2 -> LDS traffic per MFMA, so big problems use
-    // 8-wave workgroups (512 output rows each), smaller ones 4 so that enough workgroups
-    // exist; tiny column counts use NB = 1.  (16-wave workgroups are available via FM_NW.)
-    int nb = 2, nw = 8;                         // measured best at 100k x 100k (r01 sweep)
+    // nb = blocks of 16 output rows per wave: 4 (64 rows, ~110 VGPRs, 4 waves/SIMD) by default,
+    // 8 via FM_NB; nw = waves per workgroup sharing the staged tiles: 8 for big problems,
+    // 4 for small ones so that enough workgroups exist.
+    int nb = 4, nw = 8;
     if (ncols_pad < 512 * 64) nw = 4;
-    if (ncols_pad <= 128 * 64) nb = 1;
-    if (force_nb == 1 || force_nb == 2 || force_nb == 4) nb = force_nb;
+    if (force_nb == 4 || force_nb == 8) nb = force_nb;
     if (force_nw == 4 || force_nw == 8 || force_nw == 16) nw = force_nw;
-    if (nb != 2) nw = 4;
     pl.nb = nb;
     pl.nw = nw;
-    const int cb = 32 * nb * nw;
+    const int cb = 16 * nb * nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
-    // ~12 rounds of the workgroups the chip holds (16 waves per CU): enough to balance the
+    // ~6 rounds of the workgroups the chip holds (16 waves per CU): enough to balance the
     // tail, few enough that every workgroup sweeps a long slice.
-    int64_t want = 12 * 256 * (16 / nw);
+    int64_t want = 6 * 256 * (16 / nw);
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nstages / 8) nsplit = nstages / 8;   // keep >= 8 stages (1024 rows) per split
     if (nsplit < 1) nsplit = 1;
@@ -293,22 +298,25 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     return pl;
 }
 
-template <int NB, int KTOP, int NW>
+template <int NC, int KTOP, int NW>
 static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
 {
-    if (glds) hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, true, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
-    else      hipLaunchKernelGGL((rowreduce_kernel<NB, KTOP, false, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
+    if (glds) hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
+    else      hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, false, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
     return hipGetLastError();
 }
 
 template <int KTOP>
 static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool glds, hipStream_t stream)
 {
-    if (nb == 1) return launch_t<1, KTOP, 4>(p, grid, glds, stream);
-    if (nb == 4) return launch_t<4, KTOP, 4>(p, grid, glds, stream);
-    if (nw == 16) return launch_t<2, KTOP, 16>(p, grid, glds, stream);
-    if (nw == 8) return launch_t<2, KTOP, 8>(p, grid, glds, stream);
-    return launch_t<2, KTOP, 4>(p, grid, glds, stream);
+    if (nb == 8) {
+        if (nw == 16) return launch_t<8, KTOP, 16>(p, grid, glds, stream);
+        if (nw == 8) return launch_t<8, KTOP, 8>(p, grid, glds, stream);
+        return launch_t<8, KTOP, 4>(p, grid, glds, stream);
+    }
+    if (nw == 16) return launch_t<4, KTOP, 16>(p, grid, glds, stream);
+    if (nw == 8) return launch_t<4, KTOP, 8>(p, grid, glds, stream);
+    return launch_t<4, KTOP, 4>(p, grid, glds, stream);
 }
 
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,

@@ -129,6 +129,71 @@ struct TopK {
     }
 };
 
+// ---- the same state for the 16x16x64 tile shape (rowreduce.hip) ---------------------------
+// C/D map of v_mfma_i32_16x16x64_i8: col = lane & 15, row = 4 (lane >> 4) + reg, 4 registers
+// per 16-row tile.  A lane examines a 32-row unit = two tiles = 8 candidates at once; the
+// candidate key is (acc << 5) | (npar << 4) | (15 - id) with id = 4 * sub + reg (sub = tile
+// within the unit), so ties inside a unit go to the lowest row of this lane's share.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int unit_row(int id, int g) { return 16 * (id >> 2) + 4 * g + (id & 3); }
+
+template <int KTOP>
+struct TopK8 {
+    int key[KTOP];
+    int unit[KTOP];
+
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int k = 0; k < KTOP; ++k) { key[k] = kNoKey; unit[k] = -1; }
+    }
+    __device__ __forceinline__ int kth_hi() const { return key[KTOP - 1] >> 4; }
+    __device__ __forceinline__ bool full() const { return unit[KTOP - 1] >= 0; }
+    __device__ __forceinline__ int own_threshold() const { return full() ? ((kth_hi() + 1) >> 1) : INT32_MIN; }
+
+    __device__ __forceinline__ bool update(const v4i_t& a0, const v4i_t& a1, const v4i_t& l0, const v4i_t& l1, int u)
+    {
+        int k[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { k[r] = (a0[r] << 5) | l0[r]; k[4 + r] = (a1[r] << 5) | l1[r]; }
+        if constexpr (KTOP == 1) {
+            const int m0 = max(max(k[0], k[1]), k[2]);
+            const int m1 = max(max(k[3], k[4]), k[5]);
+            const int km = max(max(max(k[6], k[7]), m0), m1);
+            const bool up = (km >> 4) > (key[0] >> 4);
+            key[0] = up ? km : key[0];
+            unit[0] = up ? u : unit[0];
+            return up;
+        } else {
+            int a1_[4], a2_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a1_[i] = max(k[2 * i], k[2 * i + 1]); a2_[i] = min(k[2 * i], k[2 * i + 1]); }
+            int b1[2], b2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                b1[i] = max(a1_[2 * i], a1_[2 * i + 1]);
+                b2[i] = max(max(min(a1_[2 * i], a1_[2 * i + 1]), a2_[2 * i]), a2_[2 * i + 1]);
+            }
+            const int k1 = max(b1[0], b1[1]);
+            const int k2 = max(max(min(b1[0], b1[1]), b2[0]), b2[1]);
+            const int h1 = k1 >> 4, h2 = k2 >> 4, g1 = key[0] >> 4, g2 = key[1] >> 4;
+            const bool enter = h1 > g2, first = h1 > g1, both = h2 > g1;
+            const int n0k = first ? k1 : key[0];
+            const int n0u = first ? u : unit[0];
+            const int n1k = first ? (both ? k2 : key[0]) : (enter ? k1 : key[1]);
+            const int n1u = first ? (both ? u : unit[0]) : (enter ? u : unit[1]);
+            key[0] = n0k; unit[0] = n0u; key[1] = n1k; unit[1] = n1u;
+            return enter;
+        }
+    }
+    __device__ __forceinline__ int hi(int k) const { return key[k] >> 4; }
+    __device__ __forceinline__ int index(int k, int g) const
+    {
+        return unit[k] * kTileRows + unit_row(15 - (key[k] & 15), g);
+    }
+};
+
 // (hi, idx) a is better than b: larger hi, then lower index.  idx < 0 means "none".
 __device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
 {

@@ -112,7 +112,7 @@ def test_extreme_values_and_short_dim(ctx):
     assert _eq(idx, oidx) and _eq(d, od)
 
 
-@pytest.mark.parametrize("nsplit,nb", [(1, 1), (1, 4), (3, 2), (8, 4), (16, 1)])
+@pytest.mark.parametrize("nsplit,nb", [(1, 4), (1, 8), (3, 4), (8, 8), (16, 4)])
 def test_split_and_tile_shapes_give_identical_results(nsplit, nb, monkeypatch):
     import fastmatch_amd
     monkeypatch.setenv("FM_NSPLIT", str(nsplit))
