@@ -8,8 +8,8 @@ Workload (BASELINE.json configs[1]): 100k x 100k synthetic 128-D uint8 SIFT desc
 one independent image pair per GPU (weak scaling; SURVEY.md 8(d) C2, seed 20250002+rank).
 A step = one pass of the hot path over that pair with both banks already resident in HBM:
 cross-checked 1-NN (OpenCV BFMatcher crossCheck semantics) + float64 ratio test at
-tau = 0.7 against the query bank's self distances (fm_match_ratio), results copied back
-to the host and, for N > 1, the accepted matches all-gathered over RCCL.
+tau = 0.7 against the query bank's self distances, accepted matches compacted on the device
+(fm_match_accepted), copied back to the host and, for N > 1, all-gathered over RCCL.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -86,16 +86,16 @@ def main():
     qb.set_selfdist(selfdist)
 
     # caller-owned output buffers in page-locked memory (results arrive by direct DMA)
-    outbuf = (ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.float32),
-              ctx.pinned_empty(NQ, np.float64), ctx.pinned_empty(NQ, np.uint8))
+    outbuf = (ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
+              ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64))
 
     def step():
-        tidx, d, ratio, passed, npass = ctx.match_ratio(qb, tb, TAU, out=outbuf)
-        q_acc = np.nonzero(passed.view(np.bool_))[0]
-        packed = sharding.pack_matches(q_acc, tidx[q_acc], d[q_acc])
+        # X1 + R1 + ordered compaction of the accepted matches on the device (fm_match_accepted)
+        q_acc, t_acc, d_acc, r_acc = ctx.match_accepted(qb, tb, TAU, out=outbuf)
         if world > 1:
+            packed = sharding.pack_matches(q_acc, t_acc, d_acc)
             sharding.all_gather_matches(packed, device=dev, capacity=NQ, to_host=False)
-        return npass
+        return len(q_acc)
 
     def barrier():
         if world > 1:

@@ -67,6 +67,7 @@ SYMBOLS = {
     "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "fm_expand_create": (_INT, [_P, ctypes.POINTER(fm_expand_desc), ctypes.POINTER(_P)]),
     "fm_expand_destroy": (_INT, [_P, _P]),
@@ -282,6 +283,24 @@ class Context(object):
         self._check(self.lib.fm_match_ratio(self.handle, q.handle, t.handle, float(tau), _ptr(tidx),
                                             _ptr(dist), _ptr(ratio), _ptr(passed), ctypes.byref(npass)))
         return tidx, dist, ratio, passed.astype(bool), npass.value
+
+    def match_accepted(self, q, t, tau, out=None):
+        """X1 + R1, returning only the accepted matches in ascending query index:
+        (qidx i32[m], tidx i32[m], dist f32[m], ratio f64[m]).  ``out`` = optional buffers
+        (qidx, tidx, dist, ratio) of equal capacity (e.g. pinned); views of them are returned."""
+        if out is None:
+            cap = q.n
+            out = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.float64))
+        qidx, tidx, dist, ratio = out
+        cap = qidx.shape[0]
+        for a, dt in ((qidx, np.int32), (tidx, np.int32), (dist, np.float32), (ratio, np.float64)):
+            if a.dtype != dt or a.shape != (cap,) or not a.flags.c_contiguous:
+                raise ValueError("out buffers must be contiguous 1-D int32/int32/float32/float64 of one length")
+        n = _I64(0)
+        self._check(self.lib.fm_match_accepted(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx),
+                                               _ptr(tidx), _ptr(dist), _ptr(ratio), ctypes.byref(n)))
+        m = min(n.value, cap)
+        return qidx[:m], tidx[:m], dist[:m], ratio[:m]
 
     def ratio_filter(self, dist, selfdist, tau, qrows=None):
         dist = np.ascontiguousarray(dist, dtype=np.float32)

@@ -213,8 +213,10 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qb
                                        const double* __restrict__ selfdist, double tau,
                                        int32_t* __restrict__ tidx, float* __restrict__ dist,
                                        double* __restrict__ ratio, uint8_t* __restrict__ pass,
-                                       unsigned long long* __restrict__ npass, int f32)
+                                       unsigned long long* __restrict__ npass, int f32,
+                                       int* __restrict__ block_counts)
 {
+    __shared__ int wave_cnt[4];
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool p = false;
     if (q < nq) {
@@ -232,9 +234,49 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qb
         if (ratio) ratio[q] = r;
         if (pass) pass[q] = p ? 1 : 0;
     }
+    const unsigned long long m = __ballot(p);
     if (npass) {
-        const unsigned long long m = __ballot(p);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(npass, (unsigned long long)__popcll(m));
+    }
+    if (block_counts) {                      // for the ordered compaction (compact_kernel)
+        if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
+}
+
+// Ordered stream compaction of the accepted matches (ascending query index): block b sums
+// the counts of the blocks before it, then every accepted row writes itself at
+// offset + rank.  Deterministic (no atomics).
+__global__ void compact_kernel(const int32_t* __restrict__ tidx, const float* __restrict__ dist,
+                               const double* __restrict__ ratio, const uint8_t* __restrict__ pass,
+                               const int* __restrict__ block_counts, int64_t nq, int64_t cap,
+                               int32_t* __restrict__ o_q, int32_t* __restrict__ o_t,
+                               float* __restrict__ o_d, double* __restrict__ o_r)
+{
+    __shared__ int red[256];
+    __shared__ int wave_base[4];
+    const int tid = threadIdx.x;
+    int s = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) s += block_counts[b];
+    red[tid] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    const int64_t base = red[0];
+    const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+    const bool p = q < nq && pass[q];
+    const unsigned long long m = __ballot(p);
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) wave_base[wave] = __popcll(m);
+    __syncthreads();
+    int wb = 0;
+    for (int w = 0; w < wave; ++w) wb += wave_base[w];
+    if (p) {
+        const int64_t dst = base + wb + __popcll(m & ((1ull << lane) - 1ull));
+        if (dst < cap) { o_q[dst] = (int32_t)q; o_t[dst] = tidx[q]; o_d[dst] = dist[q]; o_r[dst] = ratio[q]; }
     }
 }
 
@@ -613,22 +655,28 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 // ---------------------------------------------------------------------------------------
 static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
-                         const char* who)
+                         const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr)
 {
+    const bool compact = compact_cap >= 0;
     int rc = check_pair(ctx, q, t, who);
     if (rc != FM_OK) return rc;
     const int f32 = q->kind == FM_BANK_F32;
     const int64_t nq = q->n, nt = t->n;
     if (n_pass) *n_pass = 0;
     if (nq == 0) return FM_OK;
-    if (!tidx || !dist) return fail(ctx, FM_EINVAL, std::string(who) + ": output pointer is NULL");
+    if (!tidx || !dist || (compact && (!c_qidx || !ratio))) return fail(ctx, FM_EINVAL, std::string(who) + ": output pointer is NULL");
     if (with_ratio && !q->selfdist) return fail(ctx, FM_EINVAL, std::string(who) + ": query bank has no self distances (fm_bank_set_selfdist)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // outputs: qbest u64[nq] | tidx i32[nq] | dist f32[nq] | ratio f64[nq] | pass u8[nq] | count u64
     const size_t o_qbest = 0, o_tidx = (size_t)nq * 8, o_dist = o_tidx + (size_t)nq * 4;
     const size_t o_ratio = (o_dist + (size_t)nq * 4 + 7) & ~(size_t)7, o_pass = o_ratio + (size_t)nq * 8;
     const size_t o_cnt = (o_pass + (size_t)nq + 15) & ~(size_t)15;
-    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_cnt + 16)) != FM_OK) return rc;
+    // compaction: block counts | compacted qidx, tidx, dist, ratio
+    const int nblk = (int)((nq + 255) / 256);
+    const int64_t ccap = compact ? (compact_cap < nq ? compact_cap : nq) : 0;
+    const size_t o_bc = o_cnt + 16, o_cq = (o_bc + (size_t)nblk * 4 + 15) & ~(size_t)15, o_ct = o_cq + (size_t)ccap * 4;
+    const size_t o_cd = o_ct + (size_t)ccap * 4, o_cr = (o_cd + (size_t)ccap * 4 + 7) & ~(size_t)7;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_cr + (size_t)ccap * 8 + 16)) != FM_OK) return rc;
     char* base = (char*)ctx->ws_out;
     unsigned long long* d_qbest = (unsigned long long*)(base + o_qbest);
     int32_t* d_tidx = (int32_t*)(base + o_tidx);
@@ -662,11 +710,33 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)d_qbest, nq, with_ratio ? (const double*)q->selfdist : (const double*)nullptr,
                        tau, d_tidx, d_dist, with_ratio ? d_ratio : (double*)nullptr,
-                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr, f32);
+                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr, f32,
+                       compact ? (int*)(base + o_bc) : (int*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
+    unsigned long long cnt = 0;
+    if (compact) {
+        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                           (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
+                           (const int*)(base + o_bc), nq, ccap, (int32_t*)(base + o_cq), (int32_t*)(base + o_ct),
+                           (float*)(base + o_cd), (double*)(base + o_cr));
+        HIP_TRY(ctx, hipGetLastError());
+        // the count must be known before the copies can be sized: one tiny synchronous read
+        HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t m = (size_t)((int64_t)cnt < ccap ? (int64_t)cnt : ccap);
+        if (m) {
+            HIP_TRY(ctx, hipMemcpyAsync(c_qidx, base + o_cq, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(tidx, base + o_ct, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(dist, base + o_cd, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ratio, base + o_cr, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        rc = cs.finish();
+        if (rc != FM_OK) return rc;
+        if (n_pass) *n_pass = (int64_t)cnt;
+        return FM_OK;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(tidx, d_tidx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long cnt = 0;
     if (with_ratio) {
         if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, d_ratio, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (pass) HIP_TRY(ctx, hipMemcpyAsync(pass, d_pass, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
@@ -687,6 +757,13 @@ extern "C" int fm_match_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, d
                               float* dist, double* ratio, uint8_t* pass, int64_t* n_pass)
 {
     return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, pass, n_pass, "fm_match_ratio");
+}
+
+extern "C" int fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                                 int32_t* qidx, int32_t* tidx, float* dist, double* ratio, int64_t* n_accepted)
+{
+    if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted: cap < 0");
+    return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, nullptr, n_accepted, "fm_match_accepted", cap, qidx);
 }
 
 extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* selfdist, const int32_t* qrows,

@@ -122,6 +122,13 @@ int  fm_match_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau,
                     double* ratio /*[nq] or NULL*/, uint8_t* pass /*[nq] or NULL*/,
                     int64_t* n_pass /*or NULL*/);
 
+/* As fm_match_ratio, but returns only the accepted matches (ratio < tau), compacted on the
+ * device in ascending query index: qidx/tidx/dist/ratio[0 .. min(*n_accepted, cap)).
+ * *n_accepted is the total number accepted (may exceed cap; the rest is dropped).        */
+int  fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                       int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
+                       int64_t* n_accepted);
+
 /* ---- K4: many match_position rounds in one launch ------------------------------------
  * Round b matches the query rows  q_rows[q_off[b] .. q_off[b+1])  of bank q (the radius
  * subset Metric_Cache.get returns, cache.pyx:173-188, in its order) against the train

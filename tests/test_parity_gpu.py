@@ -325,3 +325,22 @@ def test_mixed_kind_pair_is_rejected(ctx):
     T = synth.synth_sift(10, np.random.default_rng(4))
     with pytest.raises(_ffi.FastMatchHipError):
         ctx.xcheck1(ctx.bank(Q), ctx.bank(T))
+
+
+def test_match_accepted_is_the_compacted_match_ratio(ctx):
+    Q, T, _ = synth.planted_pair(5000, 4300, seed=61)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    qb.set_selfdist(ctx.self_dist(qb))
+    tidx, dist, ratio, passed, npass = ctx.match_ratio(qb, tb, 0.7)
+    qa, ta, da, ra = ctx.match_accepted(qb, tb, 0.7)
+    sel = np.nonzero(passed)[0]
+    assert len(qa) == npass and np.array_equal(qa, sel.astype(np.int32))      # ascending query index
+    assert _eq(ta, tidx[sel]) and _eq(da, dist[sel]) and _eq(ra, ratio[sel])
+    # caller-owned (pinned) buffers with a capacity below the count: truncated, order kept
+    out = (ctx.pinned_empty(100, np.int32), ctx.pinned_empty(100, np.int32),
+           ctx.pinned_empty(100, np.float32), ctx.pinned_empty(100, np.float64))
+    qa2, ta2, da2, ra2 = ctx.match_accepted(qb, tb, 0.7, out=out)
+    assert len(qa2) == 100 and np.array_equal(qa2, qa[:100]) and _eq(ra2, ra[:100])
+    # nothing accepted
+    qa3, _, _, _ = ctx.match_accepted(qb, tb, 0.0)
+    assert len(qa3) == 0
