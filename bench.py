@@ -64,12 +64,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    # FM_BENCH_BACKEND=gloo + FM_BENCH_SINGLE_DEVICE=1: dry-run of the N > 1 code path on a
+    # box with one GPU (all ranks share device 0, collectives on CPU tensors); never used by
+    # the driver.
+    backend = os.environ.get("FM_BENCH_BACKEND", "nccl")
+    if os.environ.get("FM_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
 
     import fastmatch_amd
     from fastmatch_amd import synth, sharding
@@ -89,12 +98,16 @@ def main():
     outbuf = (ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
               ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64))
 
+    # N > 1: the all-gather of step i's accepted matches (RCCL, its own stream) overlaps the
+    # matching kernels of step i+1 (the library's stream); the last one is waited for inside
+    # the timed region.
+    gatherer = sharding.MatchGatherer(dev, capacity=NQ // 2) if world > 1 else None
+
     def step():
         # X1 + R1 + ordered compaction of the accepted matches on the device (fm_match_accepted)
         q_acc, t_acc, d_acc, r_acc = ctx.match_accepted(qb, tb, TAU, out=outbuf)
-        if world > 1:
-            packed = sharding.pack_matches(q_acc, t_acc, d_acc)
-            sharding.all_gather_matches(packed, device=dev, capacity=NQ, to_host=False)
+        if gatherer is not None:
+            gatherer.submit(sharding.pack_matches(q_acc, t_acc, d_acc))
         return len(q_acc)
 
     def barrier():
@@ -103,6 +116,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if gatherer is not None:
+        gatherer.finish()
     ctx.reset_stats()
     barrier()
     torch.cuda.synchronize()
@@ -110,14 +125,16 @@ def main():
     npass = 0
     for _ in range(args.steps):
         npass = step()
+    if gatherer is not None:
+        gatherer.finish()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot_pass = torch.tensor([npass], dtype=torch.int64, device=dev)
+        tot_pass = torch.tensor([npass], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tot_pass, op=dist.ReduceOp.SUM)
         npass_all = int(tot_pass.item())
     else:

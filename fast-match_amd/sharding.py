@@ -40,6 +40,8 @@ def all_gather_matches(packed, device=None, group=None, capacity=None, to_host=T
         return [np.asarray(packed, dtype=np.int32).reshape(-1, 3)]
     world = dist.get_world_size(group)
     dev = device if device is not None else "cpu"
+    if not isinstance(dev, str):
+        dev = dev if dev.type != "cpu" else "cpu"
     packed = np.ascontiguousarray(packed, dtype=np.int32).reshape(-1, 3)
     m = packed.shape[0]
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
@@ -66,3 +68,58 @@ def all_gather_matches(packed, device=None, group=None, capacity=None, to_host=T
     counts = counts.cpu().numpy()
     host = allbuf.cpu().numpy()
     return [host[r, :int(counts[r])].copy() for r in range(world)]
+
+
+class MatchGatherer(object):
+    """Overlapped result gather for a stream of steps: ``submit(packed)`` starts the
+    all-gather of this step's accepted matches asynchronously (the previous one is waited
+    for first, buffers are double-buffered), so the collective runs while the next step's
+    matching kernels execute on the library's own HIP stream.  ``finish()`` waits for the
+    last one and returns ``(counts int64[world], rows int32[world, capacity, 3])`` tensors."""
+
+    def __init__(self, device, capacity, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.dev = device
+        self.capacity = int(capacity)
+        self.on_cpu = isinstance(device, str) and device == "cpu"
+        mk = lambda *shape, dtype: [torch.zeros(shape, dtype=dtype, device=device) for _ in range(2)]
+        self.buf = mk(self.capacity, 3, dtype=torch.int32)
+        self.mine = mk(1, dtype=torch.int64)
+        self.allbuf = mk(self.world * self.capacity, 3, dtype=torch.int32)
+        self.counts = mk(self.world, dtype=torch.int64)
+        self.pending = []
+        self.slot = 0
+
+    def _wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def submit(self, packed):
+        torch, dist = self.torch, self.dist
+        packed = np.ascontiguousarray(packed, dtype=np.int32).reshape(-1, 3)
+        m = packed.shape[0]
+        if m > self.capacity:
+            raise ValueError("capacity %d smaller than local match count %d" % (self.capacity, m))
+        self._wait()                       # at most one gather in flight; frees the other slot
+        k = self.slot
+        self.slot ^= 1
+        if m:
+            self.buf[k][:m].copy_(torch.from_numpy(packed))
+        self.mine[k][0] = m
+        if self.on_cpu:
+            self.pending = [dist.all_gather(list(self.counts[k].split(1)), self.mine[k], group=self.group, async_op=True),
+                            dist.all_gather(list(self.allbuf[k].split(self.capacity)), self.buf[k], group=self.group, async_op=True)]
+        else:
+            self.pending = [dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group, async_op=True),
+                            dist.all_gather_into_tensor(self.allbuf[k], self.buf[k], group=self.group, async_op=True)]
+        self.last = k
+
+    def finish(self):
+        self._wait()
+        k = self.last
+        return self.counts[k], self.allbuf[k].view(self.world, self.capacity, 3)

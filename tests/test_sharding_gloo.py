@@ -41,6 +41,16 @@ for cap in (None, 64):
         assert d.dtype == np.float32 and np.array_equal(d.view(np.int32), exp[:, 2])
 empty = sharding.all_gather_matches(np.zeros((0, 3), np.int32) if rank == 0 else mine[:2])
 assert len(empty[0]) == 0 and len(empty[1]) == 2
+# overlapped gatherer: a stream of steps, double-buffered, last result checked
+g = sharding.MatchGatherer("cpu", capacity=64)
+for step in range(5):
+    g.submit(mine[: max(0, len(mine) - step)])
+counts, rows = g.finish()
+for r in range(world):
+    n_r = sum(3 + 2 * p for p in sharding.shard_items(7, r, world)) - 4
+    assert int(counts[r]) == n_r, (rank, r, int(counts[r]), n_r)
+    if r == rank:
+        assert np.array_equal(rows[r, :n_r].numpy(), mine[:n_r])
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
