@@ -1,0 +1,120 @@
+"""GPU: error behaviour and robustness of the C-ABI / Python surface (the analogue of the
+cv2.error cases of the reference's operator boundary)."""
+import threading
+
+import numpy as np
+import pytest
+
+import fastmatch_amd
+import oracle
+from fastmatch_amd import _ffi, synth, cache
+
+pytestmark = pytest.mark.gpu
+Err = _ffi.FastMatchHipError
+
+
+def test_bad_arguments_raise_and_context_survives(ctx):
+    Q, T, _ = synth.planted_pair(50, 60, seed=1)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    with pytest.raises(Err):                                   # dim > 128
+        ctx.bank(np.zeros((4, 129), np.uint8))
+    with pytest.raises(ValueError):
+        ctx.bank(np.zeros(128, np.uint8))                      # not 2-D
+    with pytest.raises(Err):                                   # width mismatch (cv2.error in the reference)
+        ctx.xcheck1(ctx.bank(Q[:, :64].copy()), tb)
+    with pytest.raises(Err):                                   # ratio test without self distances
+        ctx.match_ratio(qb, tb, 0.7)
+    with pytest.raises(ValueError):
+        qb.set_selfdist(np.ones(3))
+    with pytest.raises(Err):                                   # q_rows out of range
+        ctx.xcheck1_batched(qb, np.array([0, 50], np.int32), [0, 2], tb, [0, 10])
+    with pytest.raises(Err):                                   # cell range beyond the bank
+        ctx.xcheck1_batched(qb, np.array([0, 1], np.int32), [0, 2], tb, [0, 61])
+    with pytest.raises(ValueError):
+        ctx.xcheck1_batched(qb, np.array([0, 1], np.int32), [0, 2], tb, [0, 10, 20])
+    with pytest.raises(Err):                                   # more than 4096 rows in one round
+        big = ctx.bank(np.zeros((5000, 128), np.uint8))
+        ctx.xcheck1_batched(big, np.arange(5000, dtype=np.int32), [0, 5000], tb, [0, 10])
+    # the context still works after every failure
+    tidx, dist = ctx.xcheck1(qb, tb)
+    ot, od = oracle.bf_xcheck1(Q, T)
+    assert np.array_equal(tidx, ot) and np.array_equal(dist, od)
+
+
+def test_closed_bank_and_context_fail_cleanly():
+    c = fastmatch_amd.Context(0)
+    b = c.bank(np.ones((3, 128), np.uint8))
+    name = c.device_name()
+    assert name.startswith("gfx950")
+    b.close()
+    b.close()                                                  # idempotent
+    with pytest.raises(Err):
+        c.knn2(b, b)                                           # NULL bank handle
+    c.close()
+    c.close()
+    with pytest.raises(Exception):
+        c.bank(np.ones((3, 128), np.uint8))
+
+
+def test_float_dtypes_are_converted_like_float32(ctx):
+    Q, T, _ = synth.planted_pair(120, 90, seed=4)
+    a = ctx.xcheck1(ctx.bank(Q.astype(np.float64)), ctx.bank(T.astype(np.int32)))
+    b = oracle.bf_xcheck1(Q, T)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # non-contiguous input views are handled (copied) on the way in
+    Qs = np.asfortranarray(Q)
+    c = ctx.knn2(ctx.bank(Qs), ctx.bank(T[::-1][::-1]))
+    d = oracle.bf_knn(Q, T, 2)
+    assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])
+
+
+def test_two_contexts_on_two_threads(ctx):
+    """Distinct contexts are independent (one stream each): concurrent use from two host
+    threads gives the single-threaded answers."""
+    Q, T, _ = synth.planted_pair(3000, 2500, seed=9)
+    exp = oracle.bf_knn(Q, T, 2)
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            c = fastmatch_amd.Context(0)
+            qb, tb = c.bank(Q), c.bank(T)
+            for _ in range(5):
+                out[k] = c.knn2(qb, tb)
+            c.close()
+        except Exception as e:       # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for k in range(2):
+        assert np.array_equal(out[k][0], exp[0]) and np.array_equal(out[k][1], exp[1])
+
+
+def test_stats_account_pairs_and_kernel_time(ctx):
+    Q, T, _ = synth.planted_pair(700, 900, seed=2)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    ctx.reset_stats()
+    ctx.xcheck1(qb, tb)
+    ctx.knn2(qb, tb)
+    s = ctx.stats()
+    assert s["pairs"] == 2 * 700 * 900 and s["kernel_launches"] == 2 and s["calls"] == 2
+    assert 0 < s["kernel_ms"] <= s["total_ms"]
+
+
+def test_metric_cache_from_arrays_computes_exact_self_distances(ctx, tmp_path):
+    q, _ = synth.image_pair((300, 200), 400, seed=8, n_thumb=80)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], path=b"q.ppm",
+                                        options={"context": ctx})
+    assert np.array_equal(mc.original["distances"], oracle.self_dist(q["descriptors"]))
+    assert np.array_equal(mc.thumb["distances"], oracle.self_dist(q["thumb_descriptors"]))
+    mc.save(str(tmp_path))
+    mc2 = cache.Metric_Cache(None, {"context": ctx})
+    mc2.path = b"q.ppm"
+    assert mc2.load(str(tmp_path))
+    ds, ps, dis, idx = mc2.get(150, 100, 60)
+    eds, eps, edis, eidx = mc.get(150, 100, 60)
+    assert np.array_equal(idx, eidx) and np.array_equal(dis, edis)
+    assert mc2.bank(ctx).n == 400                            # lazily re-created device bank
