@@ -103,6 +103,60 @@ __device__ __forceinline__ int center_coord(int i, int cell, int limit)
     return c < limit - 1 ? c : limit - 1;
 }
 
+// Sort n <= kExpCand (key, idx) pairs held in LDS ascending by (key, idx); pairs are unique.
+// Runs of 64 are sorted inside a wave with a shuffle bitonic network (no barriers), then
+// every element finds its final rank by binary-searching the other runs.  tmp: int[kExpCand].
+__device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, int* tmp, int n)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nruns = (n + 63) >> 6;
+    for (int r = wave; r < nruns; r += 4) {
+        const int i = r * 64 + lane;
+        unsigned long long k = i < n ? keys[i] : ~0ull;
+        int v = i < n ? idx[i] : 0x7fffffff;
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                const unsigned long long ok = __shfl_xor(k, j);
+                const int ov = __shfl_xor(v, j);
+                const bool up = (lane & kk) == 0;            // ascending block
+                const bool lower = (lane & j) == 0;          // this lane keeps the smaller one
+                const bool other_less = ok < k || (ok == k && ov < v);
+                const bool take = (lower == up) ? other_less : !other_less;
+                k = take ? ok : k;
+                v = take ? ov : v;
+            }
+        keys[i] = k;                                          // padded slots sort to the end
+        idx[i] = v;
+    }
+    __syncthreads();
+    if (nruns > 1) {
+        for (int i = tid; i < n; i += 256) {
+            const unsigned long long k = keys[i];
+            const int v = idx[i];
+            const int r = i >> 6;
+            int rank = i & 63;
+            for (int o = 0; o < nruns; ++o) {
+                if (o == r) continue;
+                const int base = o * 64;
+                int lo = 0, hi = min(64, n - base);          // number of (key, idx) < (k, v) in run o
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const unsigned long long mk = keys[base + mid];
+                    const bool less = mk < k || (mk == k && idx[base + mid] < v);
+                    if (less) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            tmp[rank] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) idx[i] = tmp[i];
+        __syncthreads();
+    }
+}
+
 // Exclusive scan of per-thread counts over the 256-thread block; returns the total.
 __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[4]*/)
 {
@@ -144,6 +198,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     long long n_matches = 0, n_rounds = 0, n_pairs = 0;
     long long seen_n = 0;
     int status = kExpOk;
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tstamp = P.prof ? wall_clock64() : 0;
+#define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
 
     for (;;) {
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
@@ -180,6 +237,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         status = sh_i[3];
         if (!sh_i[0] || status != kExpOk) break;
         const int col = sh_i[1], row = sh_i[2];
+        const long long sh_i_top_before = sh_top;
+        EXP_STAMP(0);
         // C-int truncation of the positions (fastmatch.pyx:147-150)
         const int qx = (int)cur[0], qy = (int)cur[1], tx = (int)cur[2], ty = (int)cur[3];
         if (tx > P.width || ty > P.height) { status = kExpOutOfBounds; break; }     // cache.pyx:56-57
@@ -215,25 +274,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         __syncthreads();
         const int nq = sh_i[4];
         if (nq > kExpCand) { status = kExpCandFull; break; }
-        // bitonic sort of (d2 bits, index): non-negative doubles order like their bit patterns
-        int npow = 1;
-        while (npow < nq) npow <<= 1;
-        for (int i = nq + tid; i < npow; i += 256) { keys[i] = ~0ull; cand[i] = 0x7fffffff; }
-        __syncthreads();
-        for (int k = 2; k <= npow; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < npow; i += 256) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const unsigned long long ki = keys[i], kl = keys[l];
-                        const int ci = cand[i], cl = cand[l];
-                        const bool gt = ki > kl || (ki == kl && ci > cl);
-                        if (gt == ((i & k) == 0)) { keys[i] = kl; keys[l] = ki; cand[i] = cl; cand[l] = ci; }
-                    }
-                }
-                __syncthreads();
-            }
+        EXP_STAMP(1);
+        // sort by (d2 bits, index): non-negative doubles order like their bit patterns
+        block_sort_pairs(keys, cand, tix, nq);
 
+        EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
         const int cell = gcol * P.rows + grow;
         const int64_t t0 = P.cell_off[cell];
@@ -244,149 +289,138 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         x1_round<1>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys);
         __syncthreads();
 
+        EXP_STAMP(3);
         // ---- 4./5. accepted matches: neighbours and new results, in slot order ------------------
+        // (a) compact the accepted slots in order:  tix[k] = slot | t_local << 11,
+        //     nkey[k] = ratio bits  (k < na)
         const int ccx = center_coord(row, P.cell_w, P.width), ccy = center_coord(col, P.cell_h, P.height);
-        int n_push = 0, n_emit = 0;          // this thread's counts (slots tid, tid+256, ...)
-        // pass A: per slot flags; nkey = neighbour key (or ~0), keys[] keeps qbest for pass B
-        for (int i = tid; i < nq; i += 256) {
-            const unsigned long long qb = keys[i];
-            int t_local = -1;
-            unsigned long long nk = ~0ull;
-            if (qb != ~0ull) {
-                const float d = sqrtf((float)(unsigned)(qb >> 32));
-                const double ratio = (double)d / P.q_selfdist[cand[i]];
-                if (ratio < P.tau) {
-                    t_local = (int)(unsigned)qb;
-                    const double px = P.t_pos[2 * (t0 + t_local)], py = P.t_pos[2 * (t0 + t_local) + 1];
-                    const int xd = (int)px - ccx, yd = (int)py - ccy;
-                    int ncol = col, nrow = row;
-                    if (yd < xd && yd < -xd) ncol = col - 1;
-                    else if (xd > yd) nrow = row + 1;
-                    else if (yd > -xd) ncol = col + 1;
-                    else nrow = row - 1;
-                    if (ncol >= 0 && ncol < P.cols && nrow >= 0 && nrow < P.rows) {
-                        // pushed entry = (query position of the match, centre of the neighbour cell)
-                        const double nx = (double)center_coord(nrow, P.cell_w, P.width);
-                        const double ny = (double)center_coord(ncol, P.cell_h, P.height);
-                        const double mqx = P.q_pos[2 * cand[i]], mqy = P.q_pos[2 * cand[i] + 1];
-                        nk = pack4x16(blk(ny, P.cell_h), blk(nx, P.cell_w), blk(mqy, P.cell_h), blk(mqx, P.cell_w));
-                        if (set_contains(P.seen, P.seen_cap, nk)) nk = ~0ull;      // would be skipped when popped
-                    }
-                }
-            }
-            tix[i] = t_local;
-            nkey[i] = nk;
-        }
-        __syncthreads();
-        // pass B: drop neighbours whose key an earlier slot of this round already pushes; count
-        for (int i = tid; i < nq; i += 256) {
-            unsigned long long nk = nkey[i];
-            if (nk != ~0ull) {
-                bool dup = false;
-                for (int j = 0; j < i && !dup; ++j) dup = nkey[j] == nk;
-                if (!dup) ++n_push;
-                else tix[i] |= 0x40000000;          // mark "no push" (bit 30; train indices are small)
-            }
-        }
-        __syncthreads();
-        // stack push, first accepted slot on top: entry for rank k goes to top + (total-1-k)
-        {
-            int off;
-            const int total = block_exclusive_scan(n_push, &off, wave_tot);
-            if (tid == 0) sh_i[5] = (sh_top + total > P.stack_cap) ? 1 : 0;
-            __syncthreads();
-            if (sh_i[5]) { status = kExpStackFull; break; }
-            // ranks must follow SLOT order, and a thread owns slots tid, tid+256, ...: do it per
-            // 256-slot pass with a scan per pass
-            const long long base = sh_top;
-            int pushed_before = 0;
-            for (int s0 = 0; s0 < nq; s0 += 256) {
-                const int i = s0 + tid;
-                const bool doit = i < nq && nkey[i] != ~0ull && !(tix[i] & 0x40000000);
-                int o;
-                const int cnt = block_exclusive_scan(doit ? 1 : 0, &o, wave_tot);
-                if (doit) {
-                    const int rank = pushed_before + o;
-                    const long long dst = base + (total - 1 - rank);
-                    const int ti = tix[i] & 0x3fffffff;
-                    const double px = P.t_pos[2 * (t0 + ti)], py = P.t_pos[2 * (t0 + ti) + 1];
-                    const int xd = (int)px - ccx, yd = (int)py - ccy;
-                    int ncol = col, nrow = row;
-                    if (yd < xd && yd < -xd) ncol = col - 1;
-                    else if (xd > yd) nrow = row + 1;
-                    else if (yd > -xd) ncol = col + 1;
-                    else nrow = row - 1;
-                    P.stack[dst * 4 + 0] = P.q_pos[2 * cand[i]];
-                    P.stack[dst * 4 + 1] = P.q_pos[2 * cand[i] + 1];
-                    P.stack[dst * 4 + 2] = (double)center_coord(nrow, P.cell_w, P.width);
-                    P.stack[dst * 4 + 3] = (double)center_coord(ncol, P.cell_h, P.height);
-                }
-                pushed_before += cnt;
-            }
-            if (tid == 0) top += total;
-        }
-        __syncthreads();
-        // results: dedup against earlier rounds (table lookups) and earlier slots (pairwise)
-        for (int i = tid; i < nq; i += 256) {
-            unsigned long long k1 = ~0ull;
-            const int tl = tix[i];
-            if (tl >= 0) {
-                const int ti = tl & 0x3fffffff;
-                const double mqx = P.q_pos[2 * cand[i]], mqy = P.q_pos[2 * cand[i] + 1];
-                const double px = P.t_pos[2 * (t0 + ti)], py = P.t_pos[2 * (t0 + ti) + 1];
-                k1 = pack4x16((int)mqx, (int)mqy, (int)px, (int)py);
-            }
-            nkey[i] = k1;                              // ratio part is recomputed below (keys[] = qbest)
-        }
-        __syncthreads();
+        int na = 0;
         for (int s0 = 0; s0 < nq; s0 += 256) {
             const int i = s0 + tid;
-            bool emit = false;
-            unsigned long long k0 = 0, k1 = 0;
+            bool acc = false;
             double ratio = 0.0;
-            if (i < nq && tix[i] >= 0) {
-                const float d = sqrtf((float)(unsigned)(keys[i] >> 32));
-                ratio = (double)d / P.q_selfdist[cand[i]];
-                k0 = (unsigned long long)__double_as_longlong(ratio);
-                k1 = nkey[i];
-                emit = !found_contains(P.found, P.found_cap, k0, k1);
-                for (int j = 0; j < i && emit; ++j) {
-                    if (tix[j] >= 0 && nkey[j] == k1) {
-                        const float dj = sqrtf((float)(unsigned)(keys[j] >> 32));
-                        const double rj = (double)dj / P.q_selfdist[cand[j]];
-                        if ((unsigned long long)__double_as_longlong(rj) == k0) emit = false;
-                    }
+            int t_local = 0;
+            if (i < nq) {
+                const unsigned long long qb = keys[i];
+                if (qb != ~0ull) {
+                    const float d = sqrtf((float)(unsigned)(qb >> 32));
+                    ratio = (double)d / P.q_selfdist[cand[i]];
+                    acc = ratio < P.tau;
+                    t_local = (int)(unsigned)qb;
                 }
             }
             int o;
-            const int cnt = block_exclusive_scan(emit ? 1 : 0, &o, wave_tot);
-            if (tid == 0) sh_i[6] = (n_matches + n_emit + cnt > P.match_cap || 2 * (n_matches + n_emit + cnt) > P.found_cap) ? 1 : 0;
+            const int cnt = block_exclusive_scan(acc ? 1 : 0, &o, wave_tot);
+            // keys[] (qbest) of slots < s0 + 256 are consumed: entries na+o <= i never clobber unread ones
             __syncthreads();
-            if (sh_i[6]) { status = kExpMatchFull; break; }
-            if (emit) {
-                const long long dst = n_matches + n_emit + o;
-                const int ti = tix[i] & 0x3fffffff;
-                P.m_index[dst] = cand[i];
-                P.m_pos[dst * 4 + 0] = P.q_pos[2 * cand[i]];
-                P.m_pos[dst * 4 + 1] = P.q_pos[2 * cand[i] + 1];
-                P.m_pos[dst * 4 + 2] = P.t_pos[2 * (t0 + ti)];
-                P.m_pos[dst * 4 + 3] = P.t_pos[2 * (t0 + ti) + 1];
-                P.m_ratio[dst] = ratio;
-                if (!found_insert(P.found, P.found_cap, k0, k1)) sh_i[7] = 1;
+            if (acc) { tix[na + o] = i | (t_local << 11); nkey[na + o] = (unsigned long long)__double_as_longlong(ratio); }
+            na += cnt;
+        }
+        __syncthreads();
+        EXP_STAMP(4);
+        // (b) per accepted match: neighbour key + seen probe, result key + found probe.
+        //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
+        unsigned long long* rk = (unsigned long long*)smem;        // stage buffer is free now
+        int n_emit = 0;
+        for (int k0 = 0; k0 < na; k0 += 256) {
+            const int k = k0 + tid;
+            const bool live = k < na;
+            double mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
+            unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
+            int qrow_idx = 0;
+            bool known = false;
+            if (live) {
+                const int slot = tix[k] & 2047, t_local = tix[k] >> 11;
+                qrow_idx = cand[slot];
+                rbits = nkey[k];
+                mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
+                px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
+                const int xd = (int)px - ccx, yd = (int)py - ccy;          // Grid_Cache.get_neighbor
+                int ncol = col, nrow = row;
+                if (yd < xd && yd < -xd) ncol = col - 1;
+                else if (xd > yd) nrow = row + 1;
+                else if (yd > -xd) ncol = col + 1;
+                else nrow = row - 1;
+                if (ncol >= 0 && ncol < P.cols && nrow >= 0 && nrow < P.rows) {
+                    nx = (double)center_coord(nrow, P.cell_w, P.width);
+                    ny = (double)center_coord(ncol, P.cell_h, P.height);
+                    nk = pack4x16(blk(ny, P.cell_h), blk(nx, P.cell_w), blk(mqy, P.cell_h), blk(mqx, P.cell_w));
+                }
+                k1 = pack4x16((int)mqx, (int)mqy, (int)px, (int)py);
+                // two independent probes: would the neighbour be skipped when popped? is the
+                // result already in the list?
+                if (nk != ~0ull && set_contains(P.seen, P.seen_cap, nk)) nk = ~0ull;
+                known = found_contains(P.found, P.found_cap, rbits, k1);
+                keys[k] = nk;
+                rk[k] = k1;
             }
-            n_emit += cnt;
+            __syncthreads();
+            // earlier entries of this round with the same key win (lists are in slot order)
+            bool push = live && nk != ~0ull, emit = live && !known;
+            if (live) {
+                for (int j = 0; j < k && (push || emit); ++j) {
+                    if (push && keys[j] == nk) push = false;
+                    if (emit && rk[j] == k1 && nkey[j] == rbits) emit = false;
+                }
+            }
+            // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
+            // chunks of 256 accepted matches are pushed in reverse chunk order below
+            int po;
+            const int ptot = block_exclusive_scan(push ? 1 : 0, &po, wave_tot);
+            int eo;
+            const int etot = block_exclusive_scan(emit ? 1 : 0, &eo, wave_tot);
+            if (tid == 0) {
+                sh_i[5] = (sh_top + ptot > P.stack_cap) ? 1 : 0;
+                sh_i[6] = (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) ? 1 : 0;
+            }
+            __syncthreads();
+            if (sh_i[5]) { status = kExpStackFull; break; }
+            if (sh_i[6]) { status = kExpMatchFull; break; }
+            if (push) {
+                // a later chunk (k0 > 0) must end up BELOW this one: handled by pushing chunks
+                // into a per-round region whose size is known only at the end, so for more
+                // than 256 accepted matches the region is reversed afterwards (rare)
+                const long long dst = sh_top + po;
+                P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
+                P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
+            }
+            if (emit) {
+                const long long dst = n_matches + n_emit + eo;
+                P.m_index[dst] = qrow_idx;
+                P.m_pos[dst * 4 + 0] = mqx; P.m_pos[dst * 4 + 1] = mqy;
+                P.m_pos[dst * 4 + 2] = px;  P.m_pos[dst * 4 + 3] = py;
+                P.m_ratio[dst] = __longlong_as_double((long long)rbits);
+                if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
+            }
+            n_emit += etot;
+            __syncthreads();
+            if (tid == 0) { sh_top += ptot; top += ptot; }
+            __syncthreads();
         }
         if (status != kExpOk) break;
+        // The pushed region [top_before, top) is in ascending slot order; the first accepted
+        // match must be popped first, i.e. sit on top: reverse the region in place.
+        {
+            const long long lo = sh_i_top_before, hi = sh_top;
+            const long long cntp = hi - lo;
+            for (long long x = tid; x < cntp / 2; x += 256) {
+                const long long a = lo + x, b = hi - 1 - x;
+                for (int c = 0; c < 4; ++c) { const double t = P.stack[a * 4 + c]; P.stack[a * 4 + c] = P.stack[b * 4 + c]; P.stack[b * 4 + c] = t; }
+            }
+        }
+        EXP_STAMP(5);
         n_matches += n_emit;
         __threadfence_block();
         __syncthreads();           // table / stack writes visible before the next round reads them
         if (sh_i[7]) { status = kExpTableFull; break; }
+        EXP_STAMP(6);
     }
     if (tid == 0) {
         P.result[0] = n_matches;
         P.result[1] = n_rounds;
         P.result[2] = n_pairs;
         P.result[3] = status;
+        if (P.prof) for (int k = 0; k < 8; ++k) P.result[4 + k] = pt[k];
     }
 }
 

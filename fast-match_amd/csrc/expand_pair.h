@@ -36,7 +36,8 @@ struct ExpandPair {
     double*  m_pos;                // [match_cap][4]
     double*  m_ratio;              // [match_cap]
     int64_t  match_cap;
-    long long* result;             // [4]: n_matches, n_rounds, n_pairs, status
+    long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers
+    int        prof;               // non-zero: thread 0 accumulates per-phase 100 MHz ticks
 };
 
 
