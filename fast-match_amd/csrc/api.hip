@@ -914,7 +914,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16);
     const size_t o_stack = carve((size_t)stack_cap * 32), o_seen = carve((size_t)seen_cap * 8), o_found = carve((size_t)found_cap * 16);
     const size_t o_mi = carve((size_t)match_cap * 4), o_mp = carve((size_t)match_cap * 32), o_mr = carve((size_t)match_cap * 8);
-    const size_t o_res = carve(128);
+    const size_t o_res = carve(256);
     hipError_t e = hipMalloc(&ex->blob, off);
     if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
     char* b = (char*)ex->blob;
@@ -1006,11 +1006,12 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
     if (getenv("FM_EXPAND_PROF")) {
-        long long pr[12];
+        long long pr[16];
         (void)hipMemcpy(pr, pairs[0]->dev.result, sizeof(pr), hipMemcpyDeviceToHost);
-        static const char* names[7] = {"pop+key", "radius", "sort", "x1_round", "compact", "neigh+push+emit", "end"};
+        static const char* names[12] = {"pop+key", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "-",
+                                        "x1:bfrag+barrier", "x1:gather", "x1:mfma", "x1:merge"};
         fprintf(stderr, "[fm_expand prof, pair 0, %lld rounds] ", pr[1]);
-        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
+        for (int k = 0; k < 12; ++k) if (k != 7) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
         fprintf(stderr, "\n");
     }
     rc = cs.finish();

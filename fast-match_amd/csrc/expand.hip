@@ -27,6 +27,9 @@
 namespace fm {
 
 constexpr int kExpCand = 2048;            // radius-subset capacity per round
+constexpr int kExpSR = 512;               // query rows gathered per staging step
+constexpr int kExpStageBytes = kExpSR * kDim + kExpSR / 32 * 256;
+constexpr int kExpLdsBytes = kExpStageBytes + kExpCand * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5 };
 
@@ -104,60 +107,88 @@ __device__ __forceinline__ int center_coord(int i, int cell, int limit)
 }
 
 // Sort n <= kExpCand (key, idx) pairs held in LDS ascending by (key, idx); pairs are unique.
-// Runs of 64 are sorted inside a wave with a shuffle bitonic network (no barriers), then
-// every element finds its final rank by binary-searching the other runs.  tmp: int[kExpCand].
-__device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, int* tmp, int n)
+// keys are the bit patterns of squared distances in [0, r2]: inside a disc they are spread
+// uniformly, so a counting sort over kSortBuckets linear buckets leaves ~n / kSortBuckets
+// elements per bucket and the exact order inside a bucket is fixed by a handful of
+// comparisons.  bucket(d2) is monotone in d2, so bucket order + in-bucket order = total order.
+// Scratch: k2 (u64[kExpCand]), i2 (int[kExpCand]), hist (int[2 * kSortBuckets + 8]).
+constexpr int kSortBuckets = 1024;
+__device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot);
+
+__device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, unsigned long long* k2,
+                                                 int* i2, int* hist, int n, double r2)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nruns = (n + 63) >> 6;
-    for (int r = wave; r < nruns; r += 4) {
-        const int i = r * 64 + lane;
-        unsigned long long k = i < n ? keys[i] : ~0ull;
-        int v = i < n ? idx[i] : 0x7fffffff;
+    const int tid = threadIdx.x;
+    int* start = hist;                       // [kSortBuckets + 1] after the scan
+    int* cursor = hist + kSortBuckets + 4;   // [kSortBuckets]
+    for (int b = tid; b < kSortBuckets; b += 256) { start[b] = 0; cursor[b] = 0; }
+    __syncthreads();
+    const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
+    int myb[kExpCand / 256];
 #pragma unroll
-        for (int kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-            for (int j = kk >> 1; j > 0; j >>= 1) {
-                const unsigned long long ok = __shfl_xor(k, j);
-                const int ov = __shfl_xor(v, j);
-                const bool up = (lane & kk) == 0;            // ascending block
-                const bool lower = (lane & j) == 0;          // this lane keeps the smaller one
-                const bool other_less = ok < k || (ok == k && ov < v);
-                const bool take = (lower == up) ? other_less : !other_less;
-                k = take ? ok : k;
-                v = take ? ov : v;
-            }
-        keys[i] = k;                                          // padded slots sort to the end
-        idx[i] = v;
+    for (int s = 0; s < kExpCand / 256; ++s) {
+        const int i = s * 256 + tid;
+        myb[s] = 0;
+        if (i < n) {
+            const double d2 = __longlong_as_double((long long)keys[i]);
+            int b = (int)(d2 * scale);
+            b = b < kSortBuckets - 1 ? b : kSortBuckets - 1;
+            myb[s] = b;
+            atomicAdd(&start[b], 1);
+        }
     }
     __syncthreads();
-    if (nruns > 1) {
-        for (int i = tid; i < n; i += 256) {
-            const unsigned long long k = keys[i];
-            const int v = idx[i];
-            const int r = i >> 6;
-            int rank = i & 63;
-            for (int o = 0; o < nruns; ++o) {
-                if (o == r) continue;
-                const int base = o * 64;
-                int lo = 0, hi = min(64, n - base);          // number of (key, idx) < (k, v) in run o
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const unsigned long long mk = keys[base + mid];
-                    const bool less = mk < k || (mk == k && idx[base + mid] < v);
-                    if (less) lo = mid + 1; else hi = mid;
-                }
-                rank += lo;
-            }
-            tmp[rank] = v;
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) idx[i] = tmp[i];
-        __syncthreads();
+    // exclusive scan of the bucket counts: 4 buckets per thread
+    {
+        int c[4], s = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c[q] = start[tid * 4 + q]; s += c[q]; }
+        int off;
+        block_exclusive_scan_nosync(s, &off, hist + 2 * kSortBuckets + 8 /* tail: wave totals */);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { start[tid * 4 + q] = off; off += c[q]; }
+        if (tid == 255) start[kSortBuckets] = off;
     }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kExpCand / 256; ++s) {
+        const int i = s * 256 + tid;
+        if (i < n) {
+            const int p = start[myb[s]] + atomicAdd(&cursor[myb[s]], 1);
+            k2[p] = keys[i];
+            i2[p] = idx[i] | 0;          // (bucket order; order inside a bucket is arbitrary here)
+        }
+    }
+    __syncthreads();
+    // final position = bucket start + number of smaller pairs inside the bucket
+#pragma unroll
+    for (int s = 0; s < kExpCand / 256; ++s) {
+        const int p = s * 256 + tid;
+        if (p < n) {
+            const unsigned long long k = k2[p];
+            const int v = i2[p];
+            double d2 = __longlong_as_double((long long)k);
+            int b = (int)(d2 * scale);
+            b = b < kSortBuckets - 1 ? b : kSortBuckets - 1;
+            const int s0 = start[b], s1 = start[b + 1];
+            int rank = s0;
+            for (int j = s0; j < s1; ++j) {
+                const unsigned long long kj = k2[j];
+                rank += (kj < k || (kj == k && i2[j] < v)) ? 1 : 0;
+            }
+            keys[rank] = k;
+            idx[rank] = v;
+        }
+    }
+    __syncthreads();
 }
 
 // Exclusive scan of per-thread counts over the 256-thread block; returns the total.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[4]*/);
+__device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot)
+{
+    return block_exclusive_scan(v, my_offset, wave_tot);
+}
 __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[4]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -180,11 +211,15 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* 
 __global__ __launch_bounds__(256)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
-    __shared__ __attribute__((aligned(16))) char smem[kStageBytes];
-    __shared__ unsigned long long keys[kExpCand];     // sort keys (d2 bits), then the qbest table
-    __shared__ int cand[kExpCand];                    // candidate / sorted query rows
-    __shared__ int tix[kExpCand];                     // matched local train index per slot (-1 none)
-    __shared__ unsigned long long nkey[kExpCand];     // per slot: neighbour round key / dedup key part
+    // dynamic LDS (kExpLdsBytes): a 512-row gather stage, the sort keys / qbest table, the
+    // candidate rows, and two scratch arrays
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* smem = dyn_lds;                                                         // kExpStageBytes
+    unsigned long long* keys = (unsigned long long*)(dyn_lds + kExpStageBytes);   // sort keys, then qbest
+    unsigned long long* nkey = keys + kExpCand;                                   // ratio bits of accepted matches
+    int* cand = (int*)(nkey + kExpCand);                                          // candidate / sorted query rows
+    int* tix  = cand + kExpCand;                                                  // sort scratch, then accepted list
+    int* hist = tix + kExpCand;                                                   // counting-sort buckets
     __shared__ double cur[4];                         // query_pos, target_pos of the round
     __shared__ int sh_i[8];
     __shared__ long long sh_top;
@@ -198,7 +233,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     long long n_matches = 0, n_rounds = 0, n_pairs = 0;
     long long seen_n = 0;
     int status = kExpOk;
-    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tstamp = P.prof ? wall_clock64() : 0;
 #define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
 
@@ -276,7 +311,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (nq > kExpCand) { status = kExpCandFull; break; }
         EXP_STAMP(1);
         // sort by (d2 bits, index): non-negative doubles order like their bit patterns
-        block_sort_pairs(keys, cand, tix, nq);
+        block_sort_pairs(keys, cand, nkey, tix, hist, nq, (double)P.radius * (double)P.radius);
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
@@ -286,7 +321,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
         for (int i = tid; i < nq; i += 256) keys[i] = ~0ull;     // keys[] becomes the qbest table
-        x1_round<1>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys);
+        x1_round_wsplit<kExpSR>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
+                                (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
         __syncthreads();
 
         EXP_STAMP(3);
@@ -420,13 +456,19 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[1] = n_rounds;
         P.result[2] = n_pairs;
         P.result[3] = status;
-        if (P.prof) for (int k = 0; k < 8; ++k) P.result[4 + k] = pt[k];
+        if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
     }
 }
 
 hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream)
 {
-    hipLaunchKernelGGL(expand_kernel, dim3(n_pairs), dim3(256), 0, stream, (const ExpandPair*)d_pairs);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(expand_kernel, dim3(n_pairs), dim3(256), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
     return hipGetLastError();
 }
 
