@@ -77,7 +77,7 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 
 // NW waves per workgroup share every staged tile; each wave owns NC blocks of 16 output rows.
 template <int NC, int KTOP, bool GLDS, int NW>
-__global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : 4))
+__global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
 void rowreduce_kernel(RRParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
@@ -272,7 +272,7 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     // 4 for small ones so that enough workgroups exist.
     int nb = 4, nw = 8;
     if (ncols_pad < 512 * 64) nw = 4;
-    if (force_nb == 4 || force_nb == 8) nb = force_nb;
+    if (force_nb == 4 || force_nb == 6 || force_nb == 8) nb = force_nb;
     if (force_nw == 4 || force_nw == 8 || force_nw == 16) nw = force_nw;
     pl.nb = nb;
     pl.nw = nw;
@@ -309,6 +309,10 @@ static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t s
 template <int KTOP>
 static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool glds, hipStream_t stream)
 {
+    if (nb == 6) {
+        if (nw == 8) return launch_t<6, KTOP, 8>(p, grid, glds, stream);
+        return launch_t<6, KTOP, 4>(p, grid, glds, stream);
+    }
     if (nb == 8) {
         if (nw == 16) return launch_t<8, KTOP, 16>(p, grid, glds, stream);
         if (nw == 8) return launch_t<8, KTOP, 8>(p, grid, glds, stream);
