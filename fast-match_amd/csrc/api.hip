@@ -235,7 +235,7 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qb
         if (pass) pass[q] = p ? 1 : 0;
     }
     const unsigned long long m = __ballot(p);
-    if (npass) {
+    if (npass && !block_counts) {            // (with block counts the total comes from compact_kernel)
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(npass, (unsigned long long)__popcll(m));
     }
     if (block_counts) {                      // for the ordered compaction (compact_kernel)
@@ -252,7 +252,8 @@ __global__ void compact_kernel(const int32_t* __restrict__ tidx, const float* __
                                const double* __restrict__ ratio, const uint8_t* __restrict__ pass,
                                const int* __restrict__ block_counts, int64_t nq, int64_t cap,
                                int32_t* __restrict__ o_q, int32_t* __restrict__ o_t,
-                               float* __restrict__ o_d, double* __restrict__ o_r)
+                               float* __restrict__ o_d, double* __restrict__ o_r,
+                               unsigned long long* __restrict__ npass)
 {
     __shared__ int red[256];
     __shared__ int wave_base[4];
@@ -274,6 +275,8 @@ __global__ void compact_kernel(const int32_t* __restrict__ tidx, const float* __
     __syncthreads();
     int wb = 0;
     for (int w = 0; w < wave; ++w) wb += wave_base[w];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0)       // total = everything before the last block + its own
+        *npass = (unsigned long long)(base + wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3]);
     if (p) {
         const int64_t dst = base + wb + __popcll(m & ((1ull << lane) - 1ull));
         if (dst < cap) { o_q[dst] = (int32_t)q; o_t[dst] = tidx[q]; o_d[dst] = dist[q]; o_r[dst] = ratio[q]; }
@@ -693,7 +696,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
 
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    if (!compact) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nt > 0) {
         if (d_bound)
             HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
@@ -718,7 +721,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
                            (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
                            (const int*)(base + o_bc), nq, ccap, (int32_t*)(base + o_cq), (int32_t*)(base + o_ct),
-                           (float*)(base + o_cd), (double*)(base + o_cr));
+                           (float*)(base + o_cd), (double*)(base + o_cr), d_cnt);
         HIP_TRY(ctx, hipGetLastError());
         // the count must be known before the copies can be sized: one tiny synchronous read
         HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
