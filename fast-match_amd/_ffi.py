@@ -63,6 +63,7 @@ SYMBOLS = {
     "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
+    "fm_knn2_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_self_dist": (_INT, [_P, _P, _P]),
     "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
@@ -299,6 +300,20 @@ class Context(object):
         n = _I64(0)
         self._check(self.lib.fm_match_accepted(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx),
                                                _ptr(tidx), _ptr(dist), _ptr(ratio), ctypes.byref(n)))
+        m = min(n.value, cap)
+        return qidx[:m], tidx[:m], dist[:m], ratio[:m]
+
+    def knn2_ratio(self, q, t, tau, out=None):
+        """Classic Ratio-Match: 2-NN + d1/d2 < tau, accepted matches in ascending query index:
+        (qidx i32[m], tidx i32[m], dist f32[m] (= d1), ratio f64[m])."""
+        if out is None:
+            cap = q.n
+            out = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.float64))
+        qidx, tidx, dist, ratio = out
+        cap = qidx.shape[0]
+        n = _I64(0)
+        self._check(self.lib.fm_knn2_ratio(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx), _ptr(tidx),
+                                           _ptr(dist), _ptr(ratio), ctypes.byref(n)))
         m = min(n.value, cap)
         return qidx[:m], tidx[:m], dist[:m], ratio[:m]
 

@@ -301,6 +301,32 @@ __global__ void ratio_filter_kernel(const float* __restrict__ dist, const double
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(npass, (unsigned long long)__popcll(m));
 }
 
+// Classic Ratio-Match (Classic Matching.ipynb cell 3): ratio = float64(d1) / float64(d2) of
+// the 2-NN list, accepted when ratio < tau (d2 == 0 gives inf / nan: rejected, where the
+// notebook's Python division would raise).  Feeds compact_kernel.
+__global__ void lowe_kernel(const int32_t* __restrict__ idx2, const float* __restrict__ dist2, int64_t nq,
+                            double tau, int32_t* __restrict__ tidx, float* __restrict__ dist,
+                            double* __restrict__ ratio, uint8_t* __restrict__ pass,
+                            int* __restrict__ block_counts)
+{
+    __shared__ int wave_cnt[4];
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool p = false;
+    if (q < nq) {
+        const float d1 = dist2[2 * q], d2 = dist2[2 * q + 1];
+        const double r = (idx2[2 * q + 1] >= 0) ? (double)d1 / (double)d2 : NAN;
+        p = r < tau;
+        tidx[q] = idx2[2 * q];
+        dist[q] = d1;
+        ratio[q] = r;
+        pass[q] = p ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(p);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
 __global__ void selfdist_from_knn_kernel(const float* __restrict__ dist2, int64_t n, double* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -630,6 +656,53 @@ extern "C" int fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
     return cs.finish();
+}
+
+extern "C" int fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                             int32_t* qidx, int32_t* tidx, float* dist, double* ratio, int64_t* n_accepted)
+{
+    int rc = check_pair(ctx, q, t, "fm_knn2_ratio");
+    if (rc != FM_OK) return rc;
+    if (n_accepted) *n_accepted = 0;
+    const int64_t nq = q->n;
+    if (nq == 0) return FM_OK;
+    if (cap < 0 || !qidx || !tidx || !dist || !ratio) return fail(ctx, FM_EINVAL, "fm_knn2_ratio: bad output arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int nblk = (int)((nq + 255) / 256);
+    const int64_t ccap = cap < nq ? cap : nq;
+    // knn lists | per-q tidx, dist, ratio, pass | block counts, count | compacted outputs
+    size_t off = 0;
+    auto carve = [&](size_t b) { size_t o = off; off += (b + 15) & ~(size_t)15; return o; };
+    const size_t o_i2 = carve((size_t)nq * 8), o_d2 = carve((size_t)nq * 8), o_ti = carve((size_t)nq * 4), o_di = carve((size_t)nq * 4);
+    const size_t o_ra = carve((size_t)nq * 8), o_pa = carve((size_t)nq), o_bc = carve((size_t)nblk * 4), o_cnt = carve(16);
+    const size_t o_cq = carve((size_t)ccap * 4), o_ct = carve((size_t)ccap * 4), o_cd = carve((size_t)ccap * 4), o_cr = carve((size_t)ccap * 8);
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, off + 64)) != FM_OK) return rc;
+    char* b = (char*)ctx->ws_out;
+    CallScope cs(ctx);
+    if ((rc = knn2_device(ctx, q, t, (int32_t*)(b + o_i2), (float*)(b + o_d2))) != FM_OK) return rc;
+    hipLaunchKernelGGL(lowe_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, (const int32_t*)(b + o_i2),
+                       (const float*)(b + o_d2), nq, tau, (int32_t*)(b + o_ti), (float*)(b + o_di), (double*)(b + o_ra),
+                       (uint8_t*)(b + o_pa), (int*)(b + o_bc));
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, (const int32_t*)(b + o_ti),
+                       (const float*)(b + o_di), (const double*)(b + o_ra), (const uint8_t*)(b + o_pa), (const int*)(b + o_bc),
+                       nq, ccap, (int32_t*)(b + o_cq), (int32_t*)(b + o_ct), (float*)(b + o_cd), (double*)(b + o_cr),
+                       (unsigned long long*)(b + o_cnt));
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long cnt = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&cnt, b + o_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t m = (size_t)((int64_t)cnt < ccap ? (int64_t)cnt : ccap);
+    if (m) {
+        HIP_TRY(ctx, hipMemcpyAsync(qidx, b + o_cq, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(tidx, b + o_ct, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dist, b + o_cd, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ratio, b + o_cr, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    rc = cs.finish();
+    if (rc != FM_OK) return rc;
+    if (n_accepted) *n_accepted = (int64_t)cnt;
+    return FM_OK;
 }
 
 extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)

@@ -113,6 +113,22 @@ def flann_match_arrays(dt1, dt2, k=1, options={}):
     return bf_match_arrays(dt1, dt2, k=k, options=opts)
 
 
+def ratio_match_arrays(dt1, dt2, tau, options={}):
+    """Classic Ratio-Match (the reference's baseline, ``Classic Matching.ipynb`` cell 3):
+    brute-force 2-NN then ``m[0].distance / m[1].distance < tau`` in float64, on the device.
+    Returns (query idx, train idx, distance, ratio) of the accepted matches, ascending query."""
+    ctx = _context(options)
+    qb, q_tmp = _as_bank(ctx, dt1)
+    tb, t_tmp = _as_bank(ctx, dt2)
+    try:
+        return ctx.knn2_ratio(qb, tb, tau)
+    finally:
+        if q_tmp:
+            qb.close()
+        if t_tmp:
+            tb.close()
+
+
 # ---- SIFT stays in OpenCV on the host -------------------------------------------------
 
 def sift():

@@ -89,6 +89,14 @@ int  fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* selfdist /*[
 int  fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
              int32_t* idx /*[nq*2]*/, float* dist /*[nq*2]*/);
 
+/* Classic Ratio-Match in one call: knnMatch(q, t, k=2) then ratio = m[0].distance /
+ * m[1].distance (float64) and ratio < tau  -- Classic Matching.ipynb cell 3 (JSON 59-72), the
+ * baseline Fast-Match is compared against (README.md:5-13).  Returns the accepted matches
+ * compacted in ascending query index: qidx/tidx/dist (= d1)/ratio[0 .. min(*n_accepted, cap)).
+ * A zero second distance (where the notebook's Python division raises) is rejected.       */
+int  fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                   int32_t* qidx, int32_t* tidx, float* dist, double* ratio, int64_t* n_accepted);
+
 /* Replaces bf_match(d, d, k=2) + [r[1].distance] (cache.pyx:250-252; exact substitute
  * for the approximate flann_match at cache.pyx:271-273).  selfdist[i] = distance from
  * row i to its 2nd entry of the self 2-NN list, as float64 of the float32 value.         */

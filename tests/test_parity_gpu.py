@@ -344,3 +344,21 @@ def test_match_accepted_is_the_compacted_match_ratio(ctx):
     # nothing accepted
     qa3, _, _, _ = ctx.match_accepted(qb, tb, 0.0)
     assert len(qa3) == 0
+
+
+def test_classic_ratio_match_knn2_ratio(ctx):
+    """CR row: 2-NN + d1/d2 (float64) < tau, against the oracle's restatement of the notebook."""
+    Q, T, _ = synth.planted_pair(3000, 2600, seed=17)
+    T[10] = T[11]                                          # some query may see d1 == d2
+    Q[4] = T[10]                                           # d1 = d2 = 0 -> nan -> rejected
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    qa, ta, da, ra = ctx.knn2_ratio(qb, tb, 0.7)
+    oidx, od = oracle.bf_knn(Q, T, 2)
+    orat = oracle.lowe_ratio(od)
+    sel = np.nonzero(orat < 0.7)[0]
+    assert len(sel) > 100 and 4 not in sel
+    assert np.array_equal(qa, sel.astype(np.int32)) and _eq(ta, oidx[sel, 0]) and _eq(da, od[sel, 0]) and _eq(ra, orat[sel])
+    q2, t2, d2, r2 = matchutil.ratio_match_arrays(Q, T, 0.7, {"context": ctx})
+    assert np.array_equal(q2, qa) and _eq(r2, ra)
+    # fewer than two train rows: nothing can pass
+    assert len(ctx.knn2_ratio(qb, ctx.bank(T[:1]), 0.99)[0]) == 0
