@@ -141,3 +141,19 @@ def test_device_loop_falls_back_when_it_cannot_run(ctx):
     got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.7)
     exp = fo.o_match(oq, ot, {"radius": 200})(0.7)
     _same_matches(got, exp)
+
+
+def test_device_loop_equals_host_loop_at_config3_scale(ctx):
+    """BASELINE config 3 geometry at reduced keypoint count (6000 x 4000 image, 9801 cells,
+    60k keypoints/side): tens of thousands of rounds, device loop == host-driven loop."""
+    q, t = synth.image_pair((6000, 4000), 60000, seed=20250003, n_thumb=1500)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    ds, hs = {}, {}
+    dev = fastmatch.match(mc, fi, {"context": ctx, "stats": ds})(0.7)
+    host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.7)
+    assert ds["rounds"] == hs["rounds"] > 3000 and ds["pairs"] == hs["pairs"]
+    _same_matches(dev, host)
+    assert len(dev) > 5000
