@@ -102,7 +102,7 @@ def main():
     # N > 1: the all-gather of step i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of step i+1 (the library's stream); the last one is waited for inside
     # the timed region.
-    gatherer = sharding.MatchGatherer(dev, capacity=NQ // 2) if world > 1 else None
+    gatherer = sharding.MatchGatherer(dev, capacity=NQ) if world > 1 else None
 
     def step():
         # X1 + R1 + ordered compaction of the accepted matches on the device (fm_match_accepted)
