@@ -362,3 +362,24 @@ def test_classic_ratio_match_knn2_ratio(ctx):
     assert np.array_equal(q2, qa) and _eq(r2, ra)
     # fewer than two train rows: nothing can pass
     assert len(ctx.knn2_ratio(qb, ctx.bank(T[:1]), 0.99)[0]) == 0
+
+
+def test_train_set_beyond_opencv_18bit_limit(ctx):
+    """OpenCV packs the train index in 18 bits and asserts nt < 262144 (SURVEY.md Appendix A.4);
+    this path has no such limit: a 300k-row bank (config-3 size) against the oracle."""
+    rng = np.random.default_rng(33)
+    T = synth.synth_sift(300000, rng)
+    Q = synth.synth_sift(512, rng)
+    sel = rng.choice(300000, 200, replace=False)
+    Q[:200] = np.clip(T[sel].astype(np.int32) + rng.integers(-4, 5, (200, 128)), 0, 255).astype(np.uint8)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    idx, dist = ctx.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2)
+    assert _eq(idx, oidx) and _eq(dist, odist) and idx.max() >= 262144
+    tidx, xd = ctx.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(xd, oxd)
+    # and the transposed problem (big query side)
+    t2, d2 = ctx.xcheck1(tb, qb)
+    ot2, od2 = oracle.bf_xcheck1(T, Q)
+    assert _eq(t2, ot2) and _eq(d2, od2)
