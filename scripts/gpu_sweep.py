@@ -46,9 +46,9 @@ def run(env):
               res["k2"][0], res["k2"][1], res["k2_ok"]), flush=True)
 
 
-variants = [dict(FM_COOP=c, FM_NSPLIT=s, FM_NB=nb) for c, s, nb in
-            [(1, 0, 0), (0, 0, 0), (1, 8, 4), (0, 8, 4), (1, 16, 4), (1, 32, 4), (1, 48, 4),
-             (1, 16, 2), (1, 32, 2), (1, 64, 2), (0, 1, 4)]]
+variants = [dict(FM_COOP=c, FM_NSPLIT=s, FM_NB=nb, FM_NW=nw) for c, s, nb, nw in
+            [(1, 0, 0, 0), (0, 0, 0, 0), (1, 8, 4, 8), (1, 16, 4, 8), (1, 32, 4, 8), (1, 16, 4, 4),
+             (1, 16, 4, 16), (1, 16, 8, 8), (0, 1, 4, 8)]]
 if len(sys.argv) > 1:
     variants = [eval("dict(%s)" % a) for a in sys.argv[1:]]
 for v in variants:
