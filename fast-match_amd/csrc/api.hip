@@ -36,6 +36,7 @@ struct fm_ctx {
     int force_nb = 0, force_nsplit = 0, force_nw = 0;
     bool use_glds = true;
     bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
+    unsigned long long* h_scratch = nullptr;   // pinned host words the kernels can write (counts)
     fm_stats stats{};
     bool kernel_timed = false;
     int64_t pending_pairs = 0;
@@ -379,6 +380,7 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
         delete ctx;
         return fail(nullptr, FM_EDEVICE, std::string("fm_ctx_create: ") + hipGetErrorString(e));
     }
+    if (hipHostMalloc((void**)&ctx->h_scratch, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_scratch = nullptr; }
     if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
     if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
     if (const char* s = getenv("FM_NW")) ctx->force_nw = atoi(s);
@@ -396,6 +398,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (ctx->ws_partial) (void)hipFree(ctx->ws_partial);
     if (ctx->ws_out) (void)hipFree(ctx->ws_out);
     if (ctx->ws_in) (void)hipFree(ctx->ws_in);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
@@ -450,6 +453,17 @@ extern "C" int fm_host_free(fm_ctx* ctx, void* p)
     hipError_t e = hipHostFree(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, FM_EDEVICE, std::string("fm_host_free: ") + hipGetErrorString(e)); }
     return FM_OK;
+}
+
+// Device-side alias of a page-locked host buffer (fm_host_alloc / hipHostMalloc), or NULL for
+// ordinary pageable memory: kernels can then write results straight into the caller's buffer.
+static void* pinned_device_alias(const void* host)
+{
+    if (!host) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    return at.devicePointer;
 }
 
 // Brackets one API call: events for total time, stats accounting after the final sync.
@@ -791,6 +805,22 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long cnt = 0;
     if (compact) {
+        // caller-owned page-locked outputs: the compaction writes them (and the count) directly,
+        // no staging copies and a single synchronisation
+        void* a_q = pinned_device_alias(c_qidx); void* a_t = pinned_device_alias(tidx);
+        void* a_d = pinned_device_alias(dist);   void* a_r = pinned_device_alias(ratio);
+        void* a_c = ctx->h_scratch ? pinned_device_alias(ctx->h_scratch) : nullptr;
+        if (a_q && a_t && a_d && a_r && a_c && compact_cap <= nq) {
+            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                               (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
+                               (const int*)(base + o_bc), nq, ccap, (int32_t*)a_q, (int32_t*)a_t,
+                               (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
+            HIP_TRY(ctx, hipGetLastError());
+            rc = cs.finish();
+            if (rc != FM_OK) return rc;
+            if (n_pass) *n_pass = (int64_t)ctx->h_scratch[0];
+            return FM_OK;
+        }
         hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
                            (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
                            (const int*)(base + o_bc), nq, ccap, (int32_t*)(base + o_cq), (int32_t*)(base + o_ct),
