@@ -116,3 +116,18 @@ def test_synth_is_deterministic_and_sift_like():
     assert Q.dtype == np.uint8 and Q.shape == (200, 128) and (planted >= 0).sum() == 60
     norms = np.linalg.norm(T.astype(np.float64), axis=1)
     assert 400 < norms.mean() < 620                             # ~512 like OpenCV SIFT
+
+
+@pytest.mark.parametrize("size,cell,margin", [((500, 333), (50, 50), 25), ((611, 389), (64, 48), 0),
+                                              ((800, 640), (75, 75), 40), ((123, 77), (50, 50), 25)])
+def test_vectorised_cell_packing_equals_cell_by_cell(size, cell, margin):
+    import time
+    _, t = synth.image_pair(size, 3000, seed=size[0])
+    t["positions"][:5] = [[0, 0], [size[0] - 1e-9, size[1] - 1e-9], [cell[0], cell[1]], [cell[0] + margin, 0.5], [25.0, 25.0]]
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"])
+    fast = cache.Grid_Cache(fi, cell, fi, margin=margin).pack_cells()
+    slow_grid = cache.Grid_Cache(fi, cell, lambda _c, bounds: fi(None, bounds), margin=margin)
+    slow_grid.fun.wants_bounds = True
+    slow = slow_grid.pack_cells()                               # visits every cell (no pack_all on a lambda)
+    for a, b in zip(fast, slow):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
