@@ -157,3 +157,25 @@ def test_device_loop_equals_host_loop_at_config3_scale(ctx):
     assert ds["rounds"] == hs["rounds"] > 3000 and ds["pairs"] == hs["pairs"]
     _same_matches(dev, host)
     assert len(dev) > 5000
+
+
+def test_evaluate_many_thresholds_reuses_state(ctx):
+    """turntable.evaluate-style driver: precision table over thresholds, device loop and host
+    loop agree, precision against the planted ground truth is high at tau 0.7."""
+    from fastmatch_amd import evaluate
+    pairs, scorers = [], []
+    for k in range(3):
+        q, t = synth.image_pair((640, 480), 2500, seed=300 + k)
+        mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                            q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+        fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                                 t["thumb_descriptors"], t["thumb_size"])
+        pairs.append((mc, fi))
+        scorers.append(evaluate.planted_scorer(q["planted"], t["positions"]))
+    taus = [0.5, 0.6, 0.7, 0.8, 0.9]
+    dev = evaluate.evaluate(pairs, taus, scorers, {"context": ctx})
+    host = evaluate.evaluate(pairs, taus, scorers, {"context": ctx, "device_loop": False})
+    assert dev == host
+    totals = [r["total"] for r in dev]
+    assert totals == sorted(totals) and totals[0] > 0
+    assert dev[2]["precision"] > 0.7

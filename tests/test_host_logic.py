@@ -131,3 +131,28 @@ def test_vectorised_cell_packing_equals_cell_by_cell(size, cell, margin):
     slow = slow_grid.pack_cells()                               # visits every cell (no pack_all on a lambda)
     for a, b in zip(fast, slow):
         assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def test_homography_and_planted_scorers(tmp_path):
+    from fastmatch_amd import evaluate
+    H = np.array([[0.9, 0.1, 12.0], [-0.05, 1.1, -7.0], [1e-4, -2e-5, 1.0]])
+    f = tmp_path / "H1to4p"
+    f.write_text("\n".join("  ".join("%.7e" % v for v in r) for r in H) + "\n")
+    assert np.allclose(evaluate.load_homography(str(f)), H)
+    rng = np.random.default_rng(1)
+    src = rng.uniform(0, 600, (50, 2))
+    h = np.concatenate([src, np.ones((50, 1))], axis=1) @ H.T
+    dst = h[:, :2] / h[:, 2:3]
+    dst[::2] += 20.0                                            # every other match is wrong
+    pos = np.stack([src, dst], axis=1)
+    good = evaluate.homography_scorer(H, 3.0)(np.arange(50), pos, np.zeros(50))
+    assert good.tolist() == [i % 2 == 1 for i in range(50)]
+    # query on the destination side: positions swapped, inverse mapping
+    good2 = evaluate.homography_scorer(H, 3.0, query_is_source=False)(np.arange(50), pos[:, ::-1, :], np.zeros(50))
+    assert good2.tolist() == good.tolist()
+    planted = np.array([3, -1, 0])
+    tpos = np.array([[1.0, 2.0], [5.0, 5.0], [9.0, 9.0], [7.0, 8.0]])
+    sc = evaluate.planted_scorer(planted, tpos)
+    p = np.array([[[0, 0], [7.0, 8.0]], [[0, 0], [5.0, 5.0]], [[0, 0], [9.0, 9.0]]])
+    assert sc(np.array([0, 1, 2]), p, None).tolist() == [True, False, False]
+    assert sc(np.array([], dtype=int), np.zeros((0, 2, 2)), None).shape == (0,)
