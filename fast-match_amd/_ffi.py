@@ -55,6 +55,7 @@ SYMBOLS = {
     "fm_get_stats": (_INT, [_P, ctypes.POINTER(fm_stats)]),
     "fm_reset_stats": (_INT, [_P]),
     "fm_device_name": (_INT, [_P, ctypes.c_char_p, _INT]),
+    "fm_f32_filter_stats": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "fm_host_alloc": (_INT, [_P, _I64, ctypes.POINTER(_P)]),
     "fm_host_free": (_INT, [_P, _P]),
     "fm_bank_create_u8": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
@@ -382,6 +383,12 @@ class Context(object):
 
     def sync(self):
         self._check(self.lib.fm_sync(self.handle))
+
+    def f32_filter_stats(self):
+        """(row-reduces routed through the bf16x3 filter, of which redone by the all-pairs kernel)."""
+        a, b = _I64(0), _I64(0)
+        self._check(self.lib.fm_f32_filter_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def device_name(self):
         buf = ctypes.create_string_buffer(256)

@@ -36,6 +36,9 @@ struct fm_ctx {
     int force_nb = 0, force_nsplit = 0, force_nw = 0;
     bool use_glds = true;
     bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
+    int  f32_filter = 1;    // float32 route: 0 = K5 only, 1 = bf16x3 filter for large calls, 2 = always
+    int* d_counters = nullptr;   // device words of the bf16x3 filter (layout: fm_internal.h, launch_filter)
+    int64_t filter_launches = 0;
     unsigned long long* h_scratch = nullptr;   // pinned host words the kernels can write (counts)
     fm_stats stats{};
     bool kernel_timed = false;
@@ -149,6 +152,58 @@ __global__ void bank_copy_f32_kernel(const float* __restrict__ src, int64_t n, i
     const int64_t row = i / kDim;
     const int k = (int)(i % kDim);
     dst[i] = (row < n && k < dim) ? src[row * dim + k] : 0.f;
+}
+
+// bf16 planes, norms and accumulator inits of a float32 bank for the bf16x3 filter
+// (filter_bf16.hip).  16 lanes per row, 8 dims per lane; x = hi + lo + O(2^-18 x) with both
+// terms rounded to nearest even.  stat[0] = max |row|^2 (float bits), stat[1] |= 1 if a norm
+// is not finite.
+__device__ __forceinline__ unsigned bf16_rne(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256)
+void bank_prep_bf16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n_pad,
+                           uint16_t* __restrict__ rowsb, float* __restrict__ normf,
+                           float* __restrict__ auxf, int* __restrict__ stat)
+{
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = threadIdx.x & 15;
+    if (row >= n_pad) return;
+    const float4 v0 = *(const float4*)(rowsf + row * kDim + 8 * c);
+    const float4 v1 = *(const float4*)(rowsf + row * kDim + 8 * c + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], l[8];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = bf16_rne(v[i]);
+        const float rest = v[i] - __uint_as_float(h[i] << 16);
+        l[i] = bf16_rne(rest);
+        ss += (double)v[i] * (double)v[i];
+    }
+    *(uint4*)(rowsb + row * 256 + 8 * c) =
+        make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    *(uint4*)(rowsb + row * 256 + 128 + 8 * c) =
+        make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    ss += __shfl_xor(ss, 8);
+    if (c == 0) {
+        const float nm = (float)ss;
+        if (row < n) {
+            normf[row] = nm;
+            auxf[row] = -0.5f * nm;
+            if (!(nm <= 3.0e38f)) atomicOr(stat + 1, 1);            // inf or NaN
+            else atomicMax(stat, (int)__float_as_uint(nm));          // nm >= 0: bit order = value order
+        } else {
+            normf[row] = 0.f;
+            auxf[row] = -3.4e38f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -386,6 +441,12 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
     if (const char* s = getenv("FM_NW")) ctx->force_nw = atoi(s);
     if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
     if (const char* s = getenv("FM_COOP")) ctx->use_coop = atoi(s) != 0;
+    if (const char* s = getenv("FM_F32_FILTER")) ctx->f32_filter = atoi(s);
+    if (hipMalloc((void**)&ctx->d_counters, 16 + 1024) != hipSuccess || hipMemset(ctx->d_counters, 0, 16 + 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_counters = nullptr;
+        ctx->f32_filter = 0;
+    }
     *out = ctx;
     return FM_OK;
 }
@@ -399,6 +460,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (ctx->ws_out) (void)hipFree(ctx->ws_out);
     if (ctx->ws_in) (void)hipFree(ctx->ws_in);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
@@ -427,6 +489,22 @@ extern "C" int fm_reset_stats(fm_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_reset_stats: ctx is NULL");
     ctx->stats = fm_stats{};
+    return FM_OK;
+}
+
+extern "C" int fm_f32_filter_stats(fm_ctx* ctx, int64_t* launches, int64_t* fallbacks)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_f32_filter_stats: ctx is NULL");
+    int c[4] = {0, 0, 0, 0};
+    if (ctx->d_counters) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, 16, hipMemcpyDeviceToHost));
+    }
+    if (getenv("FM_F32_DEBUG")) fprintf(stderr, "[fm] filter: launches %lld, redone by K5 %d, output rows rescanned %d\n",
+                                        (long long)ctx->filter_launches, c[2], c[3]);
+    if (launches) *launches = ctx->filter_launches;
+    if (fallbacks) *fallbacks = c[2];
     return FM_OK;
 }
 
@@ -503,8 +581,12 @@ static void bank_free(Bank* b)
     if (b->norm) (void)hipFree(b->norm);
     if (b->aux) (void)hipFree(b->aux);
     if (b->rowsf) (void)hipFree(b->rowsf);
+    if (b->rowsb) (void)hipFree(b->rowsb);
+    if (b->normf) (void)hipFree(b->normf);
+    if (b->auxf) (void)hipFree(b->auxf);
     if (b->selfdist) (void)hipFree(b->selfdist);
     b->rows8 = nullptr; b->norm = nullptr; b->aux = nullptr; b->rowsf = nullptr; b->selfdist = nullptr;
+    b->rowsb = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
 
 static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out)
@@ -529,7 +611,7 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     auto bail = [&](int code) { bank_free(b); delete b; return code; };
 
     const size_t flag_off = (src_bytes + 15) & ~(size_t)15;
-    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 16)) != FM_OK) return bail(rc);
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 32)) != FM_OK) return bail(rc);
     int* d_flag = (int*)((char*)ctx->ws_in + flag_off);
 #define BTRY(expr)                                                                               \
     do {                                                                                         \
@@ -566,7 +648,20 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
         hipLaunchKernelGGL(bank_copy_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float*)ctx->ws_in, n, dim, b->rowsf, b->n_pad);
         BTRY(hipGetLastError());
+        // planes for the bf16x3 filter; the filter is used only while every |row|^2 stays in a
+        // range where its error bound holds without overflow or underflow
+        BTRY(hipMalloc((void**)&b->rowsb, (size_t)b->n_pad * 512));
+        BTRY(hipMalloc((void**)&b->normf, (size_t)b->n_pad * 4));
+        BTRY(hipMalloc((void**)&b->auxf, (size_t)b->n_pad * 4));
+        BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(bank_prep_bf16_kernel, dim3((unsigned)(b->n_pad / 16)), dim3(256), 0, ctx->stream,
+                           (const float*)b->rowsf, n, b->n_pad, b->rowsb, b->normf, b->auxf, d_flag);
+        BTRY(hipGetLastError());
+        int stat[2] = {0, 0};
+        BTRY(hipMemcpyAsync(stat, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
         BTRY(hipStreamSynchronize(ctx->stream));
+        memcpy(&b->nm_max, &stat[0], 4);
+        b->filt_ok = stat[1] == 0 && b->nm_max <= 1.0e30f && (b->nm_max >= 1.0e-30f || n == 0);
     }
 #undef BTRY
     *out = b;
@@ -625,6 +720,42 @@ static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const cha
 }
 
 // ---------------------------------------------------------------------------------------
+// float32 route: K5 alone, or the bf16x3 filter (K8) with K5 as its conditional fallback
+// ---------------------------------------------------------------------------------------
+// Leaves the packed keys in ws_partial in `pl`'s layout (K5's plan) either way.
+static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* red, int ktop, RowReducePlan* pl_out)
+{
+    const RowReducePlan pl = plan_rowreduce_f32(cols->n_pad, red->n_pad, ctx->force_nsplit);
+    *pl_out = pl;
+    const bool filter = ctx->f32_filter != 0 && cols->filt_ok && red->filt_ok && cols->rowsb && red->rowsb &&
+                        (ctx->f32_filter >= 2 || (double)cols->n * (double)red->n >= 4.0e6);
+    const size_t part = (pl.partial_bytes(ktop) + 255) & ~(size_t)255;
+    if (!filter) {
+        int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part);
+        if (rc != FM_OK) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, (unsigned long long*)ctx->ws_partial, nullptr, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        return FM_OK;
+    }
+    const FilterPlan fp = plan_filter(cols->n_pad, red->n_pad);
+    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part + fp.slots_bytes() + fp.bound_bytes() + 64);
+    if (rc != FM_OK) return rc;
+    unsigned long long* d_part = (unsigned long long*)ctx->ws_partial;
+    unsigned long long* d_slots = (unsigned long long*)((char*)ctx->ws_partial + part);
+    int* d_bound = (int*)((char*)d_slots + fp.slots_bytes());
+    HIP_TRY(ctx, hipMemsetAsync(d_part, 0xff, pl.partial_bytes(ktop), ctx->stream));
+    HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, filter_empty_bound(), (size_t)fp.ncols_alloc * 2, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_filter(*cols, *red, ktop, fp, d_slots, d_bound, ctx->d_counters, d_part, ctx->stream));
+    HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, d_part, ctx->d_counters, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->filter_launches += 1;
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // K2 entry points
 // ---------------------------------------------------------------------------------------
 // Device-side knn2 into d_idx/d_dist (device pointers).
@@ -633,19 +764,22 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     const int64_t nq = q->n;
     if (nq == 0) return FM_OK;
     const int f32 = q->kind == FM_BANK_F32;
-    RowReducePlan pl = f32 ? plan_rowreduce_f32(q->n_pad, t->n_pad, ctx->force_nsplit)
-                           : plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes());
-    if (rc != FM_OK) return rc;
-    int* d_bound = nullptr;
-    if (!f32 && ctx->use_coop && pl.nsplit > 1) {
-        d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
-        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+    RowReducePlan pl;
+    int rc;
+    if (f32) {
+        if ((rc = rowreduce_f32_route(ctx, q, t, 2, &pl)) != FM_OK) return rc;
+    } else {
+        pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes())) != FM_OK) return rc;
+        int* d_bound = nullptr;
+        if (ctx->use_coop && pl.nsplit > 1) {
+            d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (f32) HIP_TRY(ctx, launch_rowreduce_f32(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, ctx->stream));
-    else     HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += nq * t->n;
     hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -776,10 +910,13 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     unsigned long long* d_cnt = (unsigned long long*)(base + o_cnt);
 
     // reverse NN: output rows = train rows, reduced over the query rows
-    RowReducePlan pl = f32 ? plan_rowreduce_f32(t->n_pad, q->n_pad, ctx->force_nsplit)
-                           : plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
-    int* d_bound = (!f32 && ctx->use_coop && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pl.partial_bytes(1)) : nullptr;
+    RowReducePlan pl;
+    int* d_bound = nullptr;
+    if (!f32) {
+        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
+        if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
+    }
 
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
@@ -787,10 +924,13 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     if (nt > 0) {
         if (d_bound)
             HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        if (f32) HIP_TRY(ctx, launch_rowreduce_f32(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, ctx->stream));
-        else     HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        if (f32) {
+            if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
+        } else {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
         hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,

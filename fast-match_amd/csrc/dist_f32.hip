@@ -34,6 +34,7 @@ struct F32Params {
     int          steps_per_split;
     int          ncols_alloc;
     unsigned long long* partial;
+    const int*   run_flag;    // null, or: skip the whole launch unless *run_flag != 0
 };
 
 __device__ __forceinline__ void load_tile_kmajor(const float* __restrict__ rows, int row0, float* __restrict__ img, int tid)
@@ -59,6 +60,10 @@ void rowreduce_f32_kernel(F32Params p)
     __shared__ __attribute__((aligned(16))) float colimg[kDim * kF32Ld];
     __shared__ __attribute__((aligned(16))) float redimg[kDim * kF32Ld];
 
+    if (p.run_flag) {
+        if (*p.run_flag == 0) return;                 // the bf16x3 filter's result stands
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((int*)p.run_flag + 2, 1);
+    }
     const int tid = threadIdx.x;
     const int tn = tid & 15, tm = tid >> 4;
     const int split = blockIdx.x % p.nsplit;
@@ -194,9 +199,10 @@ RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_
 }
 
 hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                                unsigned long long* partial, hipStream_t stream)
+                                unsigned long long* partial, const int* run_flag, hipStream_t stream)
 {
     F32Params p;
+    p.run_flag = run_flag;
     p.col_rows = cols.rowsf;
     p.ncols_pad = (int)cols.n_pad;
     p.red_rows = red.rowsf;

@@ -1,0 +1,511 @@
+// K8 -- bf16x3 MFMA filter + exact float32 rescoring for the float32 route.
+//
+// dist_f32.hip (K5) evaluates OpenCV's float32 L2 chain for every
+// pair on the vector ALUs.  Only K (1 or 2) rows per output row survive the reduce, so this
+// file finds, on the matrix cores, a small superset of the rows that can survive, and then
+// evaluates the exact chain for those rows only.  The result is bit-identical to K5's.
+//
+//   filter_kernel   approximate A(c,m) = |c|^2 + |m|^2 - 2 c.m with every value split into two
+//                   bf16 terms (x = hi + lo + O(2^-18 x)) and  c.m ~= hi.hi + hi.lo + lo.hi
+//                   accumulated in float32 by v_mfma_f32_16x16x32_bf16 (12 per 16 x 16 x 128
+//                   tile).  The accumulator starts at -|m|^2/2, so acc = c.m - |m|^2/2 and a
+//                   LARGER acc is a SMALLER distance, as in rowreduce.hip.  |A - D| <= M for
+//                   the exact chain value D, with M = 2^-12 (|c|^2 + max|m|^2) (worst-case
+//                   bound ~2^-12.5: 2^-15.5 |c||m| from the dropped lo.lo / residual terms,
+//                   384 float32 accumulations of at most 2^-23 relative each, K5's own chain
+//                   error 2^-17; the sqrt-tie slack 2^-21 is inside the remainder).
+//                   Each lane keeps the P = 4 largest acc of its share of the rows, and a row
+//                   is examined only if acc >= (K-th best acc known for this output row) - M;
+//                   that bound is shared between lane groups, waves and blocks through
+//                   bound[n] as in K1.  At the end every lane emits its P entries.
+//   rescore_kernel  one wave per output row: exact chain s = fmaf(v, v, s), k ascending,
+//                   sqrtf, for the emitted rows with acc >= (final K-th best acc) - M; top-K of
+//                   (distance bits, index) -> the same packed keys K5 writes.  A row that
+//                   belongs to the exact top-K has acc >= bound - M; it can be missing from its
+//                   lane's entries only if P rows of that lane do: that case (the lane's P-th
+//                   entry inside the margin) sends the output row to rescan_kernel (a full exact
+//                   scan of that row; up to 256 rows), or, beyond that, the whole call to K5.
+//
+// Layout: rowsb [n_pad][256] bf16 = hi[128] | lo[128] per row (512 B); auxf [n_pad] float32
+// = -|m|^2/2 (padding rows: -3.4e38, below every real accumulator value).
+// Staging: 32 rows (16 KiB) + 128 B aux per step by global_load_lds_dwordx4, double buffered;
+// the 16-byte chunk index of a row is XORed with (row & 15) on the source side so that the
+// ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
+#include "tile_ops.h"
+#include <type_traits>
+
+namespace fm {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float  v4f  __attribute__((ext_vector_type(4)));
+
+constexpr int   kFRowBytes      = 512;
+constexpr int   kFStageRows     = 32;
+constexpr int   kFStageRowBytes = kFStageRows * kFRowBytes;      // 16384
+constexpr int   kFStageBytes    = kFStageRowBytes + 256;         // + aux (128 B used)
+constexpr int   kFP             = 4;                             // entries per lane and output row
+constexpr float kFEmpty         = -3.0e38f;                      // acc of an empty entry
+constexpr int   kFMaxRescan     = 256;                           // output rows rescan_kernel can take
+
+struct FParams {
+    const char*  col_rows;     // bf16 planes of the output rows
+    const float* col_norm;
+    int          ncols;        // real output rows
+    int          ncols_pad;
+    const char*  red_rows;
+    const float* red_aux;
+    int          nred;
+    int          nstages;      // nred_pad / 32
+    int          nsplit;
+    int          nchunks;
+    int          stages_per_split;
+    int          ncols_alloc;
+    float        eps;          // 2^-12
+    float        eps_nm;       // eps * max |m|^2 of the reduced bank
+    unsigned long long* slots; // [nsplit][ncols_alloc][4][kFP]  (acc bits << 32 | row), ~0 = none
+    int*         bound;        // [2][ncols_alloc] ordered-int images: best acc, 2nd best acc (see below)
+    int*         flag;
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// float <-> int with the same order (an involution)
+__device__ __forceinline__ int fmap(float f)
+{
+    const int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float funmap(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+
+template <int NW>
+__device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char* buf, int wave, int lane)
+{
+    const char* src_rows = p.red_rows + (size_t)stage * kFStageRowBytes;
+    constexpr int kPieces = 16 / NW;                   // 1-KiB pieces (2 rows) per wave
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int g   = wave * kPieces + i;
+        const int row = g * 2 + (lane >> 5);
+        const int cp  = lane & 31;                      // chunk position in LDS
+        const int c   = (cp & 16) | ((cp & 15) ^ (row & 15));
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src_rows + row * kFRowBytes + c * 16), LDS_PTR(buf + g * 1024), 16, 0, 0);
+    }
+    if (wave == NW - 1 && lane < 8)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.red_aux + (size_t)stage * kFStageRows + lane * 4),
+                                         LDS_PTR(buf + kFStageRowBytes), 16, 0, 0);
+}
+
+template <int NC, int KTOP, int NW>
+__global__ __launch_bounds__(64 * NW, 2)
+void filter_kernel(FParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes];
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g    = lane >> 4;
+    const int c16  = lane & 15;
+    const int chunk = blockIdx.x % p.nchunks;        // split major, as in rowreduce.hip
+    const int split = blockIdx.x / p.nchunks;
+    const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
+
+    // Stationary operand: NC x 16 output rows, hi and lo planes, 4 K-steps of 32.
+    v8bf bh[NC][4], bl[NC][4];
+    float marg[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int n = cb + 16 * j + c16;
+        const bool ok = n < p.ncols_pad;
+        marg[j] = ok ? fmaf(p.eps, p.col_norm[n], p.eps_nm) : 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v4i h = v4i{0, 0, 0, 0}, l = v4i{0, 0, 0, 0};
+            if (ok) {
+                h = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + (4 * s + g) * 16);
+                l = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + 256 + (4 * s + g) * 16);
+            }
+            bh[j][s] = __builtin_bit_cast(v8bf, h);
+            bl[j][s] = __builtin_bit_cast(v8bf, l);
+        }
+    }
+
+    float ea[NC][kFP];
+    int   ei[NC][kFP];
+    // Shared bounds, exact once every lane is done.  bound1[n] = max over all lanes of their
+    // best acc; every row is published at most once, when it becomes its lane's best.  K = 2:
+    // that publish is a RETURNING fetch-max, and min(value before, lane's best) is the acc of
+    // the worse of two different rows, i.e. a valid bound on the 2nd best; so is a lane's own
+    // 2nd best.  bound2[n] = max of those, which ends as exactly the 2nd best acc overall (the
+    // fetch-maxes are serialised in L2: whichever of the two best rows is published later sees
+    // the other or something better).  The returned value is consumed at the next stage start,
+    // behind the wait that already retires the LDS-DMA prefetch, so the wave never stalls on it.
+    // The lane's threshold thr[] only ever rises.
+    float thr[NC];
+    int   gnext[NC];             // bound of rank K, loaded one stage ahead
+    int   pend[NC];              // K = 2: value returned by this lane's last bound1 publish
+    int   stage_pub = 0;         // K = 2: bit j = a returning publish for row j is in flight
+    int* const bound1 = p.bound;
+    int* const boundk = p.bound + (KTOP == 2 ? p.ncols_alloc : 0);
+    const int kNone = fmap(kFEmpty);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+#pragma unroll
+        for (int i = 0; i < kFP; ++i) { ea[j][i] = kFEmpty; ei[j][i] = -1; }
+        thr[j] = kFEmpty;
+        pend[j] = kNone;
+        gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // K = 2: turn the value returned by the last bound1 publish into a bound2 publish
+    auto settle = [&](int j) {
+        if constexpr (KTOP == 2) {
+            if (pend[j] != kNone) {
+                const float v2 = fminf(funmap(pend[j]), ea[j][0]);
+                __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend[j] = kNone;
+            }
+        }
+    };
+
+    const int st0 = split * p.stages_per_split;
+    const int st1 = min(st0 + p.stages_per_split, p.nstages);
+
+    // per-lane LDS offsets of the A fragments: row c16 (+16 for the second tile), chunk (4s+g) ^ c16
+    int aoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aoff[s] = c16 * kFRowBytes + 16 * ((4 * s + g) ^ c16);
+    const int xoff = kFStageRowBytes + 16 * g;
+
+    if (st0 < st1) f_issue_stage<NW>(p, st0, smem, wave, lane);
+
+    auto stage = [&](auto buf_tag, int st) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        char* buf = smem + BUF * kFStageBytes;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            settle(j);
+            thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
+        }
+        stage_pub = 0;
+        if (st + 1 < st1) f_issue_stage<NW>(p, st + 1, smem + (BUF ^ 1) * kFStageBytes, wave, lane);
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                               // 16-row tiles of the stage
+            const char* rows = buf + t * 16 * kFRowBytes;
+            const v4f ci = *(const v4f*)(buf + xoff + t * 64);
+            v4f acc[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) acc[j] = ci;
+            {
+                v8bf ah[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ah[s] = __builtin_bit_cast(v8bf, *(const v4i*)(rows + aoff[s]));
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl[j][s], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh[j][s], acc[j], 0, 0, 0);
+            }
+            {
+                v8bf al[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) al[s] = __builtin_bit_cast(v8bf, *(const v4i*)(rows + 256 + aoff[s]));
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh[j][s], acc[j], 0, 0, 0);
+            }
+            float tmax[NC];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                tmax[j] = fmaxf(fmaxf(fmaxf(acc[j][0], acc[j][1]), acc[j][2]), acc[j][3]);
+                any |= tmax[j] >= thr[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                const int row0 = (st * 2 + t) * 16 + 4 * g;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
+                        const float a1_before = ea[j][0], a2_before = ea[j][KTOP - 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = (acc[j][r] >= thr[j]) ? acc[j][r] : -INFINITY;
+                            int id = row0 + r;
+#pragma unroll
+                            for (int i = 0; i < kFP; ++i) {
+                                const bool b = a > ea[j][i];
+                                const float ta = b ? ea[j][i] : a;
+                                const int ti = b ? ei[j][i] : id;
+                                ea[j][i] = b ? a : ea[j][i];
+                                ei[j][i] = b ? id : ei[j][i];
+                                a = ta; id = ti;
+                            }
+                        }
+                        thr[j] = fmaxf(thr[j], ea[j][KTOP - 1] - marg[j]);
+                        int* const b1 = bound1 + cb + 16 * j + c16;
+                        if constexpr (KTOP == 1) {
+                            if (ea[j][0] > a1_before)
+                                __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            if (ea[j][0] > a1_before) {
+                                // one returning publish per stage and output row; a second one in
+                                // the same stage (rare) only feeds bound1, which can leave bound2
+                                // a little low -- still a valid bound
+                                if (!(stage_pub & (1 << j))) {
+                                    pend[j] = __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    stage_pub |= 1 << j;
+                                } else {
+                                    __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                            if (ea[j][1] > a2_before)
+                                __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(ea[j][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    for (int st = st0; st < st1; st += 2) {
+        stage(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+    }
+
+    // emit every entry; rescore_kernel filters them against the final bound
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        settle(j);
+        const int n = cb + 16 * j + c16;
+        unsigned long long* out = p.slots + (((size_t)split * p.ncols_alloc + n) * 4 + g) * kFP;
+#pragma unroll
+        for (int i = 0; i < kFP; ++i) {
+            const bool v = ei[j][i] >= 0 && ei[j][i] < p.nred && n < p.ncols;
+            out[i] = v ? (((unsigned long long)__float_as_uint(ea[j][i]) << 32) | (unsigned)ei[j][i]) : ~0ull;
+        }
+    }
+}
+
+// ---- exact rescoring ------------------------------------------------------------------------
+struct RParams {
+    const unsigned long long* slots;
+    int          nsplit;
+    int          ncols_alloc;     // of the slots / bound arrays
+    const int*   bound;           // the K-th best bound array (bound1 for K = 1, bound2 for K = 2)
+    const float* col_rowsf;
+    const float* col_norm;
+    const float* red_rowsf;
+    float        eps, eps_nm;
+    int          ncols;           // real output rows
+    unsigned long long* partial;  // split 0 of the caller's layout: [n][KTOP]
+    int*         flag;            // [0] raised when more than kFMaxRescan output rows need a full scan,
+                                  // [1] number of such rows, [3] total (diagnostic), [4 ..] their indices
+};
+
+template <int KTOP>
+__global__ __launch_bounds__(256)
+void rescore_kernel(RParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.ncols) return;
+    const float thr = funmap(p.bound[n]) - fmaf(p.eps, p.col_norm[n], p.eps_nm);
+    const float4* cp = (const float4*)(p.col_rowsf + (size_t)n * kDim);
+    unsigned long long k0 = ~0ull, k1 = ~0ull;
+    bool incomplete = false;
+    const int nslots = p.nsplit * 4 * kFP;
+    for (int s0 = 0; s0 < nslots; s0 += 64) {
+        const int s = s0 + lane;
+        unsigned long long slot = ~0ull;
+        if (s < nslots) slot = p.slots[((size_t)(s >> 4) * p.ncols_alloc + n) * (4 * kFP) + (s & 15)];
+        const bool valid = slot != ~0ull && __uint_as_float((unsigned)(slot >> 32)) >= thr;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+        // a lane's last (smallest) entry inside the margin: rows it dropped may be inside too
+        incomplete |= valid && (s & (kFP - 1)) == kFP - 1;
+        if (valid) {
+            const unsigned idx = (unsigned)slot;
+            const float4* rp = (const float4*)(p.red_rowsf + (size_t)idx * kDim);
+            float sum = 0.f;
+#pragma unroll 8
+            for (int k4 = 0; k4 < kDim / 4; ++k4) {
+                const float4 a = cp[k4];
+                const float4 b = rp[k4];
+                float v;
+                v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
+                v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
+                v = a.z - b.z; sum = __builtin_fmaf(v, v, sum);
+                v = a.w - b.w; sum = __builtin_fmaf(v, v, sum);
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sqrtf(sum)) << 32) | idx;
+            if (key < k0) { k1 = k0; k0 = key; }
+            else if (key < k1) { k1 = key; }
+        }
+    }
+#pragma unroll
+    for (int mask = 1; mask < 64; mask <<= 1) {
+        const unsigned long long o0 = __shfl_xor(k0, mask), o1 = __shfl_xor(k1, mask);
+        const unsigned long long lo = k0 < o0 ? k0 : o0, hi = k0 < o0 ? o0 : k0;
+        const unsigned long long m1 = k1 < o1 ? k1 : o1;
+        k0 = lo;
+        k1 = hi < m1 ? hi : m1;
+    }
+    const bool redo = __builtin_amdgcn_ballot_w64(incomplete) != 0ull;
+    if (lane == 0) {
+        p.partial[(size_t)n * KTOP] = k0;
+        if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = k1;
+        if (redo) {
+            // this output row gets a full exact scan (rescan_kernel); too many of them: K5 instead
+            const int pos = atomicAdd(p.flag + 1, 1);
+            atomicAdd(p.flag + 3, 1);
+            if (pos < kFMaxRescan) p.flag[4 + pos] = n;
+            else atomicOr(p.flag, 1);
+        }
+    }
+}
+
+// Full exact scan for the few output rows whose candidate lists could be incomplete: one
+// workgroup per such row, thread t takes rows t, t + 256, ... of the reduced bank.
+template <int KTOP>
+__global__ __launch_bounds__(256)
+void rescan_kernel(RParams p, int nred)
+{
+    __shared__ unsigned long long sk[256 * 2];
+    const int cnt = min(p.flag[1], kFMaxRescan);
+    if ((int)blockIdx.x >= cnt || p.flag[0] != 0) return;
+    const int n = p.flag[4 + blockIdx.x];
+    const float4* cp = (const float4*)(p.col_rowsf + (size_t)n * kDim);
+    unsigned long long k0 = ~0ull, k1 = ~0ull;
+    for (int m = threadIdx.x; m < nred; m += 256) {
+        const float4* rp = (const float4*)(p.red_rowsf + (size_t)m * kDim);
+        float sum = 0.f;
+#pragma unroll 8
+        for (int k4 = 0; k4 < kDim / 4; ++k4) {
+            const float4 a = cp[k4];
+            const float4 b = rp[k4];
+            float v;
+            v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
+            v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
+            v = a.z - b.z; sum = __builtin_fmaf(v, v, sum);
+            v = a.w - b.w; sum = __builtin_fmaf(v, v, sum);
+        }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(sqrtf(sum)) << 32) | (unsigned)m;
+        if (key < k0) { k1 = k0; k0 = key; }
+        else if (key < k1) { k1 = key; }
+    }
+    sk[2 * threadIdx.x] = k0;
+    sk[2 * threadIdx.x + 1] = k1;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const unsigned long long a0 = sk[2 * threadIdx.x], a1 = sk[2 * threadIdx.x + 1];
+            const unsigned long long o0 = sk[2 * (threadIdx.x + w)], o1 = sk[2 * (threadIdx.x + w) + 1];
+            const unsigned long long lo = a0 < o0 ? a0 : o0, hi = a0 < o0 ? o0 : a0;
+            const unsigned long long m1 = a1 < o1 ? a1 : o1;
+            sk[2 * threadIdx.x] = lo;
+            sk[2 * threadIdx.x + 1] = hi < m1 ? hi : m1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.partial[(size_t)n * KTOP] = sk[0];
+        if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = sk[1];
+    }
+}
+
+FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
+{
+    FilterPlan pl;
+    pl.nw = (ncols_pad >= 8192) ? 8 : 4;
+    const int cb = 16 * 4 * pl.nw;
+    pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
+    if (pl.nchunks < 1) pl.nchunks = 1;
+    pl.ncols_alloc = pl.nchunks * cb;
+    const int64_t nstages = nred_pad / kFStageRows;
+    int64_t want = 4 * 256 * (8 / pl.nw);            // ~4 rounds of one (nw = 8) or two workgroups per CU
+    int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
+    if (nsplit > nstages / 16) nsplit = nstages / 16;   // >= 512 rows per split
+    if (nsplit < 1) nsplit = 1;
+    int64_t per = (nstages + nsplit - 1) / nsplit;
+    if (per < 1) per = 1;
+    nsplit = (nstages + per - 1) / per;
+    if (nsplit < 1) nsplit = 1;
+    pl.nsplit = (int)nsplit;
+    pl.stages_per_split = (int)per;
+    return pl;
+}
+
+int filter_empty_bound()
+{
+    union { float f; int i; } u;
+    u.f = kFEmpty;
+    return u.i ^ ((u.i >> 31) & 0x7fffffff);
+}
+
+hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& pl,
+                         unsigned long long* slots, int* bound, int* flag,
+                         unsigned long long* partial, hipStream_t stream)
+{
+    const float eps = 1.0f / 4096.0f;
+    FParams p;
+    p.col_rows = (const char*)cols.rowsb;
+    p.col_norm = cols.normf;
+    p.ncols = (int)cols.n;
+    p.ncols_pad = (int)cols.n_pad;
+    p.red_rows = (const char*)red.rowsb;
+    p.red_aux = red.auxf;
+    p.nred = (int)red.n;
+    p.nstages = (int)(red.n_pad / kFStageRows);
+    p.nsplit = pl.nsplit;
+    p.nchunks = pl.nchunks;
+    p.stages_per_split = pl.stages_per_split;
+    p.ncols_alloc = pl.ncols_alloc;
+    p.eps = eps;
+    p.eps_nm = eps * red.nm_max;
+    p.slots = slots;
+    p.bound = bound;
+    p.flag = flag;
+    const int grid = pl.nchunks * pl.nsplit;
+    if (pl.nw == 8) {
+        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<4, 1, 8>), dim3(grid), dim3(512), 0, stream, p);
+        else           hipLaunchKernelGGL((filter_kernel<4, 2, 8>), dim3(grid), dim3(512), 0, stream, p);
+    } else {
+        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<4, 1, 4>), dim3(grid), dim3(256), 0, stream, p);
+        else           hipLaunchKernelGGL((filter_kernel<4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    RParams r;
+    r.slots = slots;
+    r.nsplit = pl.nsplit;
+    r.ncols_alloc = pl.ncols_alloc;
+    r.bound = (ktop == 2) ? bound + pl.ncols_alloc : bound;
+    r.col_rowsf = cols.rowsf;
+    r.col_norm = cols.normf;
+    r.red_rowsf = red.rowsf;
+    r.eps = eps;
+    r.eps_nm = p.eps_nm;
+    r.ncols = (int)cols.n;
+    r.partial = partial;
+    r.flag = flag;
+    const int rgrid = (int)((cols.n + 3) / 4);
+    if (rgrid > 0) {
+        if (ktop == 1) hipLaunchKernelGGL((rescore_kernel<1>), dim3(rgrid), dim3(256), 0, stream, r);
+        else           hipLaunchKernelGGL((rescore_kernel<2>), dim3(rgrid), dim3(256), 0, stream, r);
+        if (ktop == 1) hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
+        else           hipLaunchKernelGGL((rescan_kernel<2>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fm
