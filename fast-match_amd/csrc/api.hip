@@ -714,7 +714,7 @@ static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const cha
     if (!ctx) return fail(nullptr, FM_EINVAL, std::string(who) + ": ctx is NULL");
     if (!q || !t) return fail(ctx, FM_EINVAL, std::string(who) + ": bank is NULL");
     if (q->dim != t->dim) return fail(ctx, FM_EINVAL, std::string(who) + ": query/train dim mismatch");
-    if (q->kind != t->kind)
+    if (q->kind != t->kind && q->n > 0 && t->n > 0)      // (an empty bank has no kind of its own)
         return fail(ctx, FM_EINVAL, std::string(who) + ": query/train kind mismatch (one bank is integer-valued, the other is not)");
     return FM_OK;
 }
@@ -764,6 +764,12 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     const int64_t nq = q->n;
     if (nq == 0) return FM_OK;
     const int f32 = q->kind == FM_BANK_F32;
+    if (t->n == 0) {                                     // no train rows: every slot is (-1, +inf)
+        hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)nullptr, 0, 0, nq, d_idx, d_dist, f32);
+        HIP_TRY(ctx, hipGetLastError());
+        return FM_OK;
+    }
     RowReducePlan pl;
     int rc;
     if (f32) {

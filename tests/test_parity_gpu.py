@@ -309,6 +309,103 @@ def test_f32_route_parity(ctx, nq, nt):
         assert _eq(t2, otidx) and _eq(ratio[m], orat) and np.array_equal(passed[m], opass)
 
 
+# ---- K8: bf16x3 MFMA filter + exact rescoring, forced on for every size --------------------
+def _f32_kind(kind, nq, nt, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "rootsift":                                 # unit-norm rows, planted near twins
+        Q = synth.synth_sift(nq, rng).astype(np.float32)
+        T = synth.synth_sift(nt, rng).astype(np.float32)
+        m = min(nq, nt) // 2
+        T[:m] = np.abs(Q[:m] + rng.normal(0, 6, size=(m, 128)).astype(np.float32))
+        Q = np.sqrt(Q / np.maximum(Q.sum(1, keepdims=True), 1)).astype(np.float32)
+        T = np.sqrt(T / np.maximum(T.sum(1, keepdims=True), 1)).astype(np.float32)
+    elif kind == "gauss":
+        Q = rng.normal(0, 1, size=(nq, 128)).astype(np.float32)
+        T = rng.normal(0, 1, size=(nt, 128)).astype(np.float32)
+    elif kind == "offset":                                 # huge norms, tiny distances: everything is inside the margin
+        Q = (1000 + rng.normal(0, 1, size=(nq, 128))).astype(np.float32)
+        T = (1000 + rng.normal(0, 1, size=(nt, 128))).astype(np.float32)
+    elif kind == "neartie":                                # a few rows per query within a hair of each other
+        T = rng.normal(0, 1, size=(nt, 128)).astype(np.float32)
+        Q = rng.normal(0, 1, size=(nq, 128)).astype(np.float32)
+        for i in range(0, min(nq, 40)):
+            for k in range(6):                             # six train rows at almost the same distance from Q[i]
+                T[(37 * i + 4 * k) % nt] = Q[i] + np.float32(0.05) * np.roll(np.eye(128, dtype=np.float32)[0], k)
+    elif kind == "scaled":
+        Q = (rng.normal(0, 1, size=(nq, 128)) * 1e-4).astype(np.float32)
+        T = (rng.normal(0, 1, size=(nt, 128)) * 1e-4).astype(np.float32)
+    else:                                                  # "dup": eight distinct rows, heavy exact and near ties
+        base = rng.normal(0, 1, size=(8, 128)).astype(np.float32)
+        Q = (base[rng.integers(0, 8, nq)] + rng.normal(0, 1e-4, size=(nq, 128))).astype(np.float32)
+        T = (base[rng.integers(0, 8, nt)] + rng.normal(0, 1e-4, size=(nt, 128))).astype(np.float32)
+    return Q, T
+
+
+@pytest.fixture
+def filter_ctx(monkeypatch):
+    import fastmatch_amd
+    monkeypatch.setenv("FM_F32_FILTER", "2")               # filter every float32 call, whatever its size
+    c = fastmatch_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind,nq,nt", [
+    ("gauss", 1, 1), ("gauss", 3, 2), ("gauss", 63, 65), ("gauss", 700, 450), ("gauss", 5000, 9000),
+    ("rootsift", 130, 257), ("rootsift", 3000, 4100), ("rootsift", 9000, 20000),
+    ("neartie", 600, 3000), ("offset", 500, 800), ("scaled", 400, 1500), ("dup", 900, 1300)])
+def test_f32_filter_route_parity(filter_ctx, kind, nq, nt):
+    """K8 gives the bits K5 and the oracle give, whichever of its three endings a call takes
+    (rescoring alone, per-row rescan, whole-call redo by K5)."""
+    c = filter_ctx
+    Q, T = _f32_kind(kind, nq, nt, 1000 + nq + nt)
+    qb, tb = c.bank(Q), c.bank(T)
+    assert qb.kind == _ffi.FM_BANK_F32
+    idx, dist = c.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
+    assert _eq(idx, oidx) and _eq(dist, odist)
+    tidx, xd = c.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T, order=1)
+    assert _eq(tidx, otidx) and _eq(xd, oxd)
+    sd = c.self_dist(qb)
+    assert _eq(sd, oracle.self_dist(Q, order=1))
+    launches, redone = c.f32_filter_stats()
+    assert launches >= 3
+    if kind in ("gauss", "rootsift"):
+        assert redone == 0                                 # well separated data never needs K5
+    if kind in ("dup", "offset") and nq * nt > 100000:
+        assert redone > 0                                  # everything inside the margin: K5 redoes the call
+
+
+def test_f32_filter_handles_dim_below_128_and_empty_banks(filter_ctx):
+    c = filter_ctx
+    rng = np.random.default_rng(5)
+    Q, T = rng.normal(0, 1, (300, 64)).astype(np.float32), rng.normal(0, 1, (500, 64)).astype(np.float32)
+    idx, dist = c.knn2(c.bank(Q), c.bank(T))
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
+    assert _eq(idx, oidx) and _eq(dist, odist)
+    E = c.bank(np.zeros((0, 64), np.float32))               # an empty bank pairs with either kind
+    tidx, d = c.xcheck1(c.bank(Q), E)
+    assert (tidx == -1).all() and np.isinf(d).all()
+    idx, dist = c.knn2(c.bank(Q), E)
+    assert (idx == -1).all() and np.isinf(dist).all()
+    tidx, d = c.xcheck1(E, c.bank(T))
+    assert tidx.shape == (0,)
+
+
+def test_f32_filter_is_skipped_outside_its_range(filter_ctx):
+    """Non-finite norms or magnitudes outside [1e-30, 1e30] keep the bank on K5."""
+    c = filter_ctx
+    rng = np.random.default_rng(6)
+    Q = (rng.normal(0, 1, (200, 128)) * 1e18).astype(np.float32)
+    T = (rng.normal(0, 1, (300, 128)) * 1e18).astype(np.float32)
+    before = c.f32_filter_stats()[0]
+    idx, dist = c.knn2(c.bank(Q), c.bank(T))
+    assert c.f32_filter_stats()[0] == before
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
+    assert _eq(idx, oidx) and _eq(dist, odist)
+
+
 def test_f32_route_close_to_opencv_order(ctx):
     # OpenCV's own accumulation order (unrolled by 4) differs from the fixed fma chain only
     # in rounding: distances agree within 1 ulp-scale relative error, indices almost always.
