@@ -36,10 +36,14 @@ struct fm_ctx {
     int force_nb = 0, force_nsplit = 0, force_nw = 0;
     bool use_glds = true;
     bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
-    int  f32_filter = 1;    // float32 route: 0 = K5 only, 1 = bf16x3 filter for large calls, 2 = always
-    int* d_counters = nullptr;   // device words of the bf16x3 filter (layout: fm_internal.h, launch_filter)
+    int  f32_filter = 1;    // float32 route: 0 = K5 only, 1 = fp16 filter for large calls, 2 = always
+    int* d_counters = nullptr;   // device words of the fp16 filter (layout: fm_internal.h, launch_filter)
     int64_t filter_launches = 0;
     unsigned long long* h_scratch = nullptr;   // pinned host words the kernels can write (counts)
+    // page-locked staging for results that go to pageable caller memory (d2h below)
+    char*  h_stage = nullptr; size_t h_stage_bytes = 0, h_stage_used = 0;
+    struct StagedCopy { void* dst; size_t off, bytes; };
+    std::vector<StagedCopy> staged;
     fm_stats stats{};
     bool kernel_timed = false;
     int64_t pending_pairs = 0;
@@ -154,20 +158,30 @@ __global__ void bank_copy_f32_kernel(const float* __restrict__ src, int64_t n, i
     dst[i] = (row < n && k < dim) ? src[row * dim + k] : 0.f;
 }
 
-// bf16 planes, norms and accumulator inits of a float32 bank for the bf16x3 filter
-// (filter_bf16.hip).  16 lanes per row, 8 dims per lane; x = hi + lo + O(2^-18 x) with both
-// terms rounded to nearest even.  stat[0] = max |row|^2 (float bits), stat[1] |= 1 if a norm
-// is not finite.
-__device__ __forceinline__ unsigned bf16_rne(float f)
+// fp16 rows, norms and accumulator inits of a float32 bank for the fp16 filter (filter_f16.hip).
+// Pass 1: stat[0] = max |value| (float bits), stat[1] |= 1 if a value is not finite.
+__global__ __launch_bounds__(256)
+void bank_absmax_kernel(const float* __restrict__ rowsf, int64_t total, int* __restrict__ stat)
 {
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    float m = 0.f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float v = fabsf(rowsf[i]);
+        bad |= !(v <= 3.0e38f);
+        m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int mask = 1; mask < 64; mask <<= 1) m = fmaxf(m, __shfl_xor(m, mask));
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) { if ((threadIdx.x & 63) == 0) atomicOr(stat + 1, 1); }
+    else if ((threadIdx.x & 63) == 0) atomicMax(stat, (int)__float_as_uint(m));     // m >= 0: bit order = value order
 }
 
+// Pass 2: 16 lanes per row, 8 dims per lane; rows scaled by 2^k (exact) and rounded to fp16
+// (nearest even); norms of the scaled rows in float64 -> float32.  stat[0] = max norm.
 __global__ __launch_bounds__(256)
-void bank_prep_bf16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n_pad,
-                           uint16_t* __restrict__ rowsb, float* __restrict__ normf,
-                           float* __restrict__ auxf, int* __restrict__ stat)
+void bank_prep_f16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n_pad, int k,
+                          uint16_t* __restrict__ rowsh, float* __restrict__ normf,
+                          float* __restrict__ auxf, int* __restrict__ stat)
 {
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c = threadIdx.x & 15;
@@ -175,19 +189,17 @@ void bank_prep_bf16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n
     const float4 v0 = *(const float4*)(rowsf + row * kDim + 8 * c);
     const float4 v1 = *(const float4*)(rowsf + row * kDim + 8 * c + 4);
     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned h[8], l[8];
+    unsigned h[8];
     double ss = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        h[i] = bf16_rne(v[i]);
-        const float rest = v[i] - __uint_as_float(h[i] << 16);
-        l[i] = bf16_rne(rest);
-        ss += (double)v[i] * (double)v[i];
+        const float x = ldexpf(v[i], k);
+        const _Float16 hx = (_Float16)x;
+        h[i] = (unsigned)__builtin_bit_cast(unsigned short, hx);
+        ss += (double)x * (double)x;
     }
-    *(uint4*)(rowsb + row * 256 + 8 * c) =
+    *(uint4*)(rowsh + row * kDim + 8 * c) =
         make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    *(uint4*)(rowsb + row * 256 + 128 + 8 * c) =
-        make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
     ss += __shfl_xor(ss, 4);
@@ -197,8 +209,7 @@ void bank_prep_bf16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n
         if (row < n) {
             normf[row] = nm;
             auxf[row] = -0.5f * nm;
-            if (!(nm <= 3.0e38f)) atomicOr(stat + 1, 1);            // inf or NaN
-            else atomicMax(stat, (int)__float_as_uint(nm));          // nm >= 0: bit order = value order
+            atomicMax(stat, (int)__float_as_uint(nm));
         } else {
             normf[row] = 0.f;
             auxf[row] = -3.4e38f;
@@ -460,6 +471,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (ctx->ws_out) (void)hipFree(ctx->ws_out);
     if (ctx->ws_in) (void)hipFree(ctx->ws_in);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev_call0) (void)hipEventDestroy(ctx->ev_call0);
     if (ctx->ev_call1) (void)hipEventDestroy(ctx->ev_call1);
@@ -544,9 +556,39 @@ static void* pinned_device_alias(const void* host)
     return at.devicePointer;
 }
 
+// Device -> caller memory on the context's stream.  A copy into pageable memory makes the
+// runtime pin the destination pages for the transfer (milliseconds for results of ~100 KB and
+// up), so such results land in the context's own page-locked staging buffer and are moved to
+// the caller by CallScope::finish() after the call's single synchronisation.
+static hipError_t d2h(fm_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    if (bytes >= 4096 && bytes <= ((size_t)256 << 20) && !pinned_device_alias(dst)) {
+        size_t off = (ctx->h_stage_used + 63) & ~(size_t)63;
+        if (off + bytes > ctx->h_stage_bytes && ctx->staged.empty()) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr;
+            ctx->h_stage_bytes = 0;
+            const size_t want = bytes * 3 + (1 << 20);
+            if (hipHostMalloc((void**)&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
+            else { (void)hipGetLastError(); ctx->h_stage = nullptr; }
+            off = 0;
+        }
+        if (ctx->h_stage && off + bytes <= ctx->h_stage_bytes) {
+            hipError_t e = hipMemcpyAsync(ctx->h_stage + off, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) return e;
+            ctx->staged.push_back({dst, off, bytes});
+            ctx->h_stage_used = off + bytes;
+            return hipSuccess;
+        }
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+
 // Brackets one API call: events for total time, stats accounting after the final sync.
 struct CallScope {
     fm_ctx* ctx;
+    ~CallScope() { ctx->staged.clear(); ctx->h_stage_used = 0; }
     explicit CallScope(fm_ctx* c) : ctx(c)
     {
         ctx->kernel_timed = false;
@@ -557,6 +599,9 @@ struct CallScope {
     {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_call1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
+        ctx->staged.clear();
+        ctx->h_stage_used = 0;
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_call0, ctx->ev_call1));
         ctx->stats.total_ms += ms;
@@ -581,12 +626,12 @@ static void bank_free(Bank* b)
     if (b->norm) (void)hipFree(b->norm);
     if (b->aux) (void)hipFree(b->aux);
     if (b->rowsf) (void)hipFree(b->rowsf);
-    if (b->rowsb) (void)hipFree(b->rowsb);
+    if (b->rowsh) (void)hipFree(b->rowsh);
     if (b->normf) (void)hipFree(b->normf);
     if (b->auxf) (void)hipFree(b->auxf);
     if (b->selfdist) (void)hipFree(b->selfdist);
     b->rows8 = nullptr; b->norm = nullptr; b->aux = nullptr; b->rowsf = nullptr; b->selfdist = nullptr;
-    b->rowsb = nullptr; b->normf = nullptr; b->auxf = nullptr;
+    b->rowsh = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
 
 static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out)
@@ -648,20 +693,32 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
         hipLaunchKernelGGL(bank_copy_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float*)ctx->ws_in, n, dim, b->rowsf, b->n_pad);
         BTRY(hipGetLastError());
-        // planes for the bf16x3 filter; the filter is used only while every |row|^2 stays in a
-        // range where its error bound holds without overflow or underflow
-        BTRY(hipMalloc((void**)&b->rowsb, (size_t)b->n_pad * 512));
+        // rows for the fp16 filter, scaled by the power of two that puts the largest magnitude
+        // of the bank in [2^13, 2^14)
+        BTRY(hipMalloc((void**)&b->rowsh, (size_t)b->n_pad * kDim * 2));
         BTRY(hipMalloc((void**)&b->normf, (size_t)b->n_pad * 4));
         BTRY(hipMalloc((void**)&b->auxf, (size_t)b->n_pad * 4));
         BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(bank_prep_bf16_kernel, dim3((unsigned)(b->n_pad / 16)), dim3(256), 0, ctx->stream,
-                           (const float*)b->rowsf, n, b->n_pad, b->rowsb, b->normf, b->auxf, d_flag);
+        hipLaunchKernelGGL(bank_absmax_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const float*)b->rowsf, tot, d_flag);
         BTRY(hipGetLastError());
         int stat[2] = {0, 0};
         BTRY(hipMemcpyAsync(stat, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
         BTRY(hipStreamSynchronize(ctx->stream));
-        memcpy(&b->nm_max, &stat[0], 4);
-        b->filt_ok = stat[1] == 0 && b->nm_max <= 1.0e30f && (b->nm_max >= 1.0e-30f || n == 0);
+        float vmax = 0.f;
+        memcpy(&vmax, &stat[0], 4);
+        b->filt_ok = stat[1] == 0;
+        if (b->filt_ok) {
+            int ex = 0;
+            if (vmax > 0.f) (void)frexpf(vmax, &ex);         // vmax = m 2^ex, m in [0.5, 1)
+            b->kscale = vmax > 0.f ? 14 - ex : 0;
+            BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(bank_prep_f16_kernel, dim3((unsigned)(b->n_pad / 16)), dim3(256), 0, ctx->stream,
+                               (const float*)b->rowsf, n, b->n_pad, b->kscale, b->rowsh, b->normf, b->auxf, d_flag);
+            BTRY(hipGetLastError());
+            BTRY(hipMemcpyAsync(stat, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+            BTRY(hipStreamSynchronize(ctx->stream));
+            memcpy(&b->nm_max, &stat[0], 4);
+        }
     }
 #undef BTRY
     *out = b;
@@ -720,14 +777,14 @@ static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const cha
 }
 
 // ---------------------------------------------------------------------------------------
-// float32 route: K5 alone, or the bf16x3 filter (K8) with K5 as its conditional fallback
+// float32 route: K5 alone, or the fp16 filter (K8) with K5 as its conditional fallback
 // ---------------------------------------------------------------------------------------
 // Leaves the packed keys in ws_partial in `pl`'s layout (K5's plan) either way.
 static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* red, int ktop, RowReducePlan* pl_out)
 {
     const RowReducePlan pl = plan_rowreduce_f32(cols->n_pad, red->n_pad, ctx->force_nsplit);
     *pl_out = pl;
-    const bool filter = ctx->f32_filter != 0 && cols->filt_ok && red->filt_ok && cols->rowsb && red->rowsb &&
+    const bool filter = ctx->f32_filter != 0 && filter_usable(*cols, *red) &&
                         (ctx->f32_filter >= 2 || (double)cols->n * (double)red->n >= 4.0e6);
     const size_t part = (pl.partial_bytes(ktop) + 255) & ~(size_t)255;
     if (!filter) {
@@ -807,8 +864,8 @@ extern "C" int fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     float* d_dist = (float*)((char*)ctx->ws_out + (size_t)nq * 8);
     CallScope cs(ctx);
     if ((rc = knn2_device(ctx, q, t, d_idx, d_dist)) != FM_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, idx, d_idx, (size_t)nq * 8));
+    HIP_TRY(ctx, d2h(ctx, dist, d_dist, (size_t)nq * 8));
     return cs.finish();
 }
 
@@ -848,10 +905,10 @@ extern "C" int fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t m = (size_t)((int64_t)cnt < ccap ? (int64_t)cnt : ccap);
     if (m) {
-        HIP_TRY(ctx, hipMemcpyAsync(qidx, b + o_cq, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(tidx, b + o_ct, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(dist, b + o_cd, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ratio, b + o_cr, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, d2h(ctx, qidx, b + o_cq, m * 4));
+        HIP_TRY(ctx, d2h(ctx, tidx, b + o_ct, m * 4));
+        HIP_TRY(ctx, d2h(ctx, dist, b + o_cd, m * 4));
+        HIP_TRY(ctx, d2h(ctx, ratio, b + o_cr, m * 8));
     }
     rc = cs.finish();
     if (rc != FM_OK) return rc;
@@ -876,7 +933,7 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
     hipLaunchKernelGGL(selfdist_from_knn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const float*)d_dist, n, d_sd);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(selfdist, d_sd, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, selfdist, d_sd, (size_t)n * 8));
     return cs.finish();
 }
 
@@ -977,21 +1034,21 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const size_t m = (size_t)((int64_t)cnt < ccap ? (int64_t)cnt : ccap);
         if (m) {
-            HIP_TRY(ctx, hipMemcpyAsync(c_qidx, base + o_cq, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(tidx, base + o_ct, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(dist, base + o_cd, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ratio, base + o_cr, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, d2h(ctx, c_qidx, base + o_cq, m * 4));
+            HIP_TRY(ctx, d2h(ctx, tidx, base + o_ct, m * 4));
+            HIP_TRY(ctx, d2h(ctx, dist, base + o_cd, m * 4));
+            HIP_TRY(ctx, d2h(ctx, ratio, base + o_cr, m * 8));
         }
         rc = cs.finish();
         if (rc != FM_OK) return rc;
         if (n_pass) *n_pass = (int64_t)cnt;
         return FM_OK;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(tidx, d_tidx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, tidx, d_tidx, (size_t)nq * 4));
+    HIP_TRY(ctx, d2h(ctx, dist, d_dist, (size_t)nq * 4));
     if (with_ratio) {
-        if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, d_ratio, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (pass) HIP_TRY(ctx, hipMemcpyAsync(pass, d_pass, (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+        if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, d_ratio, (size_t)nq * 8));
+        if (pass) HIP_TRY(ctx, d2h(ctx, pass, d_pass, (size_t)nq));
         HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     rc = cs.finish();
@@ -1049,8 +1106,8 @@ extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* sel
                        (double*)(ob + o_ratio), (uint8_t*)(ob + o_pass), (unsigned long long*)(ob + o_cnt));
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long cnt = 0;
-    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ob + o_ratio, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (pass) HIP_TRY(ctx, hipMemcpyAsync(pass, ob + o_pass, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ob + o_ratio, (size_t)n * 8));
+    if (pass) HIP_TRY(ctx, d2h(ctx, pass, ob + o_pass, (size_t)n));
     HIP_TRY(ctx, hipMemcpyAsync(&cnt, ob + o_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     rc = cs.finish();
     if (rc != FM_OK) return rc;
@@ -1101,9 +1158,9 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += pairs;
-    HIP_TRY(ctx, hipMemcpyAsync(tidx, ob + o_tidx, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(dist, ob + o_dist, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ob + o_ratio, (size_t)tot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, d2h(ctx, tidx, ob + o_tidx, (size_t)tot * 4));
+    HIP_TRY(ctx, d2h(ctx, dist, ob + o_dist, (size_t)tot * 4));
+    if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ob + o_ratio, (size_t)tot * 8));
     return cs.finish();
 }
 
@@ -1283,9 +1340,12 @@ extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int3
     if (n < 0 || n > ex->dev.match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch: n out of range");
     if (n == 0) return FM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (index) HIP_TRY(ctx, hipMemcpyAsync(index, ex->dev.m_index, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (positions) HIP_TRY(ctx, hipMemcpyAsync(positions, ex->dev.m_pos, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, ex->dev.m_ratio, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (index) HIP_TRY(ctx, d2h(ctx, index, ex->dev.m_index, (size_t)n * 4));
+    if (positions) HIP_TRY(ctx, d2h(ctx, positions, ex->dev.m_pos, (size_t)n * 32));
+    if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ex->dev.m_ratio, (size_t)n * 8));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
+    ctx->staged.clear();
+    ctx->h_stage_used = 0;
     return FM_OK;
 }

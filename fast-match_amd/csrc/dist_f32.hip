@@ -61,7 +61,7 @@ void rowreduce_f32_kernel(F32Params p)
     __shared__ __attribute__((aligned(16))) float redimg[kDim * kF32Ld];
 
     if (p.run_flag) {
-        if (*p.run_flag == 0) return;                 // the bf16x3 filter's result stands
+        if (*p.run_flag == 0) return;                 // the fp16 filter's result stands
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((int*)p.run_flag + 2, 1);
     }
     const int tid = threadIdx.x;

@@ -1,24 +1,27 @@
-// K8 -- bf16x3 MFMA filter + exact float32 rescoring for the float32 route.
+// K8 -- fp16 MFMA filter + exact float32 rescoring for the float32 route.
 //
 // dist_f32.hip (K5) evaluates OpenCV's float32 L2 chain for every
 // pair on the vector ALUs.  Only K (1 or 2) rows per output row survive the reduce, so this
 // file finds, on the matrix cores, a small superset of the rows that can survive, and then
 // evaluates the exact chain for those rows only.  The result is bit-identical to K5's.
 //
-//   filter_kernel   approximate A(c,m) = |c|^2 + |m|^2 - 2 c.m with every value split into two
-//                   bf16 terms (x = hi + lo + O(2^-18 x)) and  c.m ~= hi.hi + hi.lo + lo.hi
-//                   accumulated in float32 by v_mfma_f32_16x16x32_bf16 (12 per 16 x 16 x 128
-//                   tile).  The accumulator starts at -|m|^2/2, so acc = c.m - |m|^2/2 and a
-//                   LARGER acc is a SMALLER distance, as in rowreduce.hip.  |A - D| <= M for
-//                   the exact chain value D, with M = 2^-12 (|c|^2 + max|m|^2) (worst-case
-//                   bound ~2^-12.5: 2^-15.5 |c||m| from the dropped lo.lo / residual terms,
-//                   384 float32 accumulations of at most 2^-23 relative each, K5's own chain
-//                   error 2^-17; the sqrt-tie slack 2^-21 is inside the remainder).
+//   filter_kernel   approximate A(c,m) = |c|^2 + |m|^2 - 2 c.m with c.m computed by
+//                   v_mfma_f32_16x16x32_f16 on the rows rounded to fp16 (4 per 16 x 16 x 128
+//                   tile, float32 accumulate).  Every bank is stored scaled by its own power
+//                   of two 2^k so that its largest magnitude lies in [2^13, 2^14): exact, and
+//                   it keeps fp16 away from overflow and (relative to the bank) from underflow.
+//                   The accumulator starts at -|m|^2/2, so acc = c.m - |m|^2/2 (in units of
+//                   2^(kc+km)) and a LARGER acc is a SMALLER distance, as in rowreduce.hip.
+//                   |A - D| <= M for the exact chain value D, with M = 1.1 * 2^-10 *
+//                   (|c|^2 + max|m|^2): fp16 rounding (unit roundoff 2^-11) of both factors
+//                   gives <= 2.0005 * 2^-11 |c||m| <= 2^-11 (|c|^2 + |m|^2) on c.m, twice that
+//                   on A; the float32 accumulation, K5's own chain error (2^-17), flushed
+//                   fp16 subnormals (2^-20) and the sqrt-tie slack (2^-21) fit in the 10 %.
 //                   Each lane keeps the P = 4 largest acc of its share of the rows, and a row
 //                   is examined only if acc >= (K-th best acc known for this output row) - M;
 //                   that bound is shared between lane groups, waves and blocks through
 //                   bound[n] as in K1.  At the end every lane emits its P entries.
-//   rescore_kernel  one wave per output row: exact chain s = fmaf(v, v, s), k ascending,
+//   rescore_kernel  16 or 64 lanes per output row: exact chain s = fmaf(v, v, s), k ascending,
 //                   sqrtf, for the emitted rows with acc >= (final K-th best acc) - M; top-K of
 //                   (distance bits, index) -> the same packed keys K5 writes.  A row that
 //                   belongs to the exact top-K has acc >= bound - M; it can be missing from its
@@ -26,45 +29,48 @@
 //                   entry inside the margin) sends the output row to rescan_kernel (a full exact
 //                   scan of that row; up to 256 rows), or, beyond that, the whole call to K5.
 //
-// Layout: rowsb [n_pad][256] bf16 = hi[128] | lo[128] per row (512 B); auxf [n_pad] float32
-// = -|m|^2/2 (padding rows: -3.4e38, below every real accumulator value).
-// Staging: 32 rows (16 KiB) + 128 B aux per step by global_load_lds_dwordx4, double buffered;
+// Layout: rowsh [n_pad][128] fp16 (256 B per row); auxf [n_pad] float32 = -|m|^2/2 of the
+// scaled row (padding rows: -3.4e38, below every real accumulator value).
+// Staging: 64 rows (16 KiB) + 256 B aux per step by global_load_lds_dwordx4, double buffered;
 // the 16-byte chunk index of a row is XORed with (row & 15) on the source side so that the
 // ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
 #include "tile_ops.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace fm {
 
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float  v4f  __attribute__((ext_vector_type(4)));
 
-constexpr int   kFRowBytes      = 512;
-constexpr int   kFStageRows     = 32;
+constexpr int   kFRowBytes      = 256;
+constexpr int   kFStageRows     = 64;
 constexpr int   kFStageRowBytes = kFStageRows * kFRowBytes;      // 16384
-constexpr int   kFStageBytes    = kFStageRowBytes + 256;         // + aux (128 B used)
+constexpr int   kFStageBytes    = kFStageRowBytes + kFStageRows * 4;   // + aux
 constexpr int   kFP             = 4;                             // entries per lane and output row
 constexpr float kFEmpty         = -3.0e38f;                      // acc of an empty entry
 constexpr int   kFMaxRescan     = 256;                           // output rows rescan_kernel can take
 
 struct FParams {
-    const char*  col_rows;     // bf16 planes of the output rows
+    const char*  col_rows;     // fp16 rows of the output rows
     const float* col_norm;
     int          ncols;        // real output rows
     int          ncols_pad;
     const char*  red_rows;
     const float* red_aux;
     int          nred;
-    int          nstages;      // nred_pad / 32
+    int          nstages;      // nred_pad / kFStageRows
     int          nsplit;
     int          nchunks;
     int          stages_per_split;
     int          ncols_alloc;
-    float        eps;          // 2^-12
-    float        eps_nm;       // eps * max |m|^2 of the reduced bank
+    float        eps_c;        // eps * 2^(km-kc): times the stored |c|^2 = eps |c|^2 in acc units
+    float        eps_nm;       // eps * max |m|^2 of the reduced bank, in acc units
+    float        aux_mul;      // 2^(kc-km): stored accumulator inits -> acc units
     unsigned long long* slots; // [nsplit][ncols_alloc][4][kFP]  (acc bits << 32 | row), ~0 = none
     int*         bound;        // [2][ncols_alloc] ordered-int images: best acc, 2nd best acc (see below)
     int*         flag;
+    int          abl;          // experiments: 1 = no exact path, 2 = no staging after the first stage
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -82,16 +88,15 @@ template <int NW>
 __device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char* buf, int wave, int lane)
 {
     const char* src_rows = p.red_rows + (size_t)stage * kFStageRowBytes;
-    constexpr int kPieces = 16 / NW;                   // 1-KiB pieces (2 rows) per wave
+    constexpr int kPieces = (kFStageRows / 4) / NW;    // 1-KiB pieces (4 rows) per wave
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
         const int g   = wave * kPieces + i;
-        const int row = g * 2 + (lane >> 5);
-        const int cp  = lane & 31;                      // chunk position in LDS
-        const int c   = (cp & 16) | ((cp & 15) ^ (row & 15));
+        const int row = g * 4 + (lane >> 4);
+        const int c   = (lane & 15) ^ (row & 15);       // source chunk stored at LDS chunk position lane & 15
         __builtin_amdgcn_global_load_lds(GLB_PTR(src_rows + row * kFRowBytes + c * 16), LDS_PTR(buf + g * 1024), 16, 0, 0);
     }
-    if (wave == NW - 1 && lane < 8)
+    if (wave == NW - 1 && lane < kFStageRows / 4)
         __builtin_amdgcn_global_load_lds(GLB_PTR(p.red_aux + (size_t)stage * kFStageRows + lane * 4),
                                          LDS_PTR(buf + kFStageRowBytes), 16, 0, 0);
 }
@@ -111,23 +116,19 @@ void filter_kernel(FParams p)
     const int split = blockIdx.x / p.nchunks;
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
-    // Stationary operand: NC x 16 output rows, hi and lo planes, 4 K-steps of 32.
-    v8bf bh[NC][4], bl[NC][4];
+    // Stationary operand: NC x 16 output rows, 4 K-steps of 32.
+    v8h bh[NC][4];
     float marg[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int n = cb + 16 * j + c16;
         const bool ok = n < p.ncols_pad;
-        marg[j] = ok ? fmaf(p.eps, p.col_norm[n], p.eps_nm) : 0.f;
+        marg[j] = ok ? fmaf(p.eps_c, p.col_norm[n], p.eps_nm) : 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            v4i h = v4i{0, 0, 0, 0}, l = v4i{0, 0, 0, 0};
-            if (ok) {
-                h = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + (4 * s + g) * 16);
-                l = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + 256 + (4 * s + g) * 16);
-            }
-            bh[j][s] = __builtin_bit_cast(v8bf, h);
-            bl[j][s] = __builtin_bit_cast(v8bf, l);
+            v4i h = v4i{0, 0, 0, 0};
+            if (ok) h = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + (4 * s + g) * 16);
+            bh[j][s] = __builtin_bit_cast(v8h, h);
         }
     }
 
@@ -190,40 +191,26 @@ void filter_kernel(FParams p)
             thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
         }
         stage_pub = 0;
-        if (st + 1 < st1) f_issue_stage<NW>(p, st + 1, smem + (BUF ^ 1) * kFStageBytes, wave, lane);
+        if (st + 1 < st1 && !(p.abl & 2)) f_issue_stage<NW>(p, st + 1, smem + (BUF ^ 1) * kFStageBytes, wave, lane);
 #pragma unroll
         for (int j = 0; j < NC; ++j)
             gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {                               // 16-row tiles of the stage
+        for (int t = 0; t < kFStageRows / 16; ++t) {                // 16-row tiles of the stage
             const char* rows = buf + t * 16 * kFRowBytes;
-            const v4f ci = *(const v4f*)(buf + xoff + t * 64);
+            v4f ci = *(const v4f*)(buf + xoff + t * 64);
+            ci *= p.aux_mul;
+            v8h ah[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ah[s] = __builtin_bit_cast(v8h, *(const v4i*)(rows + aoff[s]));
             v4f acc[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) acc[j] = ci;
-            {
-                v8bf ah[4];
+            for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh[j][0], ci, 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) ah[s] = __builtin_bit_cast(v8bf, *(const v4i*)(rows + aoff[s]));
+            for (int s = 1; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl[j][s], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh[j][s], acc[j], 0, 0, 0);
-            }
-            {
-                v8bf al[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) al[s] = __builtin_bit_cast(v8bf, *(const v4i*)(rows + 256 + aoff[s]));
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh[j][s], acc[j], 0, 0, 0);
-            }
+                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[j][s], acc[j], 0, 0, 0);
             float tmax[NC];
             bool any = false;
 #pragma unroll
@@ -231,8 +218,8 @@ void filter_kernel(FParams p)
                 tmax[j] = fmaxf(fmaxf(fmaxf(acc[j][0], acc[j][1]), acc[j][2]), acc[j][3]);
                 any |= tmax[j] >= thr[j];
             }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                const int row0 = (st * 2 + t) * 16 + 4 * g;
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull && !(p.abl & 1)) {
+                const int row0 = (st * (kFStageRows / 16) + t) * 16 + 4 * g;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
@@ -305,29 +292,30 @@ struct RParams {
     const float* col_rowsf;
     const float* col_norm;
     const float* red_rowsf;
-    float        eps, eps_nm;
+    float        eps_c, eps_nm;   // as in FParams
     int          ncols;           // real output rows
     unsigned long long* partial;  // split 0 of the caller's layout: [n][KTOP]
     int*         flag;            // [0] raised when more than kFMaxRescan output rows need a full scan,
                                   // [1] number of such rows, [3] total (diagnostic), [4 ..] their indices
 };
 
-template <int KTOP>
+template <int KTOP, int LPC>       // LPC lanes per output row (16 or 64)
 __global__ __launch_bounds__(256)
 void rescore_kernel(RParams p)
 {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= p.ncols) return;
-    const float thr = funmap(p.bound[n]) - fmaf(p.eps, p.col_norm[n], p.eps_nm);
-    const float4* cp = (const float4*)(p.col_rowsf + (size_t)n * kDim);
+    const int sub = threadIdx.x & (LPC - 1);
+    const int n = (int)((blockIdx.x * 256 + threadIdx.x) / LPC);
+    const bool live = n < p.ncols;
+    const int nn = live ? n : 0;
+    const float thr = funmap(p.bound[nn]) - fmaf(p.eps_c, p.col_norm[nn], p.eps_nm);
+    const float4* cp = (const float4*)(p.col_rowsf + (size_t)nn * kDim);
     unsigned long long k0 = ~0ull, k1 = ~0ull;
     bool incomplete = false;
     const int nslots = p.nsplit * 4 * kFP;
-    for (int s0 = 0; s0 < nslots; s0 += 64) {
-        const int s = s0 + lane;
+    for (int s0 = 0; s0 < nslots; s0 += LPC) {
+        const int s = s0 + sub;
         unsigned long long slot = ~0ull;
-        if (s < nslots) slot = p.slots[((size_t)(s >> 4) * p.ncols_alloc + n) * (4 * kFP) + (s & 15)];
+        if (live && s < nslots) slot = p.slots[((size_t)(s >> 4) * p.ncols_alloc + nn) * (4 * kFP) + (s & 15)];
         const bool valid = slot != ~0ull && __uint_as_float((unsigned)(slot >> 32)) >= thr;
         if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
         // a lane's last (smallest) entry inside the margin: rows it dropped may be inside too
@@ -351,16 +339,17 @@ void rescore_kernel(RParams p)
             else if (key < k1) { k1 = key; }
         }
     }
+    int redo = incomplete ? 1 : 0;
 #pragma unroll
-    for (int mask = 1; mask < 64; mask <<= 1) {
+    for (int mask = 1; mask < LPC; mask <<= 1) {
         const unsigned long long o0 = __shfl_xor(k0, mask), o1 = __shfl_xor(k1, mask);
         const unsigned long long lo = k0 < o0 ? k0 : o0, hi = k0 < o0 ? o0 : k0;
         const unsigned long long m1 = k1 < o1 ? k1 : o1;
         k0 = lo;
         k1 = hi < m1 ? hi : m1;
+        redo |= __shfl_xor(redo, mask);
     }
-    const bool redo = __builtin_amdgcn_ballot_w64(incomplete) != 0ull;
-    if (lane == 0) {
+    if (live && sub == 0) {
         p.partial[(size_t)n * KTOP] = k0;
         if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = k1;
         if (redo) {
@@ -425,16 +414,19 @@ void rescan_kernel(RParams p, int nred)
 FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
 {
     FilterPlan pl;
-    pl.nw = (ncols_pad >= 8192) ? 8 : 4;
+    pl.nw = 4;
+    if (const char* e = getenv("FM_F32_NW")) { const int v = atoi(e); if (v == 4 || v == 8) pl.nw = v; }
     const int cb = 16 * 4 * pl.nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
     const int64_t nstages = nred_pad / kFStageRows;
-    int64_t want = 4 * 256 * (8 / pl.nw);            // ~4 rounds of one (nw = 8) or two workgroups per CU
+    int64_t want = 6 * 256 * (16 / pl.nw);            // ~6 rounds of the workgroups the chip holds
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
-    if (nsplit > nstages / 16) nsplit = nstages / 16;   // >= 512 rows per split
+    if (nsplit > nstages / 8) nsplit = nstages / 8;     // >= 512 rows per split
     if (nsplit < 1) nsplit = 1;
+    if (const char* e = getenv("FM_F32_NSPLIT")) { const int v = atoi(e); if (v > 0) nsplit = v; }
+    if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
     int64_t per = (nstages + nsplit - 1) / nsplit;
     if (per < 1) per = 1;
     nsplit = (nstages + per - 1) / per;
@@ -451,17 +443,25 @@ int filter_empty_bound()
     return u.i ^ ((u.i >> 31) & 0x7fffffff);
 }
 
+bool filter_usable(const Bank& cols, const Bank& red)
+{
+    if (!cols.filt_ok || !red.filt_ok || !cols.rowsh || !red.rowsh) return false;
+    const int d = cols.kscale - red.kscale;
+    return d >= -40 && d <= 40;
+}
+
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& pl,
                          unsigned long long* slots, int* bound, int* flag,
                          unsigned long long* partial, hipStream_t stream)
 {
-    const float eps = 1.0f / 4096.0f;
+    const float eps = 1.1f / 1024.0f;
+    const int dk = cols.kscale - red.kscale;          // acc units are 2^(kc + km)
     FParams p;
-    p.col_rows = (const char*)cols.rowsb;
+    p.col_rows = (const char*)cols.rowsh;
     p.col_norm = cols.normf;
     p.ncols = (int)cols.n;
     p.ncols_pad = (int)cols.n_pad;
-    p.red_rows = (const char*)red.rowsb;
+    p.red_rows = (const char*)red.rowsh;
     p.red_aux = red.auxf;
     p.nred = (int)red.n;
     p.nstages = (int)(red.n_pad / kFStageRows);
@@ -469,11 +469,13 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     p.nchunks = pl.nchunks;
     p.stages_per_split = pl.stages_per_split;
     p.ncols_alloc = pl.ncols_alloc;
-    p.eps = eps;
-    p.eps_nm = eps * red.nm_max;
+    p.eps_c = ldexpf(eps, -dk);
+    p.eps_nm = ldexpf(eps * red.nm_max, dk);
+    p.aux_mul = ldexpf(1.0f, dk);
     p.slots = slots;
     p.bound = bound;
     p.flag = flag;
+    p.abl = getenv("FM_F32_ABL") ? atoi(getenv("FM_F32_ABL")) : 0;
     const int grid = pl.nchunks * pl.nsplit;
     if (pl.nw == 8) {
         if (ktop == 1) hipLaunchKernelGGL((filter_kernel<4, 1, 8>), dim3(grid), dim3(512), 0, stream, p);
@@ -493,17 +495,24 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     r.col_rowsf = cols.rowsf;
     r.col_norm = cols.normf;
     r.red_rowsf = red.rowsf;
-    r.eps = eps;
+    r.eps_c = p.eps_c;
     r.eps_nm = p.eps_nm;
     r.ncols = (int)cols.n;
     r.partial = partial;
     r.flag = flag;
-    const int rgrid = (int)((cols.n + 3) / 4);
-    if (rgrid > 0) {
-        if (ktop == 1) hipLaunchKernelGGL((rescore_kernel<1>), dim3(rgrid), dim3(256), 0, stream, r);
-        else           hipLaunchKernelGGL((rescore_kernel<2>), dim3(rgrid), dim3(256), 0, stream, r);
-        if (ktop == 1) hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
-        else           hipLaunchKernelGGL((rescan_kernel<2>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
+    if (cols.n > 0) {
+        const bool narrow = pl.nsplit * 4 * kFP <= 32;
+        const int lpc = narrow ? 16 : 64;
+        const int rgrid = (int)((cols.n * lpc + 255) / 256);
+        if (ktop == 1) {
+            if (narrow) hipLaunchKernelGGL((rescore_kernel<1, 16>), dim3(rgrid), dim3(256), 0, stream, r);
+            else        hipLaunchKernelGGL((rescore_kernel<1, 64>), dim3(rgrid), dim3(256), 0, stream, r);
+            hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
+        } else {
+            if (narrow) hipLaunchKernelGGL((rescore_kernel<2, 16>), dim3(rgrid), dim3(256), 0, stream, r);
+            else        hipLaunchKernelGGL((rescore_kernel<2, 64>), dim3(rgrid), dim3(256), 0, stream, r);
+            hipLaunchKernelGGL((rescan_kernel<2>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
+        }
     }
     return hipGetLastError();
 }

@@ -35,12 +35,13 @@ struct Bank {
     int32_t* norm   = nullptr;
     int32_t* aux    = nullptr;
     float*   rowsf  = nullptr; // FM_BANK_F32: [n_pad][128] float32, zero padded
-    // FM_BANK_F32, for the bf16x3 filter (filter_bf16.hip):
-    uint16_t* rowsb = nullptr; // [n_pad][256] bf16: hi[128] | lo[128], value = hi + lo + O(2^-18)
-    float*   normf  = nullptr; // [n_pad] |row|^2
-    float*   auxf   = nullptr; // [n_pad] accumulator init -|row|^2 / 2 (padding rows: -3.4e38)
-    float    nm_max = 0.f;     // max |row|^2
-    bool     filt_ok = false;  // every |row|^2 is finite and the bank is inside the filter's range
+    // FM_BANK_F32, for the fp16 filter (filter_f16.hip); "scaled" = times 2^kscale:
+    uint16_t* rowsh = nullptr; // [n_pad][128] fp16 of the scaled rows
+    float*   normf  = nullptr; // [n_pad] |scaled row|^2
+    float*   auxf   = nullptr; // [n_pad] accumulator init -|scaled row|^2 / 2 (padding rows: -3.4e38)
+    float    nm_max = 0.f;     // max |scaled row|^2
+    int      kscale = 0;       // largest scaled magnitude lies in [2^13, 2^14)
+    bool     filt_ok = false;  // every value is finite
     double*  selfdist = nullptr;
 };
 
@@ -70,7 +71,7 @@ RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_
 hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
                                 unsigned long long* partial, const int* run_flag, hipStream_t stream);
 
-// ---- K8: bf16x3 MFMA filter + exact rescoring for the float32 route (filter_bf16.hip) -----
+// ---- K8: fp16 MFMA filter + exact rescoring for the float32 route (filter_f16.hip) --------
 // Writes the same keys as K5 into split 0 of `partial` (the caller presets the other splits to
 // ~0).  flag: device words [0] K5 must redo the call, [1] output rows rescanned in full,
 // [2] K5 runs, [3] rescans in total, [4 .. 4 + 256) the rescanned rows; [0] and [1] are reset per call.
@@ -79,12 +80,13 @@ struct FilterPlan {
     int ncols_alloc;
     int nchunks;
     int nsplit;
-    int stages_per_split;   // 32-row stages
+    int stages_per_split;   // 64-row stages
     size_t slots_bytes() const { return (size_t)nsplit * ncols_alloc * 16 * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 8; }   // best and 2nd best
 };
 FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad);
 int filter_empty_bound();
+bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry filter planes of compatible scale
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
                          unsigned long long* partial, hipStream_t stream);

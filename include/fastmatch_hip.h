@@ -55,8 +55,8 @@ int  fm_get_stats(fm_ctx* ctx, fm_stats* out);
 int  fm_reset_stats(fm_ctx* ctx);
 /* Name of the device the context runs on (e.g. "gfx950:..."), written NUL-terminated.  */
 int  fm_device_name(fm_ctx* ctx, char* buf, int buflen);
-/* Float32 route diagnostics: how many row-reduces went through the bf16x3 MFMA filter
- * (filter_bf16.hip) and how many of those had to be redone by the all-pairs float32 kernel
+/* Float32 route diagnostics: how many row-reduces went through the fp16 MFMA filter
+ * (filter_f16.hip) and how many of those had to be redone by the all-pairs float32 kernel
  * because a candidate list could have been incomplete (results are identical either way). */
 int  fm_f32_filter_stats(fm_ctx* ctx, int64_t* launches, int64_t* fallbacks);
 

@@ -393,17 +393,31 @@ def test_f32_filter_handles_dim_below_128_and_empty_banks(filter_ctx):
     assert tidx.shape == (0,)
 
 
-def test_f32_filter_is_skipped_outside_its_range(filter_ctx):
-    """Non-finite norms or magnitudes outside [1e-30, 1e30] keep the bank on K5."""
+def test_f32_filter_scales_each_bank_by_its_own_power_of_two(filter_ctx):
+    """Magnitudes far outside fp16's range still take the filter (banks are stored scaled);
+    banks whose scales differ by more than 2^40, or that hold a non-finite value, stay on K5."""
     c = filter_ctx
     rng = np.random.default_rng(6)
     Q = (rng.normal(0, 1, (200, 128)) * 1e18).astype(np.float32)
     T = (rng.normal(0, 1, (300, 128)) * 1e18).astype(np.float32)
     before = c.f32_filter_stats()[0]
     idx, dist = c.knn2(c.bank(Q), c.bank(T))
-    assert c.f32_filter_stats()[0] == before
+    assert c.f32_filter_stats()[0] == before + 1
     oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
     assert _eq(idx, oidx) and _eq(dist, odist)
+    Ts = (T * np.float32(1e-30)).astype(np.float32)        # 2^160 apart: K5
+    idx, dist = c.knn2(c.bank(Q), c.bank(Ts))
+    assert c.f32_filter_stats()[0] == before + 1
+    oidx, odist = oracle.bf_knn(Q, Ts, 2, order=1)
+    assert _eq(idx, oidx) and _eq(dist, odist)
+    Tn = rng.normal(0, 1, (300, 128)).astype(np.float32)
+    Qn = rng.normal(0, 1, (200, 128)).astype(np.float32)
+    Tn[17, 5] = np.inf
+    idx, dist = c.knn2(c.bank(Qn), c.bank(Tn))
+    assert c.f32_filter_stats()[0] == before + 1
+    oidx, odist = oracle.bf_knn(Qn, Tn, 2, order=1)
+    keep = np.arange(200)
+    assert np.array_equal(idx[:, 0], oidx[:, 0]) and np.array_equal(dist[:, 0], odist[:, 0])   # (the inf row is never nearest)
 
 
 def test_f32_route_close_to_opencv_order(ctx):
