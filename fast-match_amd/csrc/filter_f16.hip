@@ -31,7 +31,7 @@
 //
 // Layout: rowsh [n_pad][128] fp16 (256 B per row); auxf [n_pad] float32 = -|m|^2/2 of the
 // scaled row (padding rows: -3.4e38, below every real accumulator value).
-// Staging: 64 rows (16 KiB) + 256 B aux per step by global_load_lds_dwordx4, double buffered;
+// Staging: 128 rows (32 KiB) + 512 B aux per step by global_load_lds_dwordx4, double buffered;
 // the 16-byte chunk index of a row is XORed with (row & 15) on the source side so that the
 // ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
 #include "tile_ops.h"
@@ -44,8 +44,8 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float  v4f  __attribute__((ext_vector_type(4)));
 
 constexpr int   kFRowBytes      = 256;
-constexpr int   kFStageRows     = 64;
-constexpr int   kFStageRowBytes = kFStageRows * kFRowBytes;      // 16384
+constexpr int   kFStageRows     = 128;
+constexpr int   kFStageRowBytes = kFStageRows * kFRowBytes;      // 32768
 constexpr int   kFStageBytes    = kFStageRowBytes + kFStageRows * 4;   // + aux
 constexpr int   kFP             = 4;                             // entries per lane and output row
 constexpr float kFEmpty         = -3.0e38f;                      // acc of an empty entry
@@ -70,7 +70,6 @@ struct FParams {
     unsigned long long* slots; // [nsplit][ncols_alloc][4][kFP]  (acc bits << 32 | row), ~0 = none
     int*         bound;        // [2][ncols_alloc] ordered-int images: best acc, 2nd best acc (see below)
     int*         flag;
-    int          abl;          // experiments: 1 = no exact path, 2 = no staging after the first stage
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -81,6 +80,10 @@ __device__ __forceinline__ int fmap(float f)
 {
     const int i = __float_as_int(f);
     return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float fmax3(float a, float b, float c)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
 __device__ __forceinline__ float funmap(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
 
@@ -102,7 +105,7 @@ __device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char*
 }
 
 template <int NC, int KTOP, int NW>
-__global__ __launch_bounds__(64 * NW, 2)
+__global__ __launch_bounds__(64 * NW, (NC <= 2 ? 4 : 2))
 void filter_kernel(FParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes];
@@ -159,7 +162,7 @@ void filter_kernel(FParams p)
         gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // K = 2: turn the value returned by the last bound1 publish into a bound2 publish
-    auto settle = [&](int j) {
+    auto settle = [&](int j) __attribute__((always_inline)) {
         if constexpr (KTOP == 2) {
             if (pend[j] != kNone) {
                 const float v2 = fminf(funmap(pend[j]), ea[j][0]);
@@ -178,56 +181,52 @@ void filter_kernel(FParams p)
     for (int s = 0; s < 4; ++s) aoff[s] = c16 * kFRowBytes + 16 * ((4 * s + g) ^ c16);
     const int xoff = kFStageRowBytes + 16 * g;
 
-    if (st0 < st1) f_issue_stage<NW>(p, st0, smem, wave, lane);
-
-    auto stage = [&](auto buf_tag, int st) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        char* buf = smem + BUF * kFStageBytes;
+    // Software pipeline.  The A fragments (and accumulator inits) of 16-row tile k+1 are read
+    // from LDS while the MFMAs of tile k run, so no MFMA waits on an LDS read.  The step from
+    // stage st to st+1 happens in front of the LAST tile of stage st: by then that tile's
+    // fragments are in registers, so after "my share of stage st+1 has landed" + one barrier
+    // every wave may read stage st+1 and buffer st&1 may be refilled with stage st+2.
+    constexpr int kTiles = kFStageRows / 16;
+    v8h fs[2][4];                 // fragment set k & 1 holds 16-row tile k of the stage
+    v4f cs[2];
+    auto load_tile = [&](int set, const char* buf, int k) __attribute__((always_inline)) {
+        const char* rows = buf + k * 16 * kFRowBytes;
+        cs[set] = *(const v4f*)(buf + xoff + k * 64);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fs[set][s] = __builtin_bit_cast(v8h, *(const v4i*)(rows + aoff[s]));
+    };
+    if (st0 < st1) {
+        f_issue_stage<NW>(p, st0, smem, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            settle(j);
-            thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
-        }
-        stage_pub = 0;
-        if (st + 1 < st1 && !(p.abl & 2)) f_issue_stage<NW>(p, st + 1, smem + (BUF ^ 1) * kFStageBytes, wave, lane);
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-            gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st0 + 1 < st1) f_issue_stage<NW>(p, st0 + 1, smem + kFStageBytes, wave, lane);
+        load_tile(0, smem, 0);
+    }
 
-#pragma unroll
-        for (int t = 0; t < kFStageRows / 16; ++t) {                // 16-row tiles of the stage
-            const char* rows = buf + t * 16 * kFRowBytes;
-            v4f ci = *(const v4f*)(buf + xoff + t * 64);
-            ci *= p.aux_mul;
-            v8h ah[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ah[s] = __builtin_bit_cast(v8h, *(const v4i*)(rows + aoff[s]));
-            v4f acc[NC];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh[j][0], ci, 0, 0, 0);
-#pragma unroll
-            for (int s = 1; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], bh[j][s], acc[j], 0, 0, 0);
+    v4f acc[2][NC];
+    // reduce epilogue of one 32-row unit (two tiles' accumulators)
+    auto reduce_unit = [&](int st, int u) __attribute__((always_inline)) {
             float tmax[NC];
             bool any = false;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                tmax[j] = fmaxf(fmaxf(fmaxf(acc[j][0], acc[j][1]), acc[j][2]), acc[j][3]);
+                // v_maximum3_f32 (no NaN-quieting pre-pass as fmaxf needs); NaN cannot occur here
+                const float m0 = fmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
+                const float m1 = fmax3(acc[0][j][3], acc[1][j][0], acc[1][j][1]);
+                tmax[j] = fmax3(fmax3(acc[1][j][2], acc[1][j][3], m0), m1, m1);
                 any |= tmax[j] >= thr[j];
             }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull && !(p.abl & 1)) {
-                const int row0 = (st * (kFStageRows / 16) + t) * 16 + 4 * g;
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                const int row0 = (st * (kFStageRows / 16) + 2 * u) * 16 + 4 * g;
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
                         const float a1_before = ea[j][0], a2_before = ea[j][KTOP - 1];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float a = (acc[j][r] >= thr[j]) ? acc[j][r] : -INFINITY;
-                            int id = row0 + r;
+                        for (int r = 0; r < 8; ++r) {                   // ascending row order
+                            const float av = acc[r >> 2][j][r & 3];
+                            float a = (av >= thr[j]) ? av : -INFINITY;
+                            int id = row0 + 16 * (r >> 2) + (r & 3);
 #pragma unroll
                             for (int i = 0; i < kFP; ++i) {
                                 const bool b = a > ea[j][i];
@@ -261,6 +260,45 @@ void filter_kernel(FParams p)
                     }
                 }
             }
+    };
+
+    auto stage = [&](auto buf_tag, int st) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        char* buf = smem + BUF * kFStageBytes;
+#pragma unroll
+        for (int k = 0; k < kTiles; ++k) {
+            if (k + 1 < kTiles) {
+                load_tile((k + 1) & 1, buf, k + 1);
+            } else {
+                // stage boundary (see above); the shared bounds are refreshed here, once per stage
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    settle(j);
+                    thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
+                }
+                stage_pub = 0;
+                if (st + 1 < st1) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (st + 2 < st1) f_issue_stage<NW>(p, st + 2, buf, wave, lane);
+                    load_tile(0, smem + (BUF ^ 1) * kFStageBytes, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int t = k & 1;
+                const v4f ci = cs[t] * p.aux_mul;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[t][0], bh[j][0], ci, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[t][s], bh[j][s], acc[t][j], 0, 0, 0);
+            }
+            if (k & 1) reduce_unit(st, k >> 1);
         }
     };
 
@@ -416,14 +454,16 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
     FilterPlan pl;
     pl.nw = 4;
     if (const char* e = getenv("FM_F32_NW")) { const int v = atoi(e); if (v == 4 || v == 8) pl.nw = v; }
-    const int cb = 16 * 4 * pl.nw;
+    pl.nc = 4;
+    if (const char* e = getenv("FM_F32_NC")) { const int v = atoi(e); if (v == 2 || v == 4) pl.nc = v; }
+    const int cb = 16 * pl.nc * pl.nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
     const int64_t nstages = nred_pad / kFStageRows;
     int64_t want = 6 * 256 * (16 / pl.nw);            // ~6 rounds of the workgroups the chip holds
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
-    if (nsplit > nstages / 8) nsplit = nstages / 8;     // >= 512 rows per split
+    if (nsplit > nstages / 4) nsplit = nstages / 4;     // >= 512 rows per split
     if (nsplit < 1) nsplit = 1;
     if (const char* e = getenv("FM_F32_NSPLIT")) { const int v = atoi(e); if (v > 0) nsplit = v; }
     if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
@@ -475,15 +515,15 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     p.slots = slots;
     p.bound = bound;
     p.flag = flag;
-    p.abl = getenv("FM_F32_ABL") ? atoi(getenv("FM_F32_ABL")) : 0;
     const int grid = pl.nchunks * pl.nsplit;
-    if (pl.nw == 8) {
-        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<4, 1, 8>), dim3(grid), dim3(512), 0, stream, p);
-        else           hipLaunchKernelGGL((filter_kernel<4, 2, 8>), dim3(grid), dim3(512), 0, stream, p);
-    } else {
-        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<4, 1, 4>), dim3(grid), dim3(256), 0, stream, p);
-        else           hipLaunchKernelGGL((filter_kernel<4, 2, 4>), dim3(grid), dim3(256), 0, stream, p);
-    }
+#define FM_LAUNCH_FILTER(NC_, NW_)                                                                         \
+    do {                                                                                                   \
+        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<NC_, 1, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
+        else           hipLaunchKernelGGL((filter_kernel<NC_, 2, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
+    } while (0)
+    if (pl.nc == 2) { if (pl.nw == 8) FM_LAUNCH_FILTER(2, 8); else FM_LAUNCH_FILTER(2, 4); }
+    else            { if (pl.nw == 8) FM_LAUNCH_FILTER(4, 8); else FM_LAUNCH_FILTER(4, 4); }
+#undef FM_LAUNCH_FILTER
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 

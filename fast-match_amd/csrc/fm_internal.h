@@ -76,11 +76,12 @@ hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, con
 // ~0).  flag: device words [0] K5 must redo the call, [1] output rows rescanned in full,
 // [2] K5 runs, [3] rescans in total, [4 .. 4 + 256) the rescanned rows; [0] and [1] are reset per call.
 struct FilterPlan {
-    int nw;            // waves per workgroup (4 or 8), 64 output rows per wave
+    int nw;            // waves per workgroup (4 or 8)
+    int nc;            // blocks of 16 output rows per wave (2 or 4)
     int ncols_alloc;
     int nchunks;
     int nsplit;
-    int stages_per_split;   // 64-row stages
+    int stages_per_split;   // 128-row stages
     size_t slots_bytes() const { return (size_t)nsplit * ncols_alloc * 16 * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 8; }   // best and 2nd best
 };
