@@ -157,6 +157,35 @@ def main():
                "ms_per_call": 1e3 * dt, "kernel_ms": ctx.stats()["kernel_ms"] / reps,
                "note": "fm_knn2_ratio: K2 top-2 + Lowe ratio + compaction, same banks"}
 
+    # Float32 route (BASELINE.json configs[4]: 1M-row float32 target bank vs 10k-row query
+    # batches): fm_knn2 on non-integer descriptors = K8 (fp16-MFMA filter + exact float32
+    # rescoring).  Reported beside the headline at N = 1; FM_BENCH_F32=0 skips it.
+    f32 = None
+    if rank == 0 and world == 1 and os.environ.get("FM_BENCH_F32", "1") != "0":
+        rng = np.random.default_rng(20250005)
+        n_bank, n_query = 1000000, 10000
+        Tf = synth.synth_sift(n_bank, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (n_bank, 128)).astype(np.float32)
+        Qf = synth.synth_sift(n_query, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (n_query, 128)).astype(np.float32)
+        tbf, qbf = ctx.bank(Tf), ctx.bank(Qf)
+        del Tf
+        ctx.knn2(qbf, tbf)
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.knn2(qbf, tbf)
+        dt = (time.perf_counter() - t0) / reps
+        stf = ctx.stats()
+        kms = stf["kernel_ms"] / max(stf["kernel_launches"], 1)
+        launches, redone = ctx.f32_filter_stats()
+        f32 = {"pairs_per_s": float(n_bank) * n_query / (kms * 1e-3), "kernel_ms": kms, "ms_per_call": 1e3 * dt,
+               "frac_fp16_mfma_peak": float(n_bank) * n_query * 256 / (kms * 1e-3) / 2.5e15,
+               "filtered_calls": launches, "redone_by_all_pairs_kernel": redone,
+               "note": "fm_knn2, 10k x 1M non-integer float32 descriptors: fp16 MFMA filter (256 flop/pair) + exact "
+                       "float32 rescoring, results bit-identical to the all-pairs float32 chain"}
+        tbf.close()
+        qbf.close()
+
     if rank == 0:
         pairs_per_step = float(NQ) * NT
         value = world * pairs_per_step * args.steps / elapsed
@@ -196,6 +225,7 @@ def main():
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
                          "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},
             "classic_ratio_match": crm,
+            "float32_route": f32,
             "call_ms": call_ms,
             "device": ctx.device_name(),
         }
