@@ -138,18 +138,19 @@ void filter_kernel(FParams p)
     float ea[NC][kFP];
     int   ei[NC][kFP];
     // Shared bounds, exact once every lane is done.  bound1[n] = max over all lanes of their
-    // best acc; every row is published at most once, when it becomes its lane's best.  K = 2:
-    // that publish is a RETURNING fetch-max, and min(value before, lane's best) is the acc of
-    // the worse of two different rows, i.e. a valid bound on the 2nd best; so is a lane's own
-    // 2nd best.  bound2[n] = max of those, which ends as exactly the 2nd best acc overall (the
-    // fetch-maxes are serialised in L2: whichever of the two best rows is published later sees
-    // the other or something better).  The returned value is consumed at the next stage start,
-    // behind the wait that already retires the LDS-DMA prefetch, so the wave never stalls on it.
+    // best acc.  K = 2: a lane publishes a row to bound1 at most once, by a RETURNING fetch-max,
+    // and min(value before, lane's best) is the acc of the worse of two different rows, i.e. a
+    // valid bound on the 2nd best; so is a lane's own 2nd best.  bound2[n] = max of those, which
+    // ends as exactly the 2nd best acc overall (the fetch-maxes are serialised in L2: whichever
+    // of the two best rows is published later sees the other or something better).
+    // All atomics are issued at the stage hand-over, right behind its wait + barrier, and the
+    // returned values are consumed at the next hand-over: nothing issued in between is waited
+    // for, and the wait of the hand-over finds only a stage-old LDS-DMA, loads and atomics.
     // The lane's threshold thr[] only ever rises.
     float thr[NC];
     int   gnext[NC];             // bound of rank K, loaded one stage ahead
     int   pend[NC];              // K = 2: value returned by this lane's last bound1 publish
-    int   stage_pub = 0;         // K = 2: bit j = a returning publish for row j is in flight
+    float last1[NC];             // K = 2: best acc this lane has published to bound1
     int* const bound1 = p.bound;
     int* const boundk = p.bound + (KTOP == 2 ? p.ncols_alloc : 0);
     const int kNone = fmap(kFEmpty);
@@ -159,6 +160,7 @@ void filter_kernel(FParams p)
         for (int i = 0; i < kFP; ++i) { ea[j][i] = kFEmpty; ei[j][i] = -1; }
         thr[j] = kFEmpty;
         pend[j] = kNone;
+        last1[j] = kFEmpty;
         gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // K = 2: turn the value returned by the last bound1 publish into a bound2 publish
@@ -168,6 +170,19 @@ void filter_kernel(FParams p)
                 const float v2 = fminf(funmap(pend[j]), ea[j][0]);
                 __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pend[j] = kNone;
+            }
+        }
+    };
+    // publish what this lane knows and the others may not: its K-th best if that is what its
+    // threshold rests on (re-publishing an unchanged value is harmless), K = 2: a new best row
+    auto publish = [&](int j) __attribute__((always_inline)) {
+        int* const bk = boundk + cb + 16 * j + c16;
+        if (ea[j][KTOP - 1] - marg[j] >= thr[j] && ea[j][KTOP - 1] > kFEmpty)
+            __hip_atomic_fetch_max(bk, fmap(ea[j][KTOP - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (KTOP == 2) {
+            if (ea[j][0] > last1[j]) {
+                last1[j] = ea[j][0];
+                pend[j] = __hip_atomic_fetch_max(bound1 + cb + 16 * j + c16, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -221,7 +236,6 @@ void filter_kernel(FParams p)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
-                        const float a1_before = ea[j][0], a2_before = ea[j][KTOP - 1];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {                   // ascending row order
                             const float av = acc[r >> 2][j][r & 3];
@@ -238,25 +252,6 @@ void filter_kernel(FParams p)
                             }
                         }
                         thr[j] = fmaxf(thr[j], ea[j][KTOP - 1] - marg[j]);
-                        int* const b1 = bound1 + cb + 16 * j + c16;
-                        if constexpr (KTOP == 1) {
-                            if (ea[j][0] > a1_before)
-                                __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            if (ea[j][0] > a1_before) {
-                                // one returning publish per stage and output row; a second one in
-                                // the same stage (rare) only feeds bound1, which can leave bound2
-                                // a little low -- still a valid bound
-                                if (!(stage_pub & (1 << j))) {
-                                    pend[j] = __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    stage_pub |= 1 << j;
-                                } else {
-                                    __hip_atomic_fetch_max(b1, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
-                            if (ea[j][1] > a2_before)
-                                __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(ea[j][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
                     }
                 }
             }
@@ -271,21 +266,21 @@ void filter_kernel(FParams p)
                 load_tile((k + 1) & 1, buf, k + 1);
             } else {
                 // stage boundary (see above); the shared bounds are refreshed here, once per stage
-#pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    settle(j);
-                    thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
-                }
-                stage_pub = 0;
                 if (st + 1 < st1) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        settle(j);
+                        thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
+                        publish(j);
+                    }
                     if (st + 2 < st1) f_issue_stage<NW>(p, st + 2, buf, wave, lane);
                     load_tile(0, smem + (BUF ^ 1) * kFStageBytes, 0);
-                }
 #pragma unroll
-                for (int j = 0; j < NC; ++j)
-                    gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int j = 0; j < NC; ++j)
+                        gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -307,7 +302,10 @@ void filter_kernel(FParams p)
         if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
     }
 
+    // last publishes (K = 2: the value returned now is needed, so this one is waited for), then
     // emit every entry; rescore_kernel filters them against the final bound
+#pragma unroll
+    for (int j = 0; j < NC; ++j) { settle(j); publish(j); }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         settle(j);
