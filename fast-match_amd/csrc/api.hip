@@ -556,6 +556,16 @@ static void* pinned_device_alias(const void* host)
     return at.devicePointer;
 }
 
+// Copy through the kernel's own stores (dst is the device alias of page-locked host memory).
+__global__ void copy_out_kernel(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, size_t bytes)
+{
+    const size_t words = bytes / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride)
+        ((unsigned*)dst)[i] = ((const unsigned*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 3)) dst[words * 4 + threadIdx.x] = src[words * 4 + threadIdx.x];
+}
+
 // Device -> caller memory on the context's stream.  A copy into pageable memory makes the
 // runtime pin the destination pages for the transfer (milliseconds for results of ~100 KB and
 // up), so such results land in the context's own page-locked staging buffer and are moved to
@@ -575,7 +585,18 @@ static hipError_t d2h(fm_ctx* ctx, void* dst, const void* src, size_t bytes)
             off = 0;
         }
         if (ctx->h_stage && off + bytes <= ctx->h_stage_bytes) {
-            hipError_t e = hipMemcpyAsync(ctx->h_stage + off, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            // A copy kernel rather than hipMemcpyAsync: the runtime hands device-to-host copies of
+            // this size to a DMA queue behind a host-side wait for the stream, which was seen to
+            // add 1-7 ms of idle time after multi-millisecond kernels.
+            hipError_t e = hipSuccess;
+            unsigned char* alias = (((uintptr_t)src & 3) == 0) ? (unsigned char*)pinned_device_alias(ctx->h_stage + off) : nullptr;
+            if (alias) {
+                const unsigned grid = (unsigned)((bytes / 4 + 255) / 256 < 1024 ? (bytes / 4 + 255) / 256 + 1 : 1024);
+                hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, ctx->stream, alias, (const unsigned char*)src, bytes);
+                e = hipGetLastError();
+            } else {
+                e = hipMemcpyAsync(ctx->h_stage + off, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            }
             if (e != hipSuccess) return e;
             ctx->staged.push_back({dst, off, bytes});
             ctx->h_stage_used = off + bytes;
