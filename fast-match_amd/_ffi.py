@@ -64,6 +64,7 @@ SYMBOLS = {
     "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
+    "fm_xcheck1_keys": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_knn2_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_self_dist": (_INT, [_P, _P, _P]),
     "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
@@ -263,6 +264,12 @@ class Context(object):
         dist = np.empty(q.n, dtype=np.float32)
         self._check(self.lib.fm_xcheck1(self.handle, q.handle, t.handle, _ptr(tidx), _ptr(dist)))
         return tidx, dist
+
+    def xcheck1_keys(self, q, t, t_offset=0):
+        """X1 election keys of a train-set shard (see sharding.xcheck1_sharded): uint64[nq]."""
+        keys = np.empty(q.n, dtype=np.uint64)
+        self._check(self.lib.fm_xcheck1_keys(self.handle, q.handle, t.handle, int(t_offset), _ptr(keys)))
+        return keys
 
     def match_ratio(self, q, t, tau, out=None):
         """X1 + R1 fused.  ``out`` = optional (tidx i32[nq], dist f32[nq], ratio f64[nq],

@@ -258,7 +258,7 @@ __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial
 // atomicMin is order independent, so the result is deterministic.
 __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ partial, int nsplit,
                                       int ncols_alloc, int64_t nt,
-                                      unsigned long long* __restrict__ qbest)
+                                      unsigned long long* __restrict__ qbest, unsigned t_offset = 0)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -269,7 +269,8 @@ __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ par
     }
     if (b == ~0ull) return;
     const unsigned q = (unsigned)b;
-    const unsigned long long key = (b & 0xffffffff00000000ull) | (unsigned long long)(unsigned)t;
+    // (t_offset: global index of this bank's first row when the train set is sharded over ranks)
+    const unsigned long long key = (b & 0xffffffff00000000ull) | (unsigned long long)((unsigned)t + t_offset);
     atomicMin(&qbest[q], key);
 }
 
@@ -1076,6 +1077,51 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     if (rc != FM_OK) return rc;
     if (n_pass) *n_pass = (int64_t)cnt;
     return FM_OK;
+}
+
+// X1 up to the election, for a train set sharded over ranks: keys[q] =
+// (distance key << 32) | (t_offset + local train row) of the closest train row OF THIS BANK that
+// elects q, ~0 if none.  The element-wise minimum of the ranks' key arrays is the key array of
+// the unsharded call (the key carries the global index, so ties break as on one GPU).
+extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys)
+{
+    int rc = check_pair(ctx, q, t, "fm_xcheck1_keys");
+    if (rc != FM_OK) return rc;
+    const int64_t nq = q->n, nt = t->n;
+    if (nq == 0) return FM_OK;
+    if (!keys) return fail(ctx, FM_EINVAL, "fm_xcheck1_keys: output pointer is NULL");
+    if (t_offset < 0 || t_offset + nt > (int64_t)UINT32_MAX) return fail(ctx, FM_EINVAL, "fm_xcheck1_keys: t_offset + rows must fit 32 bits");
+    const int f32 = q->kind == FM_BANK_F32;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, (size_t)nq * 8 + 64)) != FM_OK) return rc;
+    unsigned long long* d_qbest = (unsigned long long*)ctx->ws_out;
+    RowReducePlan pl;
+    int* d_bound = nullptr;
+    if (!f32) {
+        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
+        if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
+    }
+    CallScope cs(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
+    if (nt > 0) {
+        if (d_bound)
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+        if (f32) {
+            if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
+        } else {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        }
+        ctx->kernel_timed = true;
+        ctx->pending_pairs += nq * nt;
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, (unsigned)t_offset);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, d2h(ctx, keys, d_qbest, (size_t)nq * 8));
+    return cs.finish();
 }
 
 extern "C" int fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t* tidx, float* dist)

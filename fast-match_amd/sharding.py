@@ -3,6 +3,9 @@
 returned with ONE variable-length all-gather (RCCL over xGMI on GPUs; gloo in the CPU
 tests).  The reference has no distributed code; this is the data-parallel axis it implies
 (turntable.py:59 maps the matcher over independent pairs) -- SURVEY.md 8(e).
+For ONE large problem: shard the train rows for the cross-check (``xcheck1_sharded``: one
+all-reduce(min) of nq packed keys) or the query rows for 2-NN (``knn2_sharded``: one
+all-gather); both reproduce the single-GPU result bit for bit.
 """
 import numpy as np
 
@@ -68,6 +71,92 @@ def all_gather_matches(packed, device=None, group=None, capacity=None, to_host=T
     counts = counts.cpu().numpy()
     host = allbuf.cpu().numpy()
     return [host[r, :int(counts[r])].copy() for r in range(world)]
+
+
+# ---- ONE large problem split over ranks -----------------------------------
+def shard_rows(n_rows, rank, world_size):
+    """Contiguous row range [lo, hi) of rank's shard of an n_rows bank."""
+    per = (n_rows + world_size - 1) // world_size
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def reduce_keys(keys, device=None, group=None):
+    """Element-wise minimum of every rank's uint64 election keys (fm_xcheck1_keys): ONE
+    all-reduce(min) of nq words -- the only exchange a train-sharded cross-check needs.
+    Keys are < 2^63 (d^2 < 2^24 or the bits of a non-negative float32 in the high word; ~0
+    = "none" maps to int64 max), so the signed minimum is the unsigned one."""
+    import torch
+    import torch.distributed as dist
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return keys
+    none = keys == np.uint64(0xFFFFFFFFFFFFFFFF)
+    signed = keys.view(np.int64).copy()
+    signed[none] = np.iinfo(np.int64).max
+    t = torch.from_numpy(signed)
+    if device is not None and not (isinstance(device, str) and device == "cpu"):
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    out = t.cpu().numpy().view(np.uint64).copy()
+    out[t.cpu().numpy() == np.iinfo(np.int64).max] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return out
+
+
+def decode_keys(keys, float32_route=False):
+    """(tidx int32[nq] (-1 = no match), dist float32[nq] (+inf = no match)) from election keys:
+    what fm_xcheck1 returns.  Integer route: dist = sqrtf(float32(d^2)), exact for d^2 < 2^24."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    none = keys == np.uint64(0xFFFFFFFFFFFFFFFF)
+    tidx = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64).astype(np.int32)
+    hi = (keys >> np.uint64(32)).astype(np.uint32)
+    dist = hi.view(np.float32).copy() if float32_route else np.sqrt(hi.astype(np.float32))
+    tidx[none] = -1
+    dist[none] = np.inf
+    return tidx, dist
+
+
+def xcheck1_sharded(ctx, qbank, tbank_shard, t_offset, device=None, group=None):
+    """Cross-checked 1-NN of the (replicated) query bank against a train set whose rows are
+    split over the ranks (this rank holds rows [t_offset, t_offset + tbank_shard.n)).
+    Every rank returns the full (tidx, dist) of the unsharded fm_xcheck1, bit for bit."""
+    from . import _ffi
+    keys = ctx.xcheck1_keys(qbank, tbank_shard, t_offset)
+    keys = reduce_keys(keys, device=device, group=group)
+    return decode_keys(keys, float32_route=(qbank.kind == _ffi.FM_BANK_F32))
+
+
+def gather_row_shards(local, n_rows, device=None, group=None):
+    """All-gather of a row-sharded int32 [m_r, c] array whose shards follow ``shard_rows``:
+    returns the full [n_rows, c] array on every rank (one collective, padded shards)."""
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(local, dtype=np.int32)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    per = (n_rows + world - 1) // world
+    dev = "cpu" if device is None or (isinstance(device, str) and device == "cpu") else device
+    buf = torch.zeros((per, local.shape[1]), dtype=torch.int32)
+    if local.shape[0]:
+        buf[:local.shape[0]] = torch.from_numpy(local)
+    buf = buf.to(dev)
+    if dev == "cpu":
+        parts = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        allbuf = torch.cat(parts)
+    else:
+        allbuf = torch.empty((world * per, local.shape[1]), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allbuf, buf, group=group)
+    return np.ascontiguousarray(allbuf.cpu().numpy()[:n_rows])      # shards are contiguous and only the last is short
+
+
+def knn2_sharded(ctx, qbank_shard, tbank, n_query, device=None, group=None):
+    """2-NN of a query bank split over the ranks by ``shard_rows`` (rows are independent):
+    this rank computes its rows; one all-gather returns all n_query rows on every rank."""
+    idx, d = ctx.knn2(qbank_shard, tbank)
+    rows = gather_row_shards(np.concatenate([idx, d.view(np.int32)], axis=1), n_query, device=device, group=group)
+    return np.ascontiguousarray(rows[:, :2]), np.ascontiguousarray(rows[:, 2:]).view(np.float32)
 
 
 class MatchGatherer(object):

@@ -115,6 +115,14 @@ int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
 int  fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
                 int32_t* tidx /*[nq]*/, float* dist /*[nq]*/);
 
+/* X1 up to the election, for a train set sharded over ranks (one process per GPU): keys[q] =
+ * (distance key << 32) | (t_offset + train row in this bank) of the closest row of THIS bank
+ * that elects q, ~0 if none; distance key = the integer d^2 (integer-valued banks) or the
+ * float32 bits of the distance (float32 route).  The element-wise minimum over the ranks
+ * (one all-reduce(min) of nq words) equals the keys of the unsharded fm_xcheck1: same
+ * matches, same tie-breaks (cv::BFMatcher cross-check, fastmatch.pyx:122-123, 161-162).   */
+int  fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys);
+
 /* ---- R1: ratio + threshold -----------------------------------------------------------
  * Replaces  ratios = m.distance / query_dis[m.queryIdx]   (fastmatch.pyx:124, 165)
  *      and  ratios < tau                                   (fastmatch.pyx:50, 75, 82)

@@ -494,3 +494,37 @@ def test_train_set_beyond_opencv_18bit_limit(ctx):
     t2, d2 = ctx.xcheck1(tb, qb)
     ot2, od2 = oracle.bf_xcheck1(T, Q)
     assert _eq(t2, ot2) and _eq(d2, od2)
+
+
+# ---- ONE large problem sharded over ranks: the per-shard pieces -----------
+@pytest.mark.parametrize("as_f32", [False, True])
+def test_train_sharded_crosscheck_keys_reduce_to_the_unsharded_result(ctx, as_f32):
+    """fm_xcheck1_keys of each train-row shard, element-wise min (what the all-reduce does),
+    decode == fm_xcheck1 on the whole train set, incl. ties across the shard boundary."""
+    from fastmatch_amd import sharding
+    rng = np.random.default_rng(11)
+    if as_f32:
+        Q = rng.normal(0, 1, (700, 128)).astype(np.float32)
+        T = rng.normal(0, 1, (5000, 128)).astype(np.float32)
+        T[4000] = T[10]; Q[5] = T[10]
+    else:
+        Q, T, _ = synth.planted_pair(700, 5000, seed=12)
+        T[4000] = T[10]                                    # equal rows in different shards: lower global index wins
+        Q[5] = T[10]
+    qb = ctx.bank(Q)
+    full_t, full_d = ctx.xcheck1(qb, ctx.bank(T))
+    for world in (2, 3):
+        keys = None
+        for r in range(world):
+            lo, hi = sharding.shard_rows(T.shape[0], r, world)
+            k = ctx.xcheck1_keys(qb, ctx.bank(T[lo:hi]), lo)
+            keys = k if keys is None else np.minimum(keys, k)
+        t, d = sharding.decode_keys(keys, float32_route=as_f32)
+        assert _eq(t, full_t) and _eq(d, full_d)
+    # single process: the helper is the plain call
+    t, d = sharding.xcheck1_sharded(ctx, qb, ctx.bank(T), 0)
+    assert _eq(t, full_t) and _eq(d, full_d)
+    lo, hi = sharding.shard_rows(700, 0, 1)
+    i2, d2 = sharding.knn2_sharded(ctx, qb, ctx.bank(T), 700)
+    oi, od = ctx.knn2(qb, ctx.bank(T))
+    assert _eq(i2, oi) and _eq(d2, od)

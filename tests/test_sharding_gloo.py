@@ -51,10 +51,30 @@ for r in range(world):
     assert int(counts[r]) == n_r, (rank, r, int(counts[r]), n_r)
     if r == rank:
         assert np.array_equal(rows[r, :n_r].numpy(), mine[:n_r])
+# ONE large problem, train rows sharded: election keys per shard (here from the CPU oracle, on
+# the GPU from fm_xcheck1_keys), one all-reduce(min), decode == the unsharded cross-check
+sys.path.insert(0, %r)
+import oracle
+rng = np.random.default_rng(5)
+Q = rng.integers(0, 4, (90, 128)).astype(np.uint8) * 60          # few levels: plenty of ties
+T = rng.integers(0, 4, (150, 128)).astype(np.uint8) * 60
+lo, hi = sharding.shard_rows(150, rank, world)
+tl, dl = oracle.bf_xcheck1(Q, T[lo:hi])
+d2 = np.rint(dl.astype(np.float64) ** 2).astype(np.uint64)
+keys = np.where(tl >= 0, (d2 << np.uint64(32)) | (tl.astype(np.int64) + lo).astype(np.uint64), np.uint64(0xFFFFFFFFFFFFFFFF))
+tidx, dd = sharding.decode_keys(sharding.reduce_keys(keys))
+ft, fd = oracle.bf_xcheck1(Q, T)
+assert np.array_equal(tidx, ft) and np.array_equal(dd.view(np.uint32), fd.view(np.uint32)), rank
+# query rows sharded (2-NN): padded row shards, one all-gather
+for n in (0, 1, 7, 150):
+    full = (np.arange(n * 4, dtype=np.int32).reshape(n, 4) * 7) ^ 0x5a5a
+    lo, hi = sharding.shard_rows(n, rank, world)
+    got = sharding.gather_row_shards(full[lo:hi], n)
+    assert got.shape == (n, 4) and np.array_equal(got, full), (rank, n)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
-''' % ROOT
+''' % (ROOT, ROOT)
 
 
 def _free_port():
@@ -63,6 +83,25 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def test_shard_rows_partition():
+    for n in (0, 1, 7, 100000):
+        for w in (1, 2, 3, 8):
+            edges = [sharding.shard_rows(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def test_decode_keys():
+    none = np.uint64(0xFFFFFFFFFFFFFFFF)
+    keys = np.array([(np.uint64(25) << np.uint64(32)) | np.uint64(7), none, np.uint64(0)], dtype=np.uint64)
+    t, d = sharding.decode_keys(keys)
+    assert t.tolist() == [7, -1, 0] and d[0] == 5.0 and np.isinf(d[1]) and d[2] == 0.0
+    f = np.array([1.25], np.float32).view(np.uint32)[0]
+    t, d = sharding.decode_keys(np.array([(np.uint64(f) << np.uint64(32)) | np.uint64(3)], dtype=np.uint64), float32_route=True)
+    assert t.tolist() == [3] and d[0] == np.float32(1.25)
+    assert np.array_equal(sharding.reduce_keys(keys), keys)          # single process: identity
 
 
 def test_shard_items_partition():
