@@ -60,6 +60,7 @@ SYMBOLS = {
     "fm_host_free": (_INT, [_P, _P]),
     "fm_bank_create_u8": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
     "fm_bank_create_f32": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
+    "fm_bank_create_f32_route": (_INT, [_P, _P, _I64, _INT, ctypes.POINTER(_P)]),
     "fm_bank_destroy": (_INT, [_P, _P]),
     "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
@@ -230,14 +231,18 @@ class Context(object):
         return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     # -- banks -------------------------------------------------------------------------
-    def bank(self, rows):
+    def bank(self, rows, float_route=False):
         """Upload an [n, dim] uint8 or float32 matrix.  Other dtypes are converted to
-        float32 first (cv2 would reject them)."""
+        float32 first (cv2 would reject them).  ``float_route``: keep the float32 route even
+        if the values are integers (to pair with a bank that is not integer valued)."""
         a = np.asarray(rows)
         if a.ndim != 2:
             raise ValueError("descriptor bank must be 2-D [n, dim]")
         h = _P()
-        if a.dtype == np.uint8:
+        if float_route:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._check(self.lib.fm_bank_create_f32_route(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
+        elif a.dtype == np.uint8:
             a = np.ascontiguousarray(a)
             self._check(self.lib.fm_bank_create_u8(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
         else:

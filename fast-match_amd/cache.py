@@ -331,16 +331,17 @@ class Grid_Cache(object):
             return np.concatenate(descs), np.concatenate(poss), cell_off
         return np.zeros((0, 128), dtype=np.uint8), np.zeros((0, 2), dtype=np.float64), cell_off
 
-    def cell_bank(self, col, row, context):
-        """Device bank of the cell's descriptors (uploaded once), or None if it has none."""
-        key = (col, row)
+    def cell_bank(self, col, row, context, float_route=False):
+        """Device bank of the cell's descriptors (uploaded once), or None if it has none.
+        ``float_route``: the query bank is not integer valued, so the cell must not be either."""
+        key = (col, row, bool(float_route))
         if key not in self._banks:
             value = self.get_cell(col, row)
             ds = value[1] if isinstance(value, tuple) else None
             if ds is None or len(ds) == 0:
                 self._banks[key] = None
             else:
-                self._banks[key] = context.bank(np.asarray(ds))
+                self._banks[key] = context.bank(np.asarray(ds), float_route=float_route)
         return self._banks[key]
 
 

@@ -656,7 +656,7 @@ static void bank_free(Bank* b)
     b->rowsh = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
 
-static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out)
+static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out, bool keep_f32 = false)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_bank_create: ctx is NULL");
     if (!out) return fail(ctx, FM_EINVAL, "fm_bank_create: bank out pointer is NULL");
@@ -705,8 +705,8 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     int flag = 0;
     BTRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     BTRY(hipStreamSynchronize(ctx->stream));
-    if (f32 && flag) {
-        // not integer-valued: keep a float32 bank for the fma-chain route
+    if (f32 && (flag || (keep_f32 && n > 0))) {
+        // not integer-valued (or the caller wants the float32 route): keep a float32 bank for the fma-chain route
         b->kind = FM_BANK_F32;
         (void)hipFree(b->rows8); b->rows8 = nullptr;
         (void)hipFree(b->aux); b->aux = nullptr;
@@ -755,6 +755,11 @@ extern "C" int fm_bank_create_u8(fm_ctx* ctx, const uint8_t* rows, int64_t n, in
 extern "C" int fm_bank_create_f32(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank)
 {
     return bank_create(ctx, rows, n, dim, true, bank);
+}
+
+extern "C" int fm_bank_create_f32_route(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank)
+{
+    return bank_create(ctx, rows, n, dim, true, bank, true);
 }
 
 extern "C" int fm_bank_destroy(fm_ctx* ctx, fm_bank* bank)

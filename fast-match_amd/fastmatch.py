@@ -267,11 +267,18 @@ def match_thumbs(img, query_cache, thumb_x=400, thumb_y=400, context=None):
     if t_descriptors is None or len(t_descriptors) == 0 or len(q_thumb_pos) == 0:
         return np.zeros((0, 2, 2), dtype=np.float64), np.zeros(0, dtype=np.float64)
 
-    t_bank = context.bank(np.asarray(t_descriptors))
+    from . import _ffi
+    q_thumb = query_cache.thumb_bank(context)
+    t_bank = context.bank(np.asarray(t_descriptors), float_route=(q_thumb.kind == _ffi.FM_BANK_F32))
+    if t_bank.kind != q_thumb.kind:                # query thumbnail integer valued, target not: pair on the float route
+        q_thumb = context.bank(query_cache.thumb["descriptors"], float_route=True)
+        q_thumb.set_selfdist(query_cache.thumb["distances"])
     try:
-        tidx, dist, ratio, _, _ = context.match_ratio(query_cache.thumb_bank(context), t_bank, np.inf)
+        tidx, dist, ratio, _, _ = context.match_ratio(q_thumb, t_bank, np.inf)
     finally:
         t_bank.close()
+        if q_thumb is not query_cache.thumb_bank(context):
+            q_thumb.close()
     m = tidx >= 0                                 # non-empty inner lists, query order
     ratios = ratio[m]
     t_pos = np.asarray(t_thumb_pos, dtype=np.float64)[tidx[m]]
@@ -297,19 +304,25 @@ def _match_position(pos, query_cache, target, radius, context):
     target_kp, target_ds = target.get(target_x, target_y)
     if target_ds is None or len(target_ds) == 0:
         return empty
+    from . import _ffi
     col, row = target.block(target_x, target_y)
-    t_bank = target.cell_bank(col, row, context)
+    q_bank = query_cache.bank(context)
+    float_route = q_bank.kind == _ffi.FM_BANK_F32
+    t_bank = target.cell_bank(col, row, context, float_route=float_route)
     nq, nt = len(query_idx), len(target_ds)
     if nq == 0:
         return (np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64), 0)
     offset_x, offset_y = target.offset(target_x, target_y)
 
-    q_bank = query_cache.bank(context)
-    if nq <= 4096:
+    if nq <= 4096 and not float_route and t_bank.kind == _ffi.FM_BANK_I8:
         tidx, dist, ratio = context.xcheck1_batched(q_bank, query_idx, [0, nq], t_bank, [0, nt])
     else:
-        # oversize radius subset: gather it into a bank of its own and use the dense path
-        sub = context.bank(query_cache.original["descriptors"][query_idx])
+        # oversize radius subset, or descriptors that are not integer valued (the per-round
+        # kernel is int8 only): gather the subset into a bank of its own and use the dense path
+        if not float_route and t_bank.kind != _ffi.FM_BANK_I8:
+            t_bank = target.cell_bank(col, row, context, float_route=True)
+            float_route = True
+        sub = context.bank(query_cache.original["descriptors"][query_idx], float_route=float_route)
         try:
             sub.set_selfdist(query_cache.original["distances"][query_idx])
             tidx, dist, ratio, _, _ = context.match_ratio(sub, t_bank, np.inf)

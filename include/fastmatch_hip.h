@@ -79,6 +79,10 @@ int  fm_host_free(fm_ctx* ctx, void* ptr);
  * A query/train pair must have the same kind and dim (cv2 raises on dtype mismatch).    */
 int  fm_bank_create_u8 (fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, fm_bank** bank);
 int  fm_bank_create_f32(fm_ctx* ctx, const float*   rows, int64_t n, int dim, fm_bank** bank);
+/* Same, but the bank takes the float32 route even if every value happens to be an integer in
+ * 0..255: for banks that must pair with a non-integer bank (e.g. one Grid_Cache cell of a
+ * RootSIFT image whose values are all 0 or 1).  Distances are the same numbers either way.  */
+int  fm_bank_create_f32_route(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank);
 int  fm_bank_destroy(fm_ctx* ctx, fm_bank* bank);
 int  fm_bank_info(const fm_bank* bank, int64_t* n, int* dim, int* kind);
 /* Attach per-row self distances (Metric_Cache.*["distances"], float64, cache.pyx:252,273)

@@ -26,6 +26,11 @@ import numpy as np
 import oracle
 
 
+# float32 accumulation order for descriptors that are not integer valued (ignored otherwise):
+# 0 = OpenCV's unrolled-by-4 order, 1 = the fixed fma chain of the device's float32 route
+FLOAT_ORDER = 0
+
+
 class OGrid(object):
     """Grid geometry and lazily filled cells over a pre-extracted target."""
 
@@ -95,10 +100,10 @@ class OQuery(object):
         self.positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
         self.size = size
         # exact self 2-NN, r[1].distance (cache.pyx:250-252 / 271-273 made exact)
-        self.distances = oracle.self_dist(descriptors) if distances is None else np.asarray(distances, np.float64)
+        self.distances = oracle.self_dist(descriptors, order=FLOAT_ORDER) if distances is None else np.asarray(distances, np.float64)
         self.thumb = thumb
         if thumb is not None and "distances" not in thumb:
-            thumb["distances"] = oracle.self_dist(thumb["descriptors"])
+            thumb["distances"] = oracle.self_dist(thumb["descriptors"], order=FLOAT_ORDER)
 
     def get(self, x, y, radius):                             # cache.pyx:173-188
         x, y, radius = int(x), int(y), int(radius)
@@ -121,7 +126,7 @@ def o_match_position(pos, query, grid, radius=100):          # fastmatch.pyx:145
     t_pos = t_kp + np.array([ox, oy], dtype=np.float64)
     if len(q_idx) == 0:
         return np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64)
-    tidx, dist = oracle.bf_xcheck1(q_ds, t_ds)
+    tidx, dist = oracle.bf_xcheck1(q_ds, t_ds, order=FLOAT_ORDER)
     positions, ratios, indices = [], [], []
     for qi in range(len(tidx)):                              # knnMatch order = query order
         if tidx[qi] < 0:
@@ -168,7 +173,7 @@ def o_do_iter(seeds, query, grid, tau, radius=100, log=None):   # fastmatch.pyx:
 
 def o_match_thumbs(query, target_thumb, target_size):        # fastmatch.pyx:107-141
     q = query.thumb
-    tidx, dist = oracle.bf_xcheck1(q["descriptors"], target_thumb["descriptors"])
+    tidx, dist = oracle.bf_xcheck1(q["descriptors"], target_thumb["descriptors"], order=FLOAT_ORDER)
     m = np.nonzero(tidx >= 0)[0]
     ratios = dist[m].astype(np.float64) / q["distances"][m]
     t_pos = np.asarray(target_thumb["positions"], np.float64)[tidx[m]]

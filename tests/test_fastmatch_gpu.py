@@ -179,3 +179,33 @@ def test_evaluate_many_thresholds_reuses_state(ctx):
     totals = [r["total"] for r in dev]
     assert totals == sorted(totals) and totals[0] > 0
     assert dev[2]["precision"] > 0.7
+
+
+def test_match_on_non_integer_descriptors_takes_the_float_route(ctx, monkeypatch):
+    """RootSIFT-style (non-integer float32) descriptors: fastmatch.match() runs on the float32
+    route (host loop, one dense call per round) and equals the oracle's transcription with
+    the device's accumulation order."""
+    from fastmatch_amd import _ffi
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    q, t = synth.image_pair((640, 480), 2500, 777)
+
+    def root(d):
+        d = d.astype(np.float32)
+        return np.sqrt(d / np.maximum(d.sum(1, keepdims=True), 1)).astype(np.float32)
+
+    qd, td, qtd, ttd = root(q["descriptors"]), root(t["descriptors"]), root(q["thumb_descriptors"]), root(t["thumb_descriptors"])
+    mc = cache.Metric_Cache.from_arrays(qd, q["positions"], q["size"], qtd, q["thumb_positions"], q["thumb_size"],
+                                        options={"context": ctx})
+    assert mc.bank(ctx).kind == _ffi.FM_BANK_F32
+    fi = cache.Feature_Image(t["size"], t["positions"], td, t["thumb_positions"], ttd, t["thumb_size"])
+    oq = fo.OQuery(qd, q["positions"], q["size"],
+                   thumb={"descriptors": qtd, "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
+          "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    assert np.array_equal(mc.original["distances"], oq.distances)
+    stats = {}
+    got = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})(0.8)
+    oget = fo.o_match(oq, ot, {})
+    exp = oget(0.8)
+    _same_matches(got, exp)
+    assert len(got) > 20 and stats["rounds"] == oget.rounds
