@@ -97,6 +97,19 @@ __device__ __forceinline__ bool found_insert(unsigned long long* tab, long long 
     return false;
 }
 
+// Single-writer insert-if-absent in one probe sequence: 1 = inserted, 0 = was present, -1 = full.
+__device__ __forceinline__ int set_insert_new(unsigned long long* tab, long long cap, unsigned long long key)
+{
+    long long p = (long long)(mix64(key) & (unsigned long long)(cap - 1));
+    for (long long n = 0; n < cap; ++n) {
+        const unsigned long long v = tab[p];
+        if (v == key) return 0;
+        if (v == ~0ull) { tab[p] = key; return 1; }
+        p = (p + 1) & (cap - 1);
+    }
+    return -1;
+}
+
 // Grid_Cache geometry (cache.pyx:95-99, 116-121, 72-92) in the reference's arithmetic:
 // float64 division / multiplication, int() truncation toward zero.
 __device__ __forceinline__ int blk(double v, int cell) { return (int)(v / (double)cell); }
@@ -255,8 +268,14 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int col = blk(e[3], P.cell_h), row = blk(e[2], P.cell_w);
                 const int qcol = blk(e[1], P.cell_h), qrow = blk(e[0], P.cell_w);
                 const unsigned long long key = pack4x16(col, row, qcol, qrow);
-                if (set_contains(P.seen, P.seen_cap, key)) continue;
-                if (2 * (seen_n + 1) > P.seen_cap || !set_insert(P.seen, P.seen_cap, key)) { status = kExpTableFull; break; }
+                if (2 * (seen_n + 1) > P.seen_cap) {                 // (only a NEW key needs room)
+                    if (set_contains(P.seen, P.seen_cap, key)) continue;
+                    status = kExpTableFull;
+                    break;
+                }
+                const int ins = set_insert_new(P.seen, P.seen_cap, key);
+                if (ins == 0) continue;
+                if (ins < 0) { status = kExpTableFull; break; }
                 ++seen_n;
                 for (int k = 0; k < 4; ++k) cur[k] = e[k];
                 sh_i[1] = col; sh_i[2] = row;
@@ -413,10 +432,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (sh_i[5]) { status = kExpStackFull; break; }
             if (sh_i[6]) { status = kExpMatchFull; break; }
             if (push) {
-                // a later chunk (k0 > 0) must end up BELOW this one: handled by pushing chunks
-                // into a per-round region whose size is known only at the end, so for more
-                // than 256 accepted matches the region is reversed afterwards (rare)
-                const long long dst = sh_top + po;
+                // The first accepted match must be popped first, i.e. sit on top.  One chunk
+                // (na <= 256, the usual case): write in reverse rank order.  More: chunks are
+                // written in ascending order and the whole region is reversed afterwards.
+                const long long dst = (na <= 256) ? sh_top + (ptot - 1 - po) : sh_top + po;
                 P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
                 P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
             }
@@ -434,9 +453,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             __syncthreads();
         }
         if (status != kExpOk) break;
-        // The pushed region [top_before, top) is in ascending slot order; the first accepted
-        // match must be popped first, i.e. sit on top: reverse the region in place.
-        {
+        // More than one chunk: the pushed region [top_before, top) is in ascending slot order;
+        // reverse it in place.
+        if (na > 256) {
             const long long lo = sh_i_top_before, hi = sh_top;
             const long long cntp = hi - lo;
             for (long long x = tid; x < cntp / 2; x += 256) {
