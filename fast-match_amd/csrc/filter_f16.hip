@@ -119,6 +119,11 @@ void filter_kernel(FParams p)
     const int split = blockIdx.x / p.nchunks;
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
+    const int st0 = split * p.stages_per_split;
+    const int st1 = min(st0 + p.stages_per_split, p.nstages);
+    // the first stage is in flight while the stationary operand is loaded
+    if (st0 < st1) f_issue_stage<NW>(p, st0, smem, wave, lane);
+
     // Stationary operand: NC x 16 output rows, 4 K-steps of 32.
     v8h bh[NC][4];
     float marg[NC];
@@ -187,9 +192,6 @@ void filter_kernel(FParams p)
         }
     };
 
-    const int st0 = split * p.stages_per_split;
-    const int st1 = min(st0 + p.stages_per_split, p.nstages);
-
     // per-lane LDS offsets of the A fragments: row c16 (+16 for the second tile), chunk (4s+g) ^ c16
     int aoff[4];
 #pragma unroll
@@ -211,7 +213,6 @@ void filter_kernel(FParams p)
         for (int s = 0; s < 4; ++s) fs[set][s] = __builtin_bit_cast(v8h, *(const v4i*)(rows + aoff[s]));
     };
     if (st0 < st1) {
-        f_issue_stage<NW>(p, st0, smem, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st0 + 1 < st1) f_issue_stage<NW>(p, st0 + 1, smem + kFStageBytes, wave, lane);
@@ -459,7 +460,7 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
     const int64_t nstages = nred_pad / kFStageRows;
-    int64_t want = 6 * 256 * (16 / pl.nw);            // ~6 rounds of the workgroups the chip holds
+    int64_t want = 5 * 256 * (8 / pl.nw);             // ~5 rounds of the workgroups the chip holds (2 / CU at nw = 4)
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nstages / 4) nsplit = nstages / 4;     // >= 512 rows per split
     if (nsplit < 1) nsplit = 1;
