@@ -260,14 +260,22 @@ __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ par
                                       int ncols_alloc, int64_t nt,
                                       unsigned long long* __restrict__ qbest, unsigned t_offset = 0)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
+    // four lanes per train row, each takes every 4th split: short independent load chains
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = gid >> 2;
+    const int part = (int)(gid & 3);
     unsigned long long b = ~0ull;
-    for (int s = 0; s < nsplit; ++s) {
-        const unsigned long long v = partial[(size_t)s * ncols_alloc + t];
-        b = v < b ? v : b;
+    if (t < nt) {
+        for (int s = part; s < nsplit; s += 4) {
+            const unsigned long long v = partial[(size_t)s * ncols_alloc + t];
+            b = v < b ? v : b;
+        }
     }
-    if (b == ~0ull) return;
+    unsigned long long o = __shfl_xor(b, 1);
+    b = o < b ? o : b;
+    o = __shfl_xor(b, 2);
+    b = o < b ? o : b;
+    if (t >= nt || part != 0 || b == ~0ull) return;
     const unsigned q = (unsigned)b;
     // (t_offset: global index of this bank's first row when the train set is sharded over ranks)
     const unsigned long long key = (b & 0xffffffff00000000ull) | (unsigned long long)((unsigned)t + t_offset);
@@ -1023,7 +1031,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
-        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -1121,7 +1129,7 @@ extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
-        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, (unsigned)t_offset);
         HIP_TRY(ctx, hipGetLastError());
     }
