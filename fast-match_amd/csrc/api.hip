@@ -579,10 +579,23 @@ __global__ void copy_out_kernel(unsigned char* __restrict__ dst, const unsigned 
 // runtime pin the destination pages for the transfer (milliseconds for results of ~100 KB and
 // up), so such results land in the context's own page-locked staging buffer and are moved to
 // the caller by CallScope::finish() after the call's single synchronisation.
+static hipError_t copy_out(fm_ctx* ctx, unsigned char* dst_alias, const void* src, size_t bytes)
+{
+    const unsigned grid = (unsigned)((bytes / 4 + 255) / 256 < 1024 ? (bytes / 4 + 255) / 256 + 1 : 1024);
+    hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, ctx->stream, dst_alias, (const unsigned char*)src, bytes);
+    return hipGetLastError();
+}
+
 static hipError_t d2h(fm_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     if (bytes == 0) return hipSuccess;
-    if (bytes >= 4096 && bytes <= ((size_t)256 << 20) && !pinned_device_alias(dst)) {
+    // A copy kernel rather than hipMemcpyAsync for anything but tiny results: the runtime hands
+    // device-to-host copies of 64 KiB and more to a DMA queue behind a host-side wait for the
+    // stream, which was seen to add 1-7 ms of idle time after multi-millisecond kernels.
+    const bool kernel_ok = bytes >= 4096 && bytes <= ((size_t)256 << 20) && ((uintptr_t)src & 3) == 0;
+    if (kernel_ok) {
+        if (unsigned char* direct = (unsigned char*)pinned_device_alias(dst))       // page-locked destination
+            return copy_out(ctx, direct, src, bytes);
         size_t off = (ctx->h_stage_used + 63) & ~(size_t)63;
         if (off + bytes > ctx->h_stage_bytes && ctx->staged.empty()) {
             if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -594,22 +607,13 @@ static hipError_t d2h(fm_ctx* ctx, void* dst, const void* src, size_t bytes)
             off = 0;
         }
         if (ctx->h_stage && off + bytes <= ctx->h_stage_bytes) {
-            // A copy kernel rather than hipMemcpyAsync: the runtime hands device-to-host copies of
-            // this size to a DMA queue behind a host-side wait for the stream, which was seen to
-            // add 1-7 ms of idle time after multi-millisecond kernels.
-            hipError_t e = hipSuccess;
-            unsigned char* alias = (((uintptr_t)src & 3) == 0) ? (unsigned char*)pinned_device_alias(ctx->h_stage + off) : nullptr;
-            if (alias) {
-                const unsigned grid = (unsigned)((bytes / 4 + 255) / 256 < 1024 ? (bytes / 4 + 255) / 256 + 1 : 1024);
-                hipLaunchKernelGGL(copy_out_kernel, dim3(grid), dim3(256), 0, ctx->stream, alias, (const unsigned char*)src, bytes);
-                e = hipGetLastError();
-            } else {
-                e = hipMemcpyAsync(ctx->h_stage + off, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (unsigned char* alias = (unsigned char*)pinned_device_alias(ctx->h_stage + off)) {
+                hipError_t e = copy_out(ctx, alias, src, bytes);
+                if (e != hipSuccess) return e;
+                ctx->staged.push_back({dst, off, bytes});
+                ctx->h_stage_used = off + bytes;
+                return hipSuccess;
             }
-            if (e != hipSuccess) return e;
-            ctx->staged.push_back({dst, off, bytes});
-            ctx->h_stage_used = off + bytes;
-            return hipSuccess;
         }
     }
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);

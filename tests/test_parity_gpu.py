@@ -528,3 +528,23 @@ def test_train_sharded_crosscheck_keys_reduce_to_the_unsharded_result(ctx, as_f3
     i2, d2 = sharding.knn2_sharded(ctx, qb, ctx.bank(T), 700)
     oi, od = ctx.knn2(qb, ctx.bank(T))
     assert _eq(i2, oi) and _eq(d2, od)
+
+
+def test_results_into_page_locked_buffers_and_offsets_into_them(ctx):
+    """Outputs in page-locked caller memory are written by the library's copy kernel through
+    the buffer's device alias -- also when the pointer is an offset into the allocation."""
+    Q, T, _ = synth.planted_pair(3000, 3500, seed=91)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    qb.set_selfdist(ctx.self_dist(qb))
+    ref = ctx.match_ratio(qb, tb, 0.7)
+    n = qb.n
+    big = (ctx.pinned_empty(n + 9, np.int32), ctx.pinned_empty(n + 9, np.float32),
+           ctx.pinned_empty(n + 9, np.float64), ctx.pinned_empty(n + 13, np.uint8))
+    for a in big:
+        a[...] = 0x55 if a.dtype != np.float64 else -7.0
+    out = (big[0][9:], big[1][9:], big[2][9:], big[3][13:])
+    got = ctx.match_ratio(qb, tb, 0.7, out=out)
+    assert _eq(got[0], ref[0]) and _eq(got[1], ref[1]) and np.array_equal(got[3].astype(bool), ref[3]) and got[4] == ref[4]
+    m = ref[0] >= 0
+    assert _eq(got[2][m], ref[2][m])
+    assert (big[0][:9] == 0x55).all() and (big[3][:13] == 0x55).all() and (big[2][:9] == -7.0).all()   # nothing before the offset touched
