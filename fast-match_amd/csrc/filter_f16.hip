@@ -105,7 +105,7 @@ __device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char*
 }
 
 template <int NC, int KTOP, int NW>
-__global__ __launch_bounds__(64 * NW, (NC <= 2 ? 4 : 2))
+__global__ __launch_bounds__(64 * NW, 2)
 void filter_kernel(FParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes];
@@ -453,8 +453,7 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
     FilterPlan pl;
     pl.nw = 4;
     if (const char* e = getenv("FM_F32_NW")) { const int v = atoi(e); if (v == 4 || v == 8) pl.nw = v; }
-    pl.nc = 4;
-    if (const char* e = getenv("FM_F32_NC")) { const int v = atoi(e); if (v == 2 || v == 4) pl.nc = v; }
+    pl.nc = 4;                                        // (NC = 2 at 4 waves/SIMD was tried: it spills)
     const int cb = 16 * pl.nc * pl.nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
@@ -520,8 +519,7 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
         if (ktop == 1) hipLaunchKernelGGL((filter_kernel<NC_, 1, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
         else           hipLaunchKernelGGL((filter_kernel<NC_, 2, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
     } while (0)
-    if (pl.nc == 2) { if (pl.nw == 8) FM_LAUNCH_FILTER(2, 8); else FM_LAUNCH_FILTER(2, 4); }
-    else            { if (pl.nw == 8) FM_LAUNCH_FILTER(4, 8); else FM_LAUNCH_FILTER(4, 4); }
+    if (pl.nw == 8) FM_LAUNCH_FILTER(4, 8); else FM_LAUNCH_FILTER(4, 4);
 #undef FM_LAUNCH_FILTER
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
