@@ -538,18 +538,21 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     r.partial = partial;
     r.flag = flag;
     if (cols.n > 0) {
-        const bool narrow = pl.nsplit * 4 * kFP <= 32;
-        const int lpc = narrow ? 16 : 64;
+        // lanes per output row: few slots and many rows -> one lane each (every lane of a wave
+        // then runs a chain), else 16 or 64 lanes share a row's slots
+        const int nslots = pl.nsplit * 4 * kFP;
+        int lpc = nslots <= 32 ? (cols.n >= 65536 ? 1 : 16) : 64;
+        if (const char* e = getenv("FM_F32_LPC")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 64) lpc = v; }
         const int rgrid = (int)((cols.n * lpc + 255) / 256);
-        if (ktop == 1) {
-            if (narrow) hipLaunchKernelGGL((rescore_kernel<1, 16>), dim3(rgrid), dim3(256), 0, stream, r);
-            else        hipLaunchKernelGGL((rescore_kernel<1, 64>), dim3(rgrid), dim3(256), 0, stream, r);
-            hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
-        } else {
-            if (narrow) hipLaunchKernelGGL((rescore_kernel<2, 16>), dim3(rgrid), dim3(256), 0, stream, r);
-            else        hipLaunchKernelGGL((rescore_kernel<2, 64>), dim3(rgrid), dim3(256), 0, stream, r);
-            hipLaunchKernelGGL((rescan_kernel<2>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);
-        }
+#define FM_LAUNCH_RESCORE(K_)                                                                                  \
+        do {                                                                                                   \
+            if (lpc == 1)       hipLaunchKernelGGL((rescore_kernel<K_, 1>), dim3(rgrid), dim3(256), 0, stream, r);  \
+            else if (lpc == 16) hipLaunchKernelGGL((rescore_kernel<K_, 16>), dim3(rgrid), dim3(256), 0, stream, r); \
+            else                hipLaunchKernelGGL((rescore_kernel<K_, 64>), dim3(rgrid), dim3(256), 0, stream, r); \
+            hipLaunchKernelGGL((rescan_kernel<K_>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);   \
+        } while (0)
+        if (ktop == 1) FM_LAUNCH_RESCORE(1); else FM_LAUNCH_RESCORE(2);
+#undef FM_LAUNCH_RESCORE
     }
     return hipGetLastError();
 }

@@ -548,3 +548,19 @@ def test_results_into_page_locked_buffers_and_offsets_into_them(ctx):
     m = ref[0] >= 0
     assert _eq(got[2][m], ref[2][m])
     assert (big[0][:9] == 0x55).all() and (big[3][:13] == 0x55).all() and (big[2][:9] == -7.0).all()   # nothing before the offset touched
+
+
+@pytest.mark.parametrize("lpc", ["1", "16", "64"])
+def test_f32_filter_rescoring_layouts_agree(filter_ctx, monkeypatch, lpc):
+    """The three lane layouts of the rescoring kernel (picked by shape in production) give the
+    same bits."""
+    monkeypatch.setenv("FM_F32_LPC", lpc)
+    Q, T = _f32_kind("rootsift", 2500, 3100, 77)
+    Q[7] = T[3]; T[9] = T[3]                                # exact zero distance, duplicate train rows
+    qb, tb = filter_ctx.bank(Q), filter_ctx.bank(T)
+    idx, dist = filter_ctx.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
+    assert _eq(idx, oidx) and _eq(dist, odist)
+    tidx, xd = filter_ctx.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T, order=1)
+    assert _eq(tidx, otidx) and _eq(xd, oxd)
