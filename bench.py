@@ -192,11 +192,11 @@ def main():
         k_ms = st["kernel_ms"] / max(st["kernel_launches"], 1)
         call_ms = st["total_ms"] / max(st["calls"], 1)
         achieved = pairs_per_step * OPS_PER_PAIR / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc = None, None, {}
         try:        # HBM bytes per K1 launch from the committed rocprofv3 PMC passes (not live)
             with open(PROFILE_JSON) as f:
-                pj = json.load(f)
-            traffic, traffic_src = pj["hbm_bytes_per_launch"], pj["source"]
+                pmc = json.load(f)
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], pmc["source"]
         except Exception:
             pass
         out = {
@@ -221,7 +221,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fm::rowreduce_kernel<4,1,true,8> (v_mfma_i32_16x16x64_i8)", "kernel_ms": k_ms,
-                         "note": "int8 ops: 256 per descriptor pair; HIP-event time of the K1 launch on its own stream"},
+                         "hbm_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac_of_8tbps": (traffic / (k_ms * 1e-3) / 8e12) if traffic else None,
+                         "mfma_pipe_busy_frac": pmc.get("mfma_pipe_busy_frac"),
+                         "note": "int8 ops: 256 per descriptor pair; HIP-event time of the K1 launch on its own stream; "
+                                 "hbm_gbps = PMC HBM bytes per launch / that time; mfma_pipe_busy_frac = rocprofv3 "
+                                 "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU cycles of the launch (profiles/)"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
                          "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},
             "classic_ratio_match": crm,

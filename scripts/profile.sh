@@ -42,9 +42,14 @@ def mean_of(fn, counter):
         return None
 fs, ws = mean_of("pmc_fetch_summary.csv", "FETCH_SIZE"), mean_of("pmc_write_summary.csv", "WRITE_SIZE")
 if fs is not None and ws is not None:
-    json.dump({"hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "fetch_size_kib_raw": fs, "write_size_kib": ws,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile.sh), FETCH_SIZE x2 gfx950 correction"},
-              open("latest_pmc.json", "w"))
+    d = {"hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0, "fetch_size_kib_raw": fs, "write_size_kib": ws,
+         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (scripts/profile.sh), FETCH_SIZE x2 gfx950 correction"}
+    mb, ga = mean_of("pmc_sq1_summary.csv", "SQ_VALU_MFMA_BUSY_CYCLES"), mean_of("pmc_sq2_summary.csv", "GRBM_GUI_ACTIVE")
+    if mb and ga:       # MFMA busy cycles are summed over 1024 SIMDs, GPU-active cycles over 8 XCDs
+        d.update({"mfma_busy_cycles_per_simd": mb / 1024, "gpu_cycles_per_launch": ga / 8,
+                  "mfma_pipe_busy_frac": (mb / 1024) / (ga / 8),
+                  "pmc_source": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (separate rocprofv3 --pmc passes)"})
+    json.dump(d, open("latest_pmc.json", "w"))
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     os.system("cp %s %s/kernel_stats.csv" % (f, out))
 PY
