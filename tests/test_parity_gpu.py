@@ -564,3 +564,36 @@ def test_f32_filter_rescoring_layouts_agree(filter_ctx, monkeypatch, lpc):
     tidx, xd = filter_ctx.xcheck1(qb, tb)
     otidx, oxd = oracle.bf_xcheck1(Q, T, order=1)
     assert _eq(tidx, otidx) and _eq(xd, oxd)
+
+
+def test_full_size_float32_route_config5(monkeypatch):
+    """BASELINE config 5 at full size (10k queries vs a 1M-row non-integer float32 bank): the
+    fp16-MFMA filter route (K8) and the all-pairs kernel (K5) return the same bits for 2-NN and
+    cross-check, 64 random query rows agree with the oracle, and the size-independent properties
+    of a k-NN result hold (sorted pairs, indices in range, idempotent)."""
+    import fastmatch_amd
+    rng = np.random.default_rng(20250005)
+    NT, NQ = 1000000, 10000
+    T = synth.synth_sift(NT, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (NT, 128)).astype(np.float32)
+    Q = synth.synth_sift(NQ, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (NQ, 128)).astype(np.float32)
+    Q[:2000] = T[rng.choice(NT, 2000, replace=False)] + rng.normal(0, 3, (2000, 128)).astype(np.float32)   # planted near twins
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("FM_F32_FILTER", mode)
+        c = fastmatch_amd.Context(0)
+        qb, tb = c.bank(Q), c.bank(T)
+        res[mode] = (c.knn2(qb, tb), c.xcheck1(qb, tb))
+        if mode == "2":
+            again = c.knn2(qb, tb)
+            assert _eq(again[0], res[mode][0][0]) and _eq(again[1], res[mode][0][1])          # idempotent
+            launches, redone = c.f32_filter_stats()
+            assert launches == 3 and redone == 0
+        c.close()
+    (i8, d8), (t8, x8) = res["2"]
+    (i5, d5), (t5, x5) = res["0"]
+    assert _eq(i8, i5) and _eq(d8, d5) and _eq(t8, t5) and _eq(x8, x5)
+    assert i8.min() >= 0 and i8.max() < NT and np.all(d8[:, 0] <= d8[:, 1])
+    assert (t8 >= 0).sum() > 1500                                                              # the planted twins cross-check
+    rows = rng.choice(NQ, 64, replace=False)
+    oi, od = oracle.bf_knn(Q[rows], T, 2, order=1)
+    assert _eq(i8[rows], oi) and _eq(d8[rows], od)
