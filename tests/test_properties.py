@@ -79,3 +79,53 @@ def test_hip_equals_oracle_on_random_tie_heavy_inputs(ctx, s):
         bt, bd, _ = ctx.xcheck1_batched(qb, rows, [0, len(rows)], tb, [lo, nt])
         et, ed = oracle.bf_xcheck1(Q[rows], T[lo:nt])
         assert np.array_equal(bt, et) and np.array_equal(bd.view(np.uint32), ed.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def filter_ctx_module():
+    import os
+    import fastmatch_amd
+    old = os.environ.get("FM_F32_FILTER")
+    os.environ["FM_F32_FILTER"] = "2"                      # the fp16-MFMA filter for every float32 call
+    c = fastmatch_amd.Context(0)
+    yield c
+    c.close()
+    if old is None:
+        del os.environ["FM_F32_FILTER"]
+    else:
+        os.environ["FM_F32_FILTER"] = old
+
+
+@pytest.mark.gpu
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(st.tuples(st.integers(1, 400), st.integers(1, 400), st.sampled_from([1, 3, 32, 100, 128]),
+                 st.sampled_from(["gauss", "levels", "twins"]), st.integers(-40, 40), st.integers(-3, 3),
+                 st.integers(0, 2**31 - 1)))
+def test_float32_filter_route_equals_oracle_on_random_inputs(filter_ctx_module, s):
+    """Non-integer float32 banks of random shape, magnitude (2^-40 .. 2^40, the two banks up to
+    2^3 apart), and tie structure: the filter route (rescoring, per-row rescan or whole-call
+    redo, whichever a case needs) returns the oracle's bits."""
+    c = filter_ctx_module
+    nq, nt, dim, kind, e, de, seed = s
+    rng = np.random.default_rng(seed)
+    if kind == "gauss":
+        Q, T = rng.normal(0, 1, (nq, dim)), rng.normal(0, 1, (nt, dim))
+    elif kind == "levels":                                  # few distinct non-integer values: exact ties everywhere
+        lv = rng.normal(0, 1, 4)
+        Q, T = lv[rng.integers(0, 4, (nq, dim))], lv[rng.integers(0, 4, (nt, dim))]
+    else:                                                   # train rows that are tiny perturbations of query rows
+        Q = rng.normal(0, 1, (nq, dim))
+        T = Q[rng.integers(0, nq, nt)] + rng.normal(0, 1e-3, (nt, dim))
+    Q = np.ldexp(Q, e).astype(np.float32)
+    T = np.ldexp(T, e + de).astype(np.float32)
+    Q[0, 0] += np.float32(np.ldexp(0.37, e))                # (never integer valued)
+    T[0, 0] += np.float32(np.ldexp(0.37, e + de))
+    qb, tb = c.bank(Q), c.bank(T)
+    if qb.kind != tb.kind:
+        return                                              # an all-integer bank by accident: not this route
+    idx, dist = c.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2, order=1)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    tidx, xd = c.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T, order=1)
+    assert np.array_equal(tidx, otidx) and np.array_equal(xd.view(np.uint32), oxd.view(np.uint32))
