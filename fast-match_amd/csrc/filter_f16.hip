@@ -217,6 +217,9 @@ void filter_kernel(FParams p)
         __syncthreads();
         if (st0 + 1 < st1) f_issue_stage<NW>(p, st0 + 1, smem + kFStageBytes, wave, lane);
         load_tile(0, smem, 0);
+        // bounds other workgroups have published already (loaded at the top) apply from the first tile on
+#pragma unroll
+        for (int j = 0; j < NC; ++j) thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
     }
 
     v4f acc[2][NC];
