@@ -463,9 +463,17 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
     pl.ncols_alloc = pl.nchunks * cb;
     const int64_t nstages = nred_pad / kFStageRows;
     int64_t want = 5 * 256 * (8 / pl.nw);             // ~5 rounds of the workgroups the chip holds (2 / CU at nw = 4)
+    // a workgroup should sweep >= 64 stages (8192 rows: prologue and cold thresholds amortised),
+    // unless that leaves fewer workgroups than the chip holds; never fewer than 4 stages
+    const int64_t slots = 256 * (8 / pl.nw);
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
-    if (nsplit > nstages / 4) nsplit = nstages / 4;     // >= 512 rows per split
+    if (nsplit > nstages / 64) nsplit = nstages / 64;
     if (nsplit < 1) nsplit = 1;
+    if (nsplit * pl.nchunks < slots) {
+        nsplit = (slots + pl.nchunks - 1) / pl.nchunks;
+        if (nsplit > nstages / 4) nsplit = nstages / 4;
+        if (nsplit < 1) nsplit = 1;
+    }
     if (const char* e = getenv("FM_F32_NSPLIT")) { const int v = atoi(e); if (v > 0) nsplit = v; }
     if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
     int64_t per = (nstages + nsplit - 1) / nsplit;
