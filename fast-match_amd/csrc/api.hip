@@ -143,7 +143,9 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
         }
     }
     if constexpr (SRC_F32) {
-        if (bad) atomicOr(nonint, 1);
+        // one atomic per wave at most, and none once the flag is up (a bank that is not integer
+        // valued would otherwise send one atomic per element to the same address)
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (tid & 63) == 0 && *(volatile int*)nonint == 0) atomicOr(nonint, 1);
     }
 }
 
@@ -209,12 +211,16 @@ void bank_prep_f16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n_
         if (row < n) {
             normf[row] = nm;
             auxf[row] = -0.5f * nm;
-            atomicMax(stat, (int)__float_as_uint(nm));
         } else {
             normf[row] = 0.f;
             auxf[row] = -3.4e38f;
         }
     }
+    // max norm: one atomic per wave (4 rows), not per row
+    float m = (c == 0 && row < n) ? (float)ss : 0.f;
+#pragma unroll
+    for (int mask = 16; mask < 64; mask <<= 1) m = fmaxf(m, __shfl_xor(m, mask));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(stat, (int)__float_as_uint(m));
 }
 
 // ---------------------------------------------------------------------------------------
