@@ -2,19 +2,28 @@
 """bench.py -- throughput of the descriptor-matching hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; a bare
+   `python bench.py --gpus N` starts those N ranks itself as a child process)
 
 Workload (BASELINE.json configs[1]): 100k x 100k synthetic 128-D uint8 SIFT descriptors,
-one independent image pair per GPU (weak scaling; SURVEY.md 8(d) C2, seed 20250002+rank).
-A step = one pass of the hot path over that pair with both banks already resident in HBM:
-cross-checked 1-NN (OpenCV BFMatcher crossCheck semantics) + float64 ratio test at
-tau = 0.7 against the query bank's self distances, accepted matches compacted on the device
-(fm_match_accepted), copied back to the host and, for N > 1, all-gathered over RCCL.
-Prints ONE JSON line (rank 0).
+brute-force cross-checked 1-NN + ratio test.  Every GPU holds a batch of PAIRS_PER_STEP
+independent image pairs (distinct banks, all resident in HBM before the timed region; weak
+scaling: the batch per GPU is fixed as N grows; SURVEY.md 8(d) C2, seed 20250002 + rank).
+A step = one pass of the hot path over that batch: per pair, cross-checked 1-NN (OpenCV
+BFMatcher crossCheck semantics) + float64 ratio test at tau = 0.7 against the query bank's
+self distances + ordered compaction of the accepted matches on the device.  N = 1: the
+accepted matches land in caller-owned page-locked host buffers (fm_match_accepted); N > 1:
+they stay on the device as packed 12-byte rows (fm_match_accepted_dev) and go straight into
+the RCCL all-gather, overlapped with the next pair's kernels.
+Prints ONE JSON line (rank 0).  Beside the headline it carries legs for the other BASELINE
+configs: `classic_ratio_match` and `self_2nn` (configs[1] read literally / Metric_Cache build),
+`expand_c3` (configs[2]), `expand_c4` (configs[3]), `float32_route` (configs[4]).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,9 +36,21 @@ if ROOT not in sys.path:
 NQ = NT = 100000
 TAU = 0.7
 SEED = 20250002
+PAIRS_PER_STEP = 10               # independent 100k x 100k pairs per GPU and step (timed region >= 0.2 s at 20 steps)
 PROFILE_JSON = os.path.join(ROOT, "profiles", "latest_pmc.json")   # written by scripts/profile.sh
+K1_SOURCES = ("fast-match_amd/csrc/rowreduce.hip", "fast-match_amd/csrc/tile_ops.h")
 INT8_DENSE_PEAK_TOPS = 5000.0     # MI355X dense int8 MFMA (2x bf16's ~2.5 PF), MI355X_MICROARCH.md
 OPS_PER_PAIR = 256                # 128 MACs per 128-D descriptor pair
+
+
+def k1_source_hash():
+    """SHA-256 over the sources of the dominant kernel; scripts/profile.sh stores the same hash
+    next to the PMC counters so that stale counters are never attached to a changed kernel."""
+    h = hashlib.sha256()
+    for rel in K1_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def cpu_baseline(Q, T, budget_s=12.0):
@@ -47,21 +68,136 @@ def cpu_baseline(Q, T, budget_s=12.0):
     oracle.bf_xcheck1(Q[:s], T, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": s * len(T) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "oracle bf_xcheck1 (C, OpenMP) on the first %d of %d query rows x all %d target rows, %.1f s"
+            "sample": "oracle bf_xcheck1 (C, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s"
                       % (s, len(Q), len(T), dt)}
+
+
+def derived_pair(Q, T, j, rng):
+    """Pair j of the batch: rows of pair 0 permuted and the 128 dimensions rolled by 8 j --
+    different banks in memory, the same distribution of distances and accepted matches."""
+    if j == 0:
+        return Q, T
+    pq, pt = rng.permutation(len(Q)), rng.permutation(len(T))
+    return np.ascontiguousarray(np.roll(Q[pq], 8 * j, axis=1)), np.ascontiguousarray(np.roll(T[pt], 8 * j, axis=1))
+
+
+def build_image_pair(ctx, size, n, seed, n_thumb):
+    from fastmatch_amd import synth, cache
+    q, t = synth.image_pair(size, n, seed, n_thumb=n_thumb)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    return mc, fi
+
+
+def leg_expand_c3(ctx, reps=3):
+    """BASELINE.json configs[2]: one 24-MP image pair (6000 x 4000, 300k keypoints per side,
+    default options), fastmatch.match()(0.7) through the device-resident expansion loop."""
+    from fastmatch_amd import fastmatch
+    t0 = time.perf_counter()
+    mc, fi = build_image_pair(ctx, (6000, 4000), 300000, 20250003, 2000)
+    setup_s = time.perf_counter() - t0
+    stats = {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats, "return_arrays": True})
+    get(TAU)                                            # builds the expander, warms the module
+    best = None
+    for _ in range(reps):
+        stats.clear()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        index, pos, ratio = get(TAU)
+        wall = time.perf_counter() - t0
+        k_ms = ctx.stats()["kernel_ms"]
+        if best is None or wall < best[0]:
+            best = (wall, k_ms, stats.get("rounds", 0), stats.get("pairs", 0), len(index))
+    wall, k_ms, rounds, pairs, nm = best
+    return {"workload": "BASELINE configs[2]: 6000x4000 pair, 300k keypoints/side, grid 50, margin 25, radius 100, tau 0.7",
+            "wall_s": wall, "rounds": rounds, "descriptor_pairs": pairs, "matches": nm,
+            "rounds_per_s": rounds / wall, "pairs_per_s": pairs / wall, "matches_per_s": nm / wall,
+            "kernel_ms": k_ms, "frac_wall_in_kernels": k_ms * 1e-3 / wall, "device_loop": rounds > 0,
+            "setup_s": setup_s,
+            "note": "fm_expand_run (K7): exact depth-first replay of do_iter on the device, results fetched to the host; "
+                    "pairs = sum over rounds of nq_i x nt_i"}
+
+
+def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=64, reps=3):
+    """BASELINE.json configs[3]: 64 independent 1-MP pairs (1000 x 1000, 12.5k keypoints per
+    side) sharded over the ranks (pair i -> rank i mod N), one launch per rank, one
+    variable-length all-gather of the match rows."""
+    import torch
+    import torch.distributed as dist
+    from fastmatch_amd import fastmatch, sharding
+    mine = sharding.shard_items(n_pairs, rank, world)
+    t0 = time.perf_counter()
+    pairs = [build_image_pair(ctx, (1000, 1000), 12500, 20250100 + i, 600) for i in mine]
+    setup_s = time.perf_counter() - t0
+    prepared, stats = [], {}
+    fastmatch.match_many(pairs, TAU, {"context": ctx, "prepared_out": prepared, "return_arrays": True})
+    tdev = dev if backend == "nccl" else "cpu"
+    best = None
+    for _ in range(reps):
+        stats.clear()
+        ctx.reset_stats()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = fastmatch.match_many(pairs, TAU, {"context": ctx, "prepared": prepared, "stats": stats, "return_arrays": True})
+        rows = [sharding.pack_matches(np.full(len(r[0]), i, np.int32), r[0], r[2].astype(np.float32))
+                for i, r in zip(mine, res)]
+        packed = np.concatenate(rows) if rows else np.zeros((0, 3), np.int32)
+        gathered = sharding.all_gather_matches(packed, device=tdev)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        k_ms = ctx.stats()["kernel_ms"]
+        tot = torch.tensor([float(stats.get("rounds", 0)), float(stats.get("pairs", 0)), float(len(packed))],
+                           dtype=torch.float64, device=tdev)
+        tm = torch.tensor([wall, k_ms], dtype=torch.float64, device=tdev)
+        if world > 1:
+            dist.all_reduce(tot)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        wall, k_ms = float(tm[0].item()), float(tm[1].item())
+        assert sum(len(g) for g in gathered) == int(tot[2].item())
+        if best is None or wall < best[0]:
+            best = (wall, k_ms, int(tot[0].item()), int(tot[1].item()), int(tot[2].item()))
+    wall, k_ms, rounds, npairs, nm = best
+    return {"workload": "BASELINE configs[3]: %d x (1000x1000 pair, 12.5k keypoints/side), pair i -> rank i mod %d, tau 0.7"
+                        % (n_pairs, world),
+            "n_gpus": world, "scaling": "strong", "wall_s": wall, "rounds": rounds, "descriptor_pairs": npairs,
+            "matches": nm, "rounds_per_s": rounds / wall, "pairs_per_s": npairs / wall, "matches_per_s": nm / wall,
+            "image_pairs_per_s": n_pairs / wall, "kernel_ms": k_ms, "frac_wall_in_kernels": k_ms * 1e-3 / wall,
+            "setup_s": setup_s,
+            "note": "fastmatch.match_many: one fm_expand_run launch per rank (one workgroup per image pair) + "
+                    "all-gather of (pair, query index, ratio) rows; wall = max over ranks, best of %d" % reps}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # started bare: launch the N ranks as a CHILD process (nothing here has touched the
+            # GPU yet, and a process that has must never exec) and pass its exit code on
+            port = 29500 + os.getpid() % 2000
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run "
+                         "--nproc-per-node %d\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
     # FM_BENCH_BACKEND=gloo + FM_BENCH_SINGLE_DEVICE=1: dry-run of the N > 1 code path on a
@@ -79,37 +215,54 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
+    legs = not args.no_legs
 
     import fastmatch_amd
     from fastmatch_amd import synth, sharding
     ctx = fastmatch_amd.Context(local_rank)
 
-    # one independent pair per rank, resident in HBM before the timed region
+    # the batch of independent pairs of this rank, resident in HBM before the timed region
     Q, T, planted = synth.planted_pair(NQ, NT, seed=SEED + rank)
-    qb, tb = ctx.bank(Q), ctx.bank(T)
-    selfdist = ctx.self_dist(qb)                        # Metric_Cache build (once per query image)
-    ctx.reset_stats()
-    t0 = time.perf_counter()
-    ctx.self_dist(qb)                                   # timed second run (first one pays module load)
-    self_s = time.perf_counter() - t0
-    self_kernel_ms = ctx.stats()["kernel_ms"]
-    qb.set_selfdist(selfdist)
+    rng = np.random.default_rng(SEED + 1000 + rank)
+    banks = []
+    self_s = self_kernel_ms = None
+    for j in range(PAIRS_PER_STEP):
+        Qj, Tj = derived_pair(Q, T, j, rng)
+        qb, tb = ctx.bank(Qj), ctx.bank(Tj)
+        selfdist = ctx.self_dist(qb)                    # Metric_Cache build (once per query image)
+        if j == 1 or (j == 0 and PAIRS_PER_STEP == 1):  # timed on a later run (the first pays module load)
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            ctx.self_dist(qb)
+            self_s = time.perf_counter() - t0
+            self_kernel_ms = ctx.stats()["kernel_ms"]
+        qb.set_selfdist(selfdist)
+        banks.append((qb, tb))
+        del Qj, Tj
 
-    # caller-owned output buffers in page-locked memory (results arrive by direct DMA)
+    # N = 1: caller-owned output buffers in page-locked memory (results arrive by direct DMA)
     outbuf = (ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
               ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64))
 
-    # N > 1: the all-gather of step i's accepted matches (RCCL, its own stream) overlaps the
-    # matching kernels of step i+1 (the library's stream); the last one is waited for inside
-    # the timed region.
-    gatherer = sharding.MatchGatherer(dev, capacity=NQ) if world > 1 else None
+    # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
+    # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
+    # the timed region.  On GPUs the rows never leave HBM (fm_match_accepted_dev).
+    gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank)) if world > 1 else None
+    device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
 
     def step():
-        # X1 + R1 + ordered compaction of the accepted matches on the device (fm_match_accepted)
-        q_acc, t_acc, d_acc, r_acc = ctx.match_accepted(qb, tb, TAU, out=outbuf)
-        if gatherer is not None:
-            gatherer.submit(sharding.pack_matches(q_acc, t_acc, d_acc))
-        return len(q_acc)
+        n_acc = 0
+        for qb, tb in banks:
+            if device_gather:
+                rows, count = gatherer.send_buffers()
+                n_acc += ctx.match_accepted_dev(qb, tb, TAU, rows.data_ptr(), count.data_ptr(), NQ)
+                gatherer.submit_device()
+            else:
+                q_acc, t_acc, d_acc, r_acc = ctx.match_accepted(qb, tb, TAU, out=outbuf)
+                n_acc += len(q_acc)
+                if gatherer is not None:
+                    gatherer.submit(sharding.pack_matches(q_acc, t_acc, d_acc))
+        return n_acc
 
     def barrier():
         if world > 1:
@@ -141,62 +294,84 @@ def main():
     else:
         npass_all = npass
     st = ctx.stats()
+    qb, tb = banks[0]
 
     # Classic Ratio-Match (2-NN + d1/d2 < 0.7, the literal "2-NN + ratio" of configs[1]), reported
     # beside the headline; not part of the timed region above.
     crm = None
-    if rank == 0:
+    if rank == 0 and legs:
         ctx.knn2_ratio(qb, tb, TAU, out=outbuf)
         ctx.reset_stats()
         t0 = time.perf_counter()
-        reps = 5
+        reps = 20
         for _ in range(reps):
             cq, _, _, _ = ctx.knn2_ratio(qb, tb, TAU, out=outbuf)
         dt = (time.perf_counter() - t0) / reps
         crm = {"pairs_per_s": float(NQ) * NT / dt, "matches_per_s": len(cq) / dt, "accepted": int(len(cq)),
                "ms_per_call": 1e3 * dt, "kernel_ms": ctx.stats()["kernel_ms"] / reps,
+               "frac_int8_mfma_peak": float(NQ) * NT * OPS_PER_PAIR / (ctx.stats()["kernel_ms"] / reps * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
                "note": "fm_knn2_ratio: K2 top-2 + Lowe ratio + compaction, same banks"}
 
     # Float32 route (BASELINE.json configs[4]: 1M-row float32 target bank vs 10k-row query
     # batches): fm_knn2 on non-integer descriptors = K8 (fp16-MFMA filter + exact float32
     # rescoring).  Reported beside the headline at N = 1; FM_BENCH_F32=0 skips it.
     f32 = None
-    if rank == 0 and world == 1 and os.environ.get("FM_BENCH_F32", "1") != "0":
-        rng = np.random.default_rng(20250005)
+    if rank == 0 and world == 1 and legs and os.environ.get("FM_BENCH_F32", "1") != "0":
+        rng5 = np.random.default_rng(20250005)
         n_bank, n_query = 1000000, 10000
-        Tf = synth.synth_sift(n_bank, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (n_bank, 128)).astype(np.float32)
-        Qf = synth.synth_sift(n_query, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (n_query, 128)).astype(np.float32)
+        Tf = synth.synth_sift(n_bank, rng5).astype(np.float32) + rng5.uniform(-0.5, 0.5, (n_bank, 128)).astype(np.float32)
+        Qf = synth.synth_sift(n_query, rng5).astype(np.float32) + rng5.uniform(-0.5, 0.5, (n_query, 128)).astype(np.float32)
         tbf, qbf = ctx.bank(Tf), ctx.bank(Qf)
         del Tf
-        ctx.knn2(qbf, tbf)
-        ctx.reset_stats()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            ctx.knn2(qbf, tbf)
-        dt = (time.perf_counter() - t0) / reps
-        stf = ctx.stats()
-        kms = stf["kernel_ms"] / max(stf["kernel_launches"], 1)
+        f32 = {}
+        for name, fn in (("knn2", lambda: ctx.knn2(qbf, tbf)), ("xcheck1", lambda: ctx.xcheck1(qbf, tbf))):
+            fn()
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                fn()
+            dt = (time.perf_counter() - t0) / reps
+            stf = ctx.stats()
+            kms = stf["kernel_ms"] / max(stf["kernel_launches"], 1)
+            f32[name] = {"pairs_per_s": float(n_bank) * n_query / (kms * 1e-3), "kernel_ms": kms, "ms_per_call": 1e3 * dt,
+                         "frac_fp16_mfma_peak": float(n_bank) * n_query * 256 / (kms * 1e-3) / 2.5e15}
         launches, redone = ctx.f32_filter_stats()
-        f32 = {"pairs_per_s": float(n_bank) * n_query / (kms * 1e-3), "kernel_ms": kms, "ms_per_call": 1e3 * dt,
-               "frac_fp16_mfma_peak": float(n_bank) * n_query * 256 / (kms * 1e-3) / 2.5e15,
-               "filtered_calls": launches, "redone_by_all_pairs_kernel": redone,
-               "note": "fm_knn2, 10k x 1M non-integer float32 descriptors: fp16 MFMA filter (256 flop/pair) + exact "
-                       "float32 rescoring, results bit-identical to the all-pairs float32 chain"}
+        f32.update({"filtered_calls": launches, "redone_by_all_pairs_kernel": redone,
+                    "note": "fm_knn2 / fm_xcheck1, 10k x 1M non-integer float32 descriptors: fp16 MFMA filter (256 flop/pair) "
+                            "+ exact float32 rescoring, results bit-identical to the all-pairs float32 chain"})
+        # backward-compatible flat keys = the knn2 call (BASELINE configs[4] as benchmarked in r01)
+        f32.update({k: f32["knn2"][k] for k in ("pairs_per_s", "kernel_ms", "ms_per_call", "frac_fp16_mfma_peak")})
         tbf.close()
         qbf.close()
 
+    c3 = None
+    if rank == 0 and world == 1 and legs and os.environ.get("FM_BENCH_C3", "1") != "0":
+        c3 = leg_expand_c3(ctx)
+    c4 = None
+    if legs and os.environ.get("FM_BENCH_C4", "1") != "0":
+        c4 = leg_expand_c4(ctx, rank, world, dev, backend)
+
     if rank == 0:
-        pairs_per_step = float(NQ) * NT
+        pairs_per_step = float(NQ) * NT * PAIRS_PER_STEP
         value = world * pairs_per_step * args.steps / elapsed
         k_ms = st["kernel_ms"] / max(st["kernel_launches"], 1)
         call_ms = st["total_ms"] / max(st["calls"], 1)
-        achieved = pairs_per_step * OPS_PER_PAIR / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src, pmc = None, None, {}
-        try:        # HBM bytes per K1 launch from the committed rocprofv3 PMC passes (not live)
+        achieved = float(NQ) * NT * OPS_PER_PAIR / (k_ms * 1e-3) / 1e12
+        # HBM bytes per K1 launch come from the committed rocprofv3 PMC passes (not live): they are
+        # attached only if they were collected from exactly the kernel source that is built here
+        traffic = traffic_src = traffic_tag = busy = None
+        traffic_note = "no profiles/latest_pmc.json"
+        try:
             with open(PROFILE_JSON) as f:
                 pmc = json.load(f)
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], pmc["source"]
+            if pmc.get("k1_source_sha256") == k1_source_hash():
+                traffic, traffic_src, traffic_tag = pmc["hbm_bytes_per_launch"], pmc["source"], pmc.get("tag")
+                busy = pmc.get("mfma_pipe_busy_frac")
+                traffic_note = "counters collected from this kernel source (sha256 match)"
+            else:
+                traffic_note = ("profiles/latest_pmc.json (tag %s) was collected from a different rowreduce.hip/tile_ops.h; "
+                                "rerun scripts/profile.sh" % pmc.get("tag"))
         except Exception:
             pass
         out = {
@@ -207,29 +382,37 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_image_pair": 1e3 * elapsed / args.steps / PAIRS_PER_STEP,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
-            "config": {"workload": "100k x 100k synthetic 128-D uint8 SIFT descriptors per GPU, brute-force "
-                                   "cross-checked 1-NN + ratio 0.7 (BASELINE.json configs[1])",
-                       "nq": NQ, "nt": NT, "dim": 128, "tau": TAU, "pairs_per_gpu": 1,
-                       "parallelism": "independent image pairs, one per GPU; RCCL all-gather of accepted matches"},
+            "config": {"workload": "batch of %d independent image pairs per GPU and step, each 100k x 100k synthetic 128-D uint8 "
+                                   "SIFT descriptors, brute-force cross-checked 1-NN + ratio 0.7 (BASELINE.json configs[1])"
+                                   % PAIRS_PER_STEP,
+                       "nq": NQ, "nt": NT, "dim": 128, "tau": TAU, "pairs_per_gpu": PAIRS_PER_STEP,
+                       "parallelism": "independent image pairs sharded over GPUs; RCCL all-gather of accepted matches"
+                                      + (" from device buffers" if device_gather else "")},
             "matches_per_s": npass_all * args.steps / elapsed,
             "accepted_matches_per_step": npass_all,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
+                         "traffic_source": traffic_src, "traffic_tag": traffic_tag, "traffic_note": traffic_note,
                          "kernel": "fm::rowreduce_kernel<4,1,true,8> (v_mfma_i32_16x16x64_i8)", "kernel_ms": k_ms,
+                         "kernel_launches_timed": st["kernel_launches"],
                          "hbm_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "hbm_frac_of_8tbps": (traffic / (k_ms * 1e-3) / 8e12) if traffic else None,
-                         "mfma_pipe_busy_frac": pmc.get("mfma_pipe_busy_frac"),
-                         "note": "int8 ops: 256 per descriptor pair; HIP-event time of the K1 launch on its own stream; "
-                                 "hbm_gbps = PMC HBM bytes per launch / that time; mfma_pipe_busy_frac = rocprofv3 "
-                                 "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU cycles of the launch (profiles/)"},
+                         "mfma_pipe_busy_frac": busy,
+                         "note": "int8 ops: 256 per descriptor pair x 1e10 pairs per launch; kernel_ms = mean HIP-event time of the "
+                                 "K1 launches of the timed region, events on the library's own stream; hbm_gbps = PMC HBM bytes "
+                                 "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
+                                 "cycles of the launch (profiles/)"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
                          "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},
             "classic_ratio_match": crm,
+            "expand_c3": c3,
+            "expand_c4": c4,
             "float32_route": f32,
             "call_ms": call_ms,
             "device": ctx.device_name(),

@@ -5,7 +5,9 @@ the HIP kernels.  There is no CPU fallback: if the library is missing, or no gfx
 device is present, every compute entry point raises ``FastMatchHipError``.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -72,6 +74,7 @@ SYMBOLS = {
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "fm_expand_create": (_INT, [_P, ctypes.POINTER(fm_expand_desc), ctypes.POINTER(_P)]),
     "fm_expand_destroy": (_INT, [_P, _P]),
@@ -83,12 +86,32 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (and
+    HSA runtime) under torch/lib; if this library pulled in /opt/rocm's copy first, a later
+    ``import torch`` would mix the two sets and find no GPU.  So when torch is installed but
+    not imported yet, its bundled runtime is loaded first and both share it (the order
+    ``import torch`` -> this library already behaves that way).  FM_SYSTEM_HIP_RUNTIME=1 skips it."""
+    if "torch" in sys.modules or os.environ.get("FM_SYSTEM_HIP_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """dlopen libfastmatch_hip.so and declare every prototype.  Raises if missing."""
     global _lib
     with _lib_lock:
         if _lib is not None:
             return _lib
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise FastMatchHipError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -107,6 +130,28 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+class _LockedLib(object):
+    """The library with every call serialised on one lock.  An fm_ctx is not re-entrant (it
+    owns shared workspaces, the staging list and the timing events) and ctypes releases the
+    GIL during a call, so two Python threads sharing a Context must not overlap inside it."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._lock = threading.RLock()
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        fn = self._wrapped.get(name)
+        if fn is None:
+            raw, lock = getattr(self._lib, name), self._lock
+
+            def fn(*args):
+                with lock:
+                    return raw(*args)
+            self._wrapped[name] = fn
+        return fn
 
 
 class Bank(object):
@@ -186,7 +231,7 @@ class Context(object):
     """One fm_ctx (= one device + one HIP stream)."""
 
     def __init__(self, device=0):
-        self.lib = load_library()
+        self.lib = _LockedLib(load_library())
         self.handle = None
         h = _P()
         rc = self.lib.fm_ctx_create(int(device), ctypes.byref(h))
@@ -199,7 +244,7 @@ class Context(object):
 
     def _check(self, rc):
         if rc != 0:
-            msg = self.lib.fm_last_error(self.handle)
+            msg = self.lib.fm_last_error(self.handle) if self.handle is not None else None
             raise FastMatchHipError("libfastmatch_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
 
     def close(self):
@@ -306,15 +351,34 @@ class Context(object):
             cap = q.n
             out = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.float64))
         qidx, tidx, dist, ratio = out
-        cap = qidx.shape[0]
-        for a, dt in ((qidx, np.int32), (tidx, np.int32), (dist, np.float32), (ratio, np.float64)):
-            if a.dtype != dt or a.shape != (cap,) or not a.flags.c_contiguous:
-                raise ValueError("out buffers must be contiguous 1-D int32/int32/float32/float64 of one length")
+        cap = self._check_accepted_out(out)
         n = _I64(0)
         self._check(self.lib.fm_match_accepted(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx),
                                                _ptr(tidx), _ptr(dist), _ptr(ratio), ctypes.byref(n)))
         m = min(n.value, cap)
         return qidx[:m], tidx[:m], dist[:m], ratio[:m]
+
+    @staticmethod
+    def _check_accepted_out(out):
+        """Capacity of an (qidx, tidx, dist, ratio) output tuple; the library (or, for pinned
+        buffers, the device) writes up to that many rows into each array."""
+        qidx, tidx, dist, ratio = out
+        cap = qidx.shape[0] if getattr(qidx, "ndim", 0) == 1 else -1
+        for a, dt in ((qidx, np.int32), (tidx, np.int32), (dist, np.float32), (ratio, np.float64)):
+            if not isinstance(a, np.ndarray) or a.dtype != dt or a.shape != (cap,) or not a.flags.c_contiguous \
+                    or not a.flags.writeable:
+                raise ValueError("out buffers must be writable contiguous 1-D int32/int32/float32/float64 of one length")
+        return cap
+
+    def match_accepted_dev(self, q, t, tau, rows_ptr, count_ptr, cap):
+        """X1 + R1 with the accepted matches left on the device: ``rows_ptr`` = device address of
+        an int32 [cap, 3] buffer (query index, train index, float32 distance bits), ``count_ptr``
+        = device address of an int64 word (e.g. ``tensor.data_ptr()`` of torch tensors on this
+        context's device).  Returns the number accepted."""
+        n = _I64(0)
+        self._check(self.lib.fm_match_accepted_dev(self.handle, q.handle, t.handle, float(tau), int(cap),
+                                                   _P(int(rows_ptr)), _P(int(count_ptr)), ctypes.byref(n)))
+        return n.value
 
     def knn2_ratio(self, q, t, tau, out=None):
         """Classic Ratio-Match: 2-NN + d1/d2 < tau, accepted matches in ascending query index:
@@ -323,7 +387,7 @@ class Context(object):
             cap = q.n
             out = (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.float64))
         qidx, tidx, dist, ratio = out
-        cap = qidx.shape[0]
+        cap = self._check_accepted_out(out)
         n = _I64(0)
         self._check(self.lib.fm_knn2_ratio(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx), _ptr(tidx),
                                            _ptr(dist), _ptr(ratio), ctypes.byref(n)))

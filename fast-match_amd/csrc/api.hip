@@ -365,6 +365,49 @@ __global__ void compact_kernel(const int32_t* __restrict__ tidx, const float* __
     }
 }
 
+// Same ordered compaction, but into the 12-byte rows the multi-GPU result gather ships
+// (query index, train index, float32 distance bits) in a caller-supplied DEVICE buffer, with
+// the count as a device word next to it (fm_match_accepted_dev): nothing crosses to the host.
+__global__ void compact_rows_kernel(const int32_t* __restrict__ tidx, const float* __restrict__ dist,
+                                    const uint8_t* __restrict__ pass, const int* __restrict__ block_counts,
+                                    int64_t nq, int64_t cap, int32_t* __restrict__ o_rows,
+                                    long long* __restrict__ o_count, unsigned long long* __restrict__ h_count)
+{
+    __shared__ int red[256];
+    __shared__ int wave_base[4];
+    const int tid = threadIdx.x;
+    int s = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) s += block_counts[b];
+    red[tid] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) red[tid] += red[tid + d];
+        __syncthreads();
+    }
+    const int64_t base = red[0];
+    const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+    const bool p = q < nq && pass[q];
+    const unsigned long long m = __ballot(p);
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) wave_base[wave] = __popcll(m);
+    __syncthreads();
+    int wb = 0;
+    for (int w = 0; w < wave; ++w) wb += wave_base[w];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const long long tot = (long long)(base + wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3]);
+        *o_count = tot;
+        if (h_count) *h_count = (unsigned long long)tot;
+    }
+    if (p) {
+        const int64_t dst = base + wb + __popcll(m & ((1ull << lane) - 1ull));
+        if (dst < cap) {
+            o_rows[3 * dst] = (int32_t)q;
+            o_rows[3 * dst + 1] = tidx[q];
+            o_rows[3 * dst + 2] = (int32_t)__float_as_uint(dist[q]);
+        }
+    }
+}
+
 __global__ void ratio_filter_kernel(const float* __restrict__ dist, const double* __restrict__ selfdist,
                                     const int32_t* __restrict__ qrows, int64_t n, double tau,
                                     double* __restrict__ ratio, uint8_t* __restrict__ pass,
@@ -987,16 +1030,18 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 // ---------------------------------------------------------------------------------------
 static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
-                         const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr)
+                         const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr,
+                         int32_t* dev_rows = nullptr, long long* dev_count = nullptr)
 {
     const bool compact = compact_cap >= 0;
+    const bool to_device = dev_rows != nullptr;
     int rc = check_pair(ctx, q, t, who);
     if (rc != FM_OK) return rc;
     const int f32 = q->kind == FM_BANK_F32;
     const int64_t nq = q->n, nt = t->n;
     if (n_pass) *n_pass = 0;
     if (nq == 0) return FM_OK;
-    if (!tidx || !dist || (compact && (!c_qidx || !ratio))) return fail(ctx, FM_EINVAL, std::string(who) + ": output pointer is NULL");
+    if (!to_device && (!tidx || !dist || (compact && (!c_qidx || !ratio)))) return fail(ctx, FM_EINVAL, std::string(who) + ": output pointer is NULL");
     if (with_ratio && !q->selfdist) return fail(ctx, FM_EINVAL, std::string(who) + ": query bank has no self distances (fm_bank_set_selfdist)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // outputs: qbest u64[nq] | tidx i32[nq] | dist f32[nq] | ratio f64[nq] | pass u8[nq] | count u64
@@ -1005,7 +1050,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     const size_t o_cnt = (o_pass + (size_t)nq + 15) & ~(size_t)15;
     // compaction: block counts | compacted qidx, tidx, dist, ratio
     const int nblk = (int)((nq + 255) / 256);
-    const int64_t ccap = compact ? (compact_cap < nq ? compact_cap : nq) : 0;
+    const int64_t ccap = (compact && !to_device) ? (compact_cap < nq ? compact_cap : nq) : 0;
     const size_t o_bc = o_cnt + 16, o_cq = (o_bc + (size_t)nblk * 4 + 15) & ~(size_t)15, o_ct = o_cq + (size_t)ccap * 4;
     const size_t o_cd = o_ct + (size_t)ccap * 4, o_cr = (o_cd + (size_t)ccap * 4 + 7) & ~(size_t)7;
     if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, o_cr + (size_t)ccap * 8 + 16)) != FM_OK) return rc;
@@ -1052,6 +1097,19 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
                        compact ? (int*)(base + o_bc) : (int*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long cnt = 0;
+    if (to_device) {
+        // accepted matches stay on the device as packed rows (multi-GPU gather input)
+        void* a_c = ctx->h_scratch ? pinned_device_alias(ctx->h_scratch) : nullptr;
+        hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                           (const int32_t*)d_tidx, (const float*)d_dist, (const uint8_t*)d_pass,
+                           (const int*)(base + o_bc), nq, compact_cap, dev_rows, dev_count, (unsigned long long*)a_c);
+        HIP_TRY(ctx, hipGetLastError());
+        if (!a_c) HIP_TRY(ctx, hipMemcpyAsync(&cnt, dev_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        rc = cs.finish();
+        if (rc != FM_OK) return rc;
+        if (n_pass) *n_pass = a_c ? (int64_t)ctx->h_scratch[0] : (int64_t)cnt;
+        return FM_OK;
+    }
     if (compact) {
         // caller-owned page-locked outputs: the compaction writes them (and the count) directly,
         // no staging copies and a single synchronisation
@@ -1163,6 +1221,23 @@ extern "C" int fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t
 {
     if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted: cap < 0");
     return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, nullptr, n_accepted, "fm_match_accepted", cap, qidx);
+}
+
+extern "C" int fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                                     int32_t* d_rows, int64_t* d_count, int64_t* n_accepted)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_dev: ctx is NULL");
+    if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev: cap < 0");
+    if (!d_rows || !d_count) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev: device output pointer is NULL");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, d_rows) != hipSuccess || at.type != hipMemoryTypeDevice ||
+        hipPointerGetAttributes(&at, d_count) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(ctx, FM_EINVAL, "fm_match_accepted_dev: d_rows / d_count must be device memory");
+    }
+    if (q && q->n == 0) HIP_TRY(ctx, hipMemset(d_count, 0, 8));
+    return xcheck_common(ctx, q, t, true, tau, nullptr, nullptr, nullptr, nullptr, n_accepted, "fm_match_accepted_dev",
+                         cap, nullptr, d_rows, (long long*)d_count);
 }
 
 extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* selfdist, const int32_t* qrows,

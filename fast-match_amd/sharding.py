@@ -160,13 +160,20 @@ def knn2_sharded(ctx, qbank_shard, tbank, n_query, device=None, group=None):
 
 
 class MatchGatherer(object):
-    """Overlapped result gather for a stream of steps: ``submit(packed)`` starts the
-    all-gather of this step's accepted matches asynchronously (the previous one is waited
-    for first, buffers are double-buffered), so the collective runs while the next step's
-    matching kernels execute on the library's own HIP stream.  ``finish()`` waits for the
-    last one and returns ``(counts int64[world], rows int32[world, capacity, 3])`` tensors."""
+    """Overlapped result gather for a stream of steps, double buffered: the all-gather of one
+    image pair's accepted matches runs (RCCL, its own stream) while the next pair's matching
+    kernels execute on the library's HIP stream.  ``finish()`` waits for the last gather and
+    returns ``(counts int64[world], rows int32[world, capacity, 3])`` tensors.
 
-    def __init__(self, device, capacity, group=None):
+    Device path (the default on GPUs): ``rows, count = send_buffers()`` hands out the free
+    slot's device tensors, ``Context.match_accepted_dev(q, t, tau, rows.data_ptr(),
+    count.data_ptr(), capacity)`` fills them on the device, ``submit_device()`` starts the
+    collective straight from them -- the match rows never leave HBM.
+    Host path: ``submit(packed)`` with an [m, 3] int32 NumPy array (CPU tests over gloo).
+    ``fill_device``: with a CPU transport (gloo dry run of the device path on a one-GPU box)
+    the send buffers still live on that CUDA device and are copied to the host for transport."""
+
+    def __init__(self, device, capacity, group=None, fill_device=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -175,11 +182,15 @@ class MatchGatherer(object):
         self.dev = device
         self.capacity = int(capacity)
         self.on_cpu = isinstance(device, str) and device == "cpu"
-        mk = lambda *shape, dtype: [torch.zeros(shape, dtype=dtype, device=device) for _ in range(2)]
-        self.buf = mk(self.capacity, 3, dtype=torch.int32)
-        self.mine = mk(1, dtype=torch.int64)
-        self.allbuf = mk(self.world * self.capacity, 3, dtype=torch.int32)
-        self.counts = mk(self.world, dtype=torch.int64)
+        mk = lambda dev, *shape, dtype: [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(2)]
+        self.buf = mk(device, self.capacity, 3, dtype=torch.int32)
+        self.mine = mk(device, 1, dtype=torch.int64)
+        self.allbuf = mk(device, self.world * self.capacity, 3, dtype=torch.int32)
+        self.counts = mk(device, self.world, dtype=torch.int64)
+        self.fill_buf = self.fill_mine = None
+        if self.on_cpu and fill_device is not None:
+            self.fill_buf = mk(fill_device, self.capacity, 3, dtype=torch.int32)
+            self.fill_mine = mk(fill_device, 1, dtype=torch.int64)
         self.pending = []
         self.slot = 0
 
@@ -188,8 +199,18 @@ class MatchGatherer(object):
             w.wait()
         self.pending = []
 
+    def _start(self, k):
+        dist = self.dist
+        if self.on_cpu:
+            self.pending = [dist.all_gather(list(self.counts[k].split(1)), self.mine[k], group=self.group, async_op=True),
+                            dist.all_gather(list(self.allbuf[k].split(self.capacity)), self.buf[k], group=self.group, async_op=True)]
+        else:
+            self.pending = [dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group, async_op=True),
+                            dist.all_gather_into_tensor(self.allbuf[k], self.buf[k], group=self.group, async_op=True)]
+        self.last = k
+
     def submit(self, packed):
-        torch, dist = self.torch, self.dist
+        torch = self.torch
         packed = np.ascontiguousarray(packed, dtype=np.int32).reshape(-1, 3)
         m = packed.shape[0]
         if m > self.capacity:
@@ -200,13 +221,26 @@ class MatchGatherer(object):
         if m:
             self.buf[k][:m].copy_(torch.from_numpy(packed))
         self.mine[k][0] = m
+        self._start(k)
+
+    def send_buffers(self):
+        """(rows int32[capacity, 3], count int64[1]) device tensors of the free slot."""
         if self.on_cpu:
-            self.pending = [dist.all_gather(list(self.counts[k].split(1)), self.mine[k], group=self.group, async_op=True),
-                            dist.all_gather(list(self.allbuf[k].split(self.capacity)), self.buf[k], group=self.group, async_op=True)]
-        else:
-            self.pending = [dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group, async_op=True),
-                            dist.all_gather_into_tensor(self.allbuf[k], self.buf[k], group=self.group, async_op=True)]
-        self.last = k
+            if self.fill_buf is None:
+                raise ValueError("send_buffers() needs device tensors (backend nccl, or fill_device=...)")
+            return self.fill_buf[self.slot], self.fill_mine[self.slot]
+        return self.buf[self.slot], self.mine[self.slot]
+
+    def submit_device(self):
+        """Start the all-gather of the slot handed out by the last ``send_buffers()``.  The
+        fill must be complete (fm_match_accepted_dev is synchronous)."""
+        self._wait()
+        k = self.slot
+        self.slot ^= 1
+        if self.on_cpu:                    # dry run: device buffers, CPU transport
+            self.buf[k].copy_(self.fill_buf[k])
+            self.mine[k].copy_(self.fill_mine[k])
+        self._start(k)
 
     def finish(self):
         self._wait()

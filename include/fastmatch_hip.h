@@ -153,6 +153,17 @@ int  fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double t
                        int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
                        int64_t* n_accepted);
 
+/* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
+ * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
+ * them) and *d_count = total accepted, both in caller-supplied DEVICE memory -- the send
+ * buffer of the multi-GPU result gather (fm_gather_matches / an RCCL all-gather), so nothing
+ * bounces through the host.  The reference has no counterpart (single process); the rows are
+ * the (queryIdx, trainIdx, distance) of the DMatch list fastmatch.pyx:161-165 consumes.
+ * Synchronous: the buffers are complete on return.  n_accepted (host) may be NULL.          */
+int  fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                           int32_t* d_rows /*device [cap][3]*/, int64_t* d_count /*device*/,
+                           int64_t* n_accepted /*host, or NULL*/);
+
 /* ---- K4: many match_position rounds in one launch ------------------------------------
  * Round b matches the query rows  q_rows[q_off[b] .. q_off[b+1])  of bank q (the radius
  * subset Metric_Cache.get returns, cache.pyx:173-188, in its order) against the train

@@ -81,8 +81,9 @@ def bf_knn(Q, T, k=2, order=0, threads=0):
     """cv2.BFMatcher(NORM_L2, crossCheck=False).knnMatch(Q, T, k) as arrays.
 
     Returns (idx int32[nq,k], dist float32[nq,k]); missing neighbours (nt < k) are
-    idx -1 / dist +inf.  ``order``: fp32 accumulation order (0 = OpenCV unrolled-4,
-    1 = fma chain, the order the device fp32 kernel uses); ignored for uint8."""
+    idx -1 / dist +inf.  ``order``: fp32 accumulation order (0 = OpenCV generic unrolled-4,
+    1 = fma chain, the order the device fp32 kernel uses, 2 = OpenCV 2.4.x SSE2 2x4 lanes,
+    3 = OpenCV 4.x 128-bit universal intrinsics 4x4 lanes); ignored for uint8."""
     Q, T, kind = _pair(Q, T)
     nq, nt, dim = Q.shape[0], T.shape[0], Q.shape[1]
     idx = np.empty((nq, k), dtype=np.int32)

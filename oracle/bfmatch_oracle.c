@@ -43,8 +43,18 @@
  *   order 1 ("fma chain"): s = fmaf(v_k, v_k, s), k ascending.  This is the order
  *                           our device fp32 kernel executes (v_sub_f32 + v_fma_f32),
  *                           fixed so that non-integer descriptors are bit-comparable.
+ *   order 2 ("sse2x4"):    OpenCV 2.4.x's SSE2 path of normL2Sqr_ (core/src/stat.cpp, the
+ *                           build the reference's 2014 .so files were linked against):
+ *                           two 4-lane accumulators over strides of 8, d0 += t0*t0,
+ *                           d1 += t1*t1 (mul then add, no fma), lanes of d0+d1 summed
+ *                           left to right.  Recalled from the OpenCV sources, like
+ *                           Appendix A; not verified against a live cv2.
+ *   order 3 ("simd4x4"):   OpenCV 3.4/4.x universal-intrinsics path on a 128-bit
+ *                           baseline (core/src/norm.cpp): four 4-lane accumulators over
+ *                           strides of 16, v_muladd without FMA3 = mul then add,
+ *                           ((d0+d1)+d2)+d3 lane-wise, then (l0+l2)+(l1+l3).  Recalled.
  * For integer-valued inputs 0..255 (what OpenCV SIFT emits) every partial sum is an
- * exact integer <= 8 323 200 < 2^24, so both orders (and any SIMD order OpenCV may
+ * exact integer <= 8 323 200 < 2^24, so all orders (and any SIMD order OpenCV may
  * use) give the same bits.                                       */
 static inline float l2sqr_f32_unrolled4(const float* a, const float* b, int n)
 {
@@ -66,6 +76,45 @@ static inline float l2sqr_f32_fmachain(const float* a, const float* b, int n)
     return s;
 }
 
+static inline float l2sqr_f32_sse2x4(const float* a, const float* b, int n)
+{
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j <= n - 8; j += 8) {
+        for (int l = 0; l < 4; l++) {
+            float t0 = a[j + l] - b[j + l], t1 = a[j + 4 + l] - b[j + 4 + l];
+            float p0 = t0 * t0, p1 = t1 * t1;
+            d0[l] = d0[l] + p0;
+            d1[l] = d1[l] + p1;
+        }
+    }
+    float buf[4];
+    for (int l = 0; l < 4; l++) buf[l] = d0[l] + d1[l];
+    float d = buf[0] + buf[1];
+    d = d + buf[2];
+    d = d + buf[3];
+    for (; j < n; j++) { float t = a[j] - b[j]; d += t * t; }
+    return d;
+}
+
+static inline float l2sqr_f32_simd4x4(const float* a, const float* b, int n)
+{
+    float acc[4][4] = {{0.f}};
+    int j = 0;
+    for (; j <= n - 16; j += 16)
+        for (int v = 0; v < 4; v++)
+            for (int l = 0; l < 4; l++) {
+                float t = a[j + 4 * v + l] - b[j + 4 * v + l];
+                float p = t * t;
+                acc[v][l] = p + acc[v][l];
+            }
+    float s[4];
+    for (int l = 0; l < 4; l++) { float x = acc[0][l] + acc[1][l]; x = x + acc[2][l]; s[l] = x + acc[3][l]; }
+    float d = (s[0] + s[2]) + (s[1] + s[3]);
+    for (; j < n; j++) { float t = a[j] - b[j]; d += t * t; }
+    return d;
+}
+
 /* OpenCV normL2Sqr<uchar,float> equivalent for CV_8U inputs: integer exact.        */
 static inline float l2sqr_u8(const uint8_t* a, const uint8_t* b, int n)
 {
@@ -74,15 +123,22 @@ static inline float l2sqr_u8(const uint8_t* a, const uint8_t* b, int n)
     return (float)s;
 }
 
-typedef struct { const void* base; int dim; int kind; /*0=f32 unrolled4, 1=f32 fma, 2=u8*/ } orc_mat;
+/* kind: 0 = f32 unrolled4, 1 = f32 fma chain, 2 = f32 sse2x4, 3 = f32 simd4x4, 8 = u8 */
+#define ORC_KIND_U8 8
+#define ORC_ORDER_OK(o) ((o) >= 0 && (o) <= 3)
+typedef struct { const void* base; int dim; int kind; } orc_mat;
 
 static inline float dist_row(const orc_mat* A, int64_t i, const orc_mat* B, int64_t j)
 {
     float d2;
-    if (A->kind == 2)
+    if (A->kind == ORC_KIND_U8)
         d2 = l2sqr_u8((const uint8_t*)A->base + i * A->dim, (const uint8_t*)B->base + j * B->dim, A->dim);
     else if (A->kind == 1)
         d2 = l2sqr_f32_fmachain((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
+    else if (A->kind == 2)
+        d2 = l2sqr_f32_sse2x4((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
+    else if (A->kind == 3)
+        d2 = l2sqr_f32_simd4x4((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
     else
         d2 = l2sqr_f32_unrolled4((const float*)A->base + i * A->dim, (const float*)B->base + j * B->dim, A->dim);
     return sqrtf(d2);      /* batchDistance: dist = std::sqrt(normL2Sqr) -- Appendix A.1 */
@@ -138,7 +194,7 @@ static int nthreads(int threads)
 ORC_API int orc_bf_knn_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim, int k,
                            int order, int32_t* idx, float* dist, int threads)
 {
-    if (k < 1 || dim < 1 || (order != 0 && order != 1)) return -1;
+    if (k < 1 || dim < 1 || !ORC_ORDER_OK(order)) return -1;
     orc_mat q = mk(Q, dim, order), t = mk(T, dim, order);
     knn_rows(&q, nq, &t, nt, k, idx, dist, nthreads(threads));
     return 0;
@@ -148,7 +204,7 @@ ORC_API int orc_bf_knn_u8(const uint8_t* Q, int64_t nq, const uint8_t* T, int64_
                           int32_t* idx, float* dist, int threads)
 {
     if (k < 1 || dim < 1) return -1;
-    orc_mat q = mk(Q, dim, 2), t = mk(T, dim, 2);
+    orc_mat q = mk(Q, dim, ORC_KIND_U8), t = mk(T, dim, ORC_KIND_U8);
     knn_rows(&q, nq, &t, nt, k, idx, dist, nthreads(threads));
     return 0;
 }
@@ -179,7 +235,7 @@ static void xcheck(const orc_mat* Q, int64_t nq, const orc_mat* T, int64_t nt,
 ORC_API int orc_bf_xcheck1_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim,
                                int order, int32_t* tidx, float* dist, int threads)
 {
-    if (dim < 1 || (order != 0 && order != 1)) return -1;
+    if (dim < 1 || !ORC_ORDER_OK(order)) return -1;
     orc_mat q = mk(Q, dim, order), t = mk(T, dim, order);
     xcheck(&q, nq, &t, nt, tidx, dist, nthreads(threads));
     return 0;
@@ -189,7 +245,7 @@ ORC_API int orc_bf_xcheck1_u8(const uint8_t* Q, int64_t nq, const uint8_t* T, in
                               int32_t* tidx, float* dist, int threads)
 {
     if (dim < 1) return -1;
-    orc_mat q = mk(Q, dim, 2), t = mk(T, dim, 2);
+    orc_mat q = mk(Q, dim, ORC_KIND_U8), t = mk(T, dim, ORC_KIND_U8);
     xcheck(&q, nq, &t, nt, tidx, dist, nthreads(threads));
     return 0;
 }

@@ -139,11 +139,15 @@ def o_match_position(pos, query, grid, radius=100):          # fastmatch.pyx:145
     return np.array(positions), np.array(ratios), np.array(indices)
 
 
-def o_do_iter(seeds, query, grid, tau, radius=100, log=None):   # fastmatch.pyx:56-89
+def o_do_iter(seeds, query, grid, tau, radius=100, log=None, max_rounds=None):   # fastmatch.pyx:56-89
+    """``max_rounds`` (test aid, not in the reference): stop after that many rounds; the match
+    list returned is then a prefix of the full run's list (matches are appended in round order)."""
     todo = [s for s in seeds]                                # front of the list = next
     matches, seen_keys, found = [], {}, {}
     rounds = 0
     while todo:
+        if max_rounds is not None and rounds >= max_rounds:
+            break
         query_pos, target_pos = todo.pop(0)
         col, row = grid.block(target_pos[0], target_pos[1])
         qcol, qrow = grid.block(query_pos[0], query_pos[1])
@@ -198,7 +202,7 @@ def o_match(query, target, options={}):                      # fastmatch.pyx:32-
 
     def get_matches(tau):
         seeds = thumb_pos[thumb_ratios < thumb_strategy(tau)]
-        matches, rounds = o_do_iter(seeds, query, grid, tau, radius, log)
+        matches, rounds = o_do_iter(seeds, query, grid, tau, radius, log, options.get("max_rounds"))
         get_matches.rounds = rounds
         return matches
 

@@ -6,7 +6,8 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+export FM_REPO=$PWD FM_PROFILE_TAG=$TAG
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq1 -- $BENCH > /dev/null 2> $OUT/pmc_sq1.err
@@ -49,6 +50,13 @@ if fs is not None and ws is not None:
         d.update({"mfma_busy_cycles_per_simd": mb / 1024, "gpu_cycles_per_launch": ga / 8,
                   "mfma_pipe_busy_frac": (mb / 1024) / (ga / 8),
                   "pmc_source": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (separate rocprofv3 --pmc passes)"})
+    # tie the counters to the kernel source they were collected from (bench.py attaches them
+    # only when this hash equals the hash of the source it runs)
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("fast-match_amd/csrc/rowreduce.hip", "fast-match_amd/csrc/tile_ops.h"):
+        h.update(open(os.path.join(os.environ["FM_REPO"], rel), "rb").read())
+    d.update({"k1_source_sha256": h.hexdigest(), "tag": os.environ.get("FM_PROFILE_TAG", "")})
     json.dump(d, open("latest_pmc.json", "w"))
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     os.system("cp %s %s/kernel_stats.csv" % (f, out))

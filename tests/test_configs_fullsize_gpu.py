@@ -1,0 +1,114 @@
+"""GPU: BASELINE.json configs[2] and configs[3] at their full workload sizes.
+
+configs[2]  single 24-MP image pair (6000 x 4000, 300 000 keypoints per side, 9801 grid cells,
+            default options): fastmatch.match() through the device-resident expansion loop ==
+            the host-driven loop == the oracle's restatement of fastmatch.pyx:56-89,145-169.
+configs[3]  batch of 64 independent 1-MP pairs (1000 x 1000, 12 500 keypoints per side):
+            fastmatch.match_many() in ONE launch == the host loop for all 64 == the oracle for
+            FM_C4_ORACLE_PAIRS (default 8) of them.
+
+The oracle's radius and cell look-ups are O(N) NumPy scans (~4 ms per round at 300k
+keypoints), so the full config-2 run costs the oracle a few minutes of host time;
+FM_C3_ORACLE_ROUNDS=<n> caps it (the capped match list is a prefix of the full one).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from fastmatch_amd import fastmatch, cache, synth
+import oracle
+from oracle import fastmatch_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _caches(q, t, ctx):
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    return mc, fi
+
+
+def _oracle_sides(q, t, distances=None, thumb_distances=None):
+    thumb = {"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]}
+    if thumb_distances is not None:
+        thumb["distances"] = thumb_distances
+    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"], distances=distances, thumb=thumb)
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"],
+                    "size": t["thumb_size"]}}
+    return oq, ot
+
+
+def _same_matches(a, b):
+    assert len(a) == len(b)
+    for (ia, da), (ib, db) in zip(a, b):
+        assert ia == ib and da["ratio"] == db["ratio"]
+        assert np.array_equal(da["positions"], db["positions"])
+
+
+def test_config3_full_size_device_loop_host_loop_oracle(ctx):
+    n = 300000
+    q, t = synth.image_pair((6000, 4000), n, seed=20250003, n_thumb=2000)
+    mc, fi = _caches(q, t, ctx)
+    # Self distances of the 300k-row bank come from the device (9e10 pairs); the oracle checks
+    # them on a row sample (its own 2-NN of those rows against the whole bank) and computes
+    # the 2000-row thumbnail bank's in full.
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(n, size=4096, replace=False))
+    oidx, odist = oracle.bf_knn(q["descriptors"][rows], q["descriptors"], k=2)
+    assert np.array_equal(mc.original["distances"][rows], odist[:, 1].astype(np.float64))
+    oq, ot = _oracle_sides(q, t, distances=mc.original["distances"])
+    assert np.array_equal(mc.thumb["distances"], oq.thumb["distances"])
+
+    ds, hs = {}, {}
+    dev = fastmatch.match(mc, fi, {"context": ctx, "stats": ds})(0.7)
+    assert ds.get("rounds", 0) > 0, "device loop did not run"
+    host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.7)
+    assert ds["rounds"] == hs["rounds"] > 10000 and ds["pairs"] == hs["pairs"]
+    _same_matches(dev, host)
+    assert len(dev) > 20000
+
+    cap = os.environ.get("FM_C3_ORACLE_ROUNDS")
+    oget = fo.o_match(oq, ot, {"max_rounds": int(cap)} if cap else {})
+    exp = oget(0.7)
+    if cap and oget.rounds >= int(cap):
+        assert len(exp) > 0
+        _same_matches(dev[:len(exp)], exp)
+    else:
+        assert oget.rounds == ds["rounds"]
+        _same_matches(dev, exp)
+
+
+def test_config4_batch_of_64_pairs_one_launch(ctx):
+    n_pairs = 64
+    n_oracle = int(os.environ.get("FM_C4_ORACLE_PAIRS", "8"))
+    raw, pairs = [], []
+    for i in range(n_pairs):
+        q, t = synth.image_pair((1000, 1000), 12500, seed=20250100 + i)
+        raw.append((q, t) if i % (n_pairs // n_oracle) == 0 else None)
+        pairs.append(_caches(q, t, ctx))
+    prepared, stats = [], {}
+    dev = fastmatch.match_many(pairs, 0.7, {"context": ctx, "prepared_out": prepared, "stats": stats})
+    assert len(dev) == n_pairs and all(p["expander"] not in (None, False) for p in prepared)
+    # every pair: device loop (one launch for all 64) == host-driven loop
+    hrounds = 0
+    for (mc, fi), got in zip(pairs, dev):
+        hs = {}
+        host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.7)
+        _same_matches(got, host)
+        hrounds += hs["rounds"]
+        assert len(got) > 100
+    assert stats["rounds"] == hrounds
+    # a spread of pairs: == the oracle
+    checked = 0
+    for i, qt in enumerate(raw):
+        if qt is None:
+            continue
+        oq, ot = _oracle_sides(*qt)
+        assert np.array_equal(pairs[i][0].original["distances"], oq.distances)
+        _same_matches(dev[i], fo.o_match(oq, ot, {})(0.7))
+        checked += 1
+    assert checked >= min(8, n_oracle)
