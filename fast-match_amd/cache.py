@@ -558,7 +558,7 @@ class Metric_Cache(object):
         """ Thumbnail features + exact self 2-NN distances (cache.pyx:242-260) """
         from . import imaging
         thumbnail = imaging.get_thumbnail(path, (thumb_x, thumb_y))
-        keypoints, descriptors = matchutil.get_features(thumbnail)
+        keypoints, descriptors = self._options.get("feature_function", matchutil.get_features)(thumbnail)
         ctx = matchutil._context(self._options)
         self._thumb_bank = ctx.bank(descriptors)
         nn_distances = ctx.self_dist(self._thumb_bank)
@@ -574,7 +574,7 @@ class Metric_Cache(object):
         """ Full-image features, self distances and position index (cache.pyx:263-284) """
         from . import imaging
         img_data = imaging.open_img(path, max_size)
-        keypoints, descriptors = matchutil.get_features(img_data)
+        keypoints, descriptors = self._options.get("feature_function", matchutil.get_features)(img_data)
         ctx = matchutil._context(self._options)
         self._bank = ctx.bank(descriptors)
         distances = ctx.self_dist(self._bank)

@@ -674,6 +674,9 @@ struct CallScope {
     ~CallScope() { ctx->staged.clear(); ctx->h_stage_used = 0; }
     explicit CallScope(fm_ctx* c) : ctx(c)
     {
+        // entries left behind by a call that failed half way point at host memory that is gone
+        ctx->staged.clear();
+        ctx->h_stage_used = 0;
         ctx->kernel_timed = false;
         ctx->pending_pairs = 0;
         (void)hipEventRecord(ctx->ev_call0, ctx->stream);
@@ -1505,12 +1508,16 @@ extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int3
     if (n < 0 || n > ex->dev.match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch: n out of range");
     if (n == 0) return FM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    struct StageGuard {      // drop the staged copies on every exit path (their targets die with the call)
+        fm_ctx* c;
+        ~StageGuard() { c->staged.clear(); c->h_stage_used = 0; }
+    } guard{ctx};
+    ctx->staged.clear();
+    ctx->h_stage_used = 0;
     if (index) HIP_TRY(ctx, d2h(ctx, index, ex->dev.m_index, (size_t)n * 4));
     if (positions) HIP_TRY(ctx, d2h(ctx, positions, ex->dev.m_pos, (size_t)n * 32));
     if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ex->dev.m_ratio, (size_t)n * 8));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
-    ctx->staged.clear();
-    ctx->h_stage_used = 0;
     return FM_OK;
 }

@@ -22,7 +22,9 @@ order, because the match set depends on that order.
 ``target_img`` is either the reference's ``uint8[H, W, 3]`` array (SIFT through OpenCV on
 the host, needs ``cv2``) or a ``cache.Feature_Image`` carrying pre-extracted features.
 Extra option keys (additions): ``"context"``/``"device"`` select the GPU,
-``"stats"`` (a dict) receives round/pair counters.
+``"stats"`` (a dict) receives round/pair counters, ``"feature_function"`` replaces
+``matchutil.get_features`` (cv2 SIFT) for the thumbnail and the lazily computed grid cells
+(e.g. ``standin.standin_features`` where cv2 is absent).
 """
 from collections import deque
 
@@ -49,7 +51,7 @@ def match(query_cache, target_img, options={}):
         cell_features = options.get("feature_function", matchutil.get_features)
     target_cache = Grid_Cache(target_img, (grid_x, grid_y), cell_features, margin=grid_margin)
     thumb_positions, thumb_ratios = match_thumbs(target_img, query_cache, thumb_x=thumb_x, thumb_y=thumb_y,
-                                                 context=context)
+                                                 context=context, feature_function=cell_features)
 
     # The whole expansion loop runs on the device when every target feature is known up
     # front (a Feature_Image) and no per-round log is wanted; otherwise (lazy SIFT per cell,
@@ -245,24 +247,24 @@ def get_neighbors(target_pos, result_pos, target_grid):
     return list(out)
 
 
-def _thumb_features(img, thumb_x, thumb_y):
+def _thumb_features(img, thumb_x, thumb_y, feature_function=None):
     """(thumbnail positions [n,2], descriptors, (thumb_w, thumb_h)) of the target."""
     if isinstance(img, Feature_Image):
         if img.thumb is None:
             raise ValueError("Feature_Image has no thumbnail features (thumb_positions/thumb_descriptors)")
         return img.thumb["positions"], img.thumb["descriptors"], img.thumb["size"]
     target = get_thumbnail(img, (thumb_x, thumb_y))
-    t_keypoints, t_descriptors = matchutil.get_features(target)
+    t_keypoints, t_descriptors = (feature_function or matchutil.get_features)(target)
     return keypoint_positions(t_keypoints), t_descriptors, (target.shape[1], target.shape[0])
 
 
-def match_thumbs(img, query_cache, thumb_x=400, thumb_y=400, context=None):
+def match_thumbs(img, query_cache, thumb_x=400, thumb_y=400, context=None, feature_function=None):
     """Seeding: cross-checked 1-NN between the thumbnail banks, ratio against the query
     thumbnail's self distances, positions scaled to full resolution, sorted by ratio
     (stable sort; the reference's quicksort leaves equal ratios in unspecified order)."""
     context = context or matchutil._context({})
     t_orig_x, t_orig_y = get_size(img)
-    t_thumb_pos, t_descriptors, t_size = _thumb_features(img, thumb_x, thumb_y)
+    t_thumb_pos, t_descriptors, t_size = _thumb_features(img, thumb_x, thumb_y, feature_function)
     q_thumb_pos = query_cache.thumb["positions"]
     if t_descriptors is None or len(t_descriptors) == 0 or len(q_thumb_pos) == 0:
         return np.zeros((0, 2, 2), dtype=np.float64), np.zeros(0, dtype=np.float64)

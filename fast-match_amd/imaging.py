@@ -1,9 +1,13 @@
-"""Minimal host-side image helpers used only to feed SIFT (out of the accelerated path).
+"""Host-side image helpers that feed the feature extractor (out of the accelerated path).
 
-The reference's ``imaging.py`` (PIL two-pass thumbnail ``imaging.py:49-55``, cv2
-``open_img`` ``imaging.py:80-85``) is host image I/O and stays on the CPU; this shim
-offers the three calls the hot path's callers need (``get_thumbnail``, ``get_size``,
-``open_img``) on top of Pillow, and accepts ``cache.Feature_Image`` objects unchanged."""
+Mirrors the three calls of the reference's ``imaging.py`` that the hot path's callers use --
+``get_thumbnail`` (reference ``imaging.py:67-69`` -> ``scale_pil_antialias``, ``:49-55``),
+``get_size`` (``:71-72``) and ``open_img`` (``:80-85``) -- on Pillow alone (the reference also
+needs cv2 for ``open_img``).  Same argument meaning: ``path`` is a file name or an image
+array, ``size`` a (width, height) box.  Differences forced by the environment: Pillow >= 10
+has no ``Image.ANTIALIAS`` (``LANCZOS`` is the same filter) and no Python-2 ``basestring``;
+``open_img`` resizes with Pillow's BOX filter where the reference uses cv2 ``INTER_AREA``.
+``cache.Feature_Image`` objects pass through ``get_size`` unchanged."""
 import numpy as np
 
 
@@ -15,33 +19,54 @@ def _pil():
     return Image
 
 
-def get_size(img):
-    """(width, height) of an image array or Feature_Image."""
-    return (int(img.shape[1]), int(img.shape[0]))
+def _is_path(data):
+    return isinstance(data, (str, bytes))
 
 
-def open_img(path, max_size=-1):
+def _open_pil(data):
+    """PIL image from a path or an array (reference scale_pil.open / from_array, imaging.py:41-42)."""
     Image = _pil()
-    if isinstance(path, bytes):
-        path = path.decode()
-    im = Image.open(path).convert("RGB")
-    if max_size is not None and max_size > 0 and max(im.size) > max_size:
-        s = float(max_size) / max(im.size)
-        im = im.resize((max(1, int(im.size[0] * s)), max(1, int(im.size[1] * s))), Image.LANCZOS)
-    return np.asarray(im, dtype=np.uint8)[:, :, ::-1].copy()      # BGR like cv2.imread
+    if _is_path(data):
+        return Image.open(data.decode() if isinstance(data, bytes) else data)
+    return Image.fromarray(np.ascontiguousarray(data))
 
 
-def get_thumbnail(img, size=(400, 400)):
-    """Aspect-preserving thumbnail no larger than ``size`` (w, h) as uint8[H, W, 3]."""
+def resize_rule(width, height, size=(200, 200)):
+    """Target size of the reference's ``scale.resize`` (imaging.py:28-36): the longer side
+    takes the box's extent on that axis, the other follows the aspect ratio (truncated)."""
+    if width > height:
+        w = size[0]
+        h = int((w / float(width)) * height)
+    else:
+        h = size[1]
+        w = int((h / float(height)) * width)
+    return (w, h)
+
+
+def get_thumbnail(path, size=(200, 200)):
+    """ Get thumbnail with PIL: two ``Image.thumbnail`` passes, first to twice the target size
+    with the default filter, then to the target with the antialias (Lanczos) filter
+    (reference imaging.py:49-55).  Returns uint8 [h, w, channels]. """
     Image = _pil()
-    if isinstance(img, (str, bytes)):
-        img = open_img(img)
-    im = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
-    w, h = im.size
-    scale = min(float(size[0]) / w, float(size[1]) / h, 1.0)
-    tw, th = max(1, int(w * scale)), max(1, int(h * scale))
-    # two passes like the reference: a cheap 2x oversize reduction, then antialias
-    if w > 2 * tw and h > 2 * th:
-        im = im.resize((2 * tw, 2 * th), Image.NEAREST)
-    im = im.resize((tw, th), Image.LANCZOS)
-    return np.asarray(im, dtype=np.uint8)[:, :, ::-1].copy()
+    img = _open_pil(path)
+    new_size = resize_rule(img.size[0], img.size[1], size)
+    img.thumbnail(tuple(i * 2 for i in new_size))
+    img.thumbnail(new_size, Image.LANCZOS)
+    return np.array(img, dtype=np.uint8)
+
+
+def get_size(path):
+    """(width, height) of an image file, an image array or a Feature_Image."""
+    if _is_path(path):
+        return _open_pil(path).size
+    return (int(path.shape[1]), int(path.shape[0]))
+
+
+def open_img(path, size=None):
+    """ Image as uint8 [H, W, 3] in cv2.imread's BGR channel order; ``size`` None or -1 keeps
+    the resolution, a (width, height) box rescales by the rule above (reference imaging.py:80-85). """
+    Image = _pil()
+    img = _open_pil(path).convert("RGB")
+    if not (size is None or (np.isscalar(size) and size == -1)):
+        img = img.resize(resize_rule(img.size[0], img.size[1], size), Image.BOX)
+    return np.asarray(img, dtype=np.uint8)[:, :, ::-1].copy()

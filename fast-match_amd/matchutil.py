@@ -54,6 +54,30 @@ def _as_bank(ctx, d):
     return ctx.bank(a), True
 
 
+def _as_bank_pair(ctx, dt1, dt2):
+    """Both operands as banks of ONE kind.  A float32 array whose values all happen to be
+    integers in 0..255 is uploaded on the exact int8 route, any other float32 array on the
+    float32 route; cv2.BFMatcher takes any two float32 arrays, so when the two kinds differ
+    (say a one-row all-zero bank against normalised descriptors) the integer-valued array is
+    uploaded again on the float32 route, which yields the same numbers for it.  A resident
+    Bank of the other kind cannot be re-uploaded: the library then reports the mismatch."""
+    qb, q_tmp = _as_bank(ctx, dt1)
+    try:
+        tb, t_tmp = _as_bank(ctx, dt2)
+    except Exception:
+        if q_tmp:
+            qb.close()
+        raise
+    if qb.kind != tb.kind:
+        if q_tmp and qb.kind == _ffi.FM_BANK_I8 and np.asarray(dt1).dtype != np.uint8:
+            qb.close()
+            qb = ctx.bank(np.asarray(dt1), float_route=True)
+        elif t_tmp and tb.kind == _ffi.FM_BANK_I8 and np.asarray(dt2).dtype != np.uint8:
+            tb.close()
+            tb = ctx.bank(np.asarray(dt2), float_route=True)
+    return qb, q_tmp, tb, t_tmp
+
+
 def bf_match_arrays(dt1, dt2, k=1, options={}):
     """Array form of :func:`bf_match`.
 
@@ -65,8 +89,7 @@ def bf_match_arrays(dt1, dt2, k=1, options={}):
         raise ValueError("bf_match: only k = 1 or 2 is supported on the HIP path (the reference uses no other)")
     crossCheck = k == 1 and options.get("crossCheck", False) == True   # noqa: E712  (reference semantics)
     ctx = _context(options)
-    qb, q_tmp = _as_bank(ctx, dt1)
-    tb, t_tmp = _as_bank(ctx, dt2)
+    qb, q_tmp, tb, t_tmp = _as_bank_pair(ctx, dt1, dt2)
     try:
         if crossCheck:
             return ctx.xcheck1(qb, tb)
@@ -118,8 +141,7 @@ def ratio_match_arrays(dt1, dt2, tau, options={}):
     brute-force 2-NN then ``m[0].distance / m[1].distance < tau`` in float64, on the device.
     Returns (query idx, train idx, distance, ratio) of the accepted matches, ascending query."""
     ctx = _context(options)
-    qb, q_tmp = _as_bank(ctx, dt1)
-    tb, t_tmp = _as_bank(ctx, dt2)
+    qb, q_tmp, tb, t_tmp = _as_bank_pair(ctx, dt1, dt2)
     try:
         return ctx.knn2_ratio(qb, tb, tau)
     finally:

@@ -34,7 +34,7 @@ FLOAT_ORDER = 0
 class OGrid(object):
     """Grid geometry and lazily filled cells over a pre-extracted target."""
 
-    def __init__(self, size, cell_size, margin, positions=None, descriptors=None):
+    def __init__(self, size, cell_size, margin, positions=None, descriptors=None, image=None, fun=None):
         self.w, self.h = int(size[0]), int(size[1])
         self.cw, self.ch = int(cell_size[0]), int(cell_size[1])
         self.rows = int(self.w / cell_size[0]) + 1          # cells along x  (cache.pyx:41)
@@ -42,6 +42,7 @@ class OGrid(object):
         self.margin = int(margin)
         self.positions = positions
         self.descriptors = descriptors
+        self.image, self.fun = image, fun                   # pixel target: cell = fun(crop), cache.pyx:132-137
         self.cells = {}
         self.last = None
 
@@ -84,6 +85,12 @@ class OGrid(object):
         if (col, row) not in self.cells:
             b = self.bounds(col, row)
             (x0, x1), (y0, y1) = b
+            if self.fun is not None:                         # lazy features of the crop (cache.pyx:132-137)
+                kp, ds = self.fun(self.image[y0:y1, x0:x1, :])
+                pts = np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+                self.cells[(col, row)] = (pts, ds if ds is not None and len(ds) else None)
+                self.last = b
+                return self.cells[(col, row)]
             p = self.positions
             sel = np.nonzero((p[:, 0] >= x0) & (p[:, 0] < x1) & (p[:, 1] >= y0) & (p[:, 1] < y1))[0]
             self.cells[(col, row)] = (p[sel] - np.array([x0, y0], dtype=np.float64),
@@ -191,12 +198,17 @@ def o_match_thumbs(query, target_thumb, target_size):        # fastmatch.pyx:107
 
 
 def o_match(query, target, options={}):                      # fastmatch.pyx:32-53
-    """``target`` = dict(size, positions, descriptors, thumb=dict(positions, descriptors, size))."""
+    """``target`` = dict(size, positions, descriptors, thumb=dict(positions, descriptors, size)), or
+    dict(size, image, feature_function, thumb=...) for a pixel target whose cells are computed lazily."""
     grid_size = options.get("grid_size", (50, 50))
     thumb_strategy = options.get("thumb_strategy", lambda n: n)
     log = options.get("log", None)
-    grid = OGrid(target["size"], grid_size, options.get("grid_margin", 25),
-                 np.asarray(target["positions"], np.float64).reshape(-1, 2), target["descriptors"])
+    if "image" in target:        # pixel target + feature function (the reference's own mode, fastmatch.pyx:45)
+        grid = OGrid(target["size"], grid_size, options.get("grid_margin", 25), image=target["image"],
+                     fun=target["feature_function"])
+    else:
+        grid = OGrid(target["size"], grid_size, options.get("grid_margin", 25),
+                     np.asarray(target["positions"], np.float64).reshape(-1, 2), target["descriptors"])
     radius = options.get("radius", 100)
     thumb_pos, thumb_ratios = o_match_thumbs(query, target["thumb"], target["size"])
 

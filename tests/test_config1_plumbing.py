@@ -1,0 +1,156 @@
+"""BASELINE config 1 (images/graf img1 <-> img4, ratio 0.7) as PLUMBING: the README flow
+(reference README.md:34-55) -- Metric_Cache(query_path), target pixel array,
+fastmatch.match(query_cache, target_img, {'log': log})(0.7) -- on real pixel arrays through
+the thumbnail path and the lazy Grid_Cache.cache() crop -> features -> per-cell bank path.
+
+cv2 (SIFT) is installed neither here nor on the GPU box and the graf images do not travel,
+so the pixels are procedural (tests/imagegen.py) and the features come from the labelled
+stand-in extractor (fast-match_amd/standin.py: NOT SIFT).  What this pins is the plumbing
+and its parity with the oracle on identical features, not matching quality on graf."""
+import os
+
+import numpy as np
+import pytest
+
+from fastmatch_amd import imaging, standin, evaluate
+from imagegen import texture, warp, H1TO4P
+
+
+# ---- host-side pieces (no GPU) ---------------------------------------------------------------
+@pytest.mark.parametrize("wh,box", [((800, 640), (400, 400)), ((800, 640), (600, 600)), ((640, 800), (400, 400)),
+                                    ((500, 500), (200, 200)), ((1000, 300), (400, 400)), ((300, 200), (400, 400))])
+def test_get_thumbnail_sizes_like_the_reference(wh, box):
+    """reference imaging.py:28-36,49-55: the longer side takes the box extent, the other one is
+    int(aspect * it); PIL's thumbnail() then never enlarges and rounds the short side itself."""
+    from PIL import Image
+    w, h = wh
+    img = texture(w, h, seed=w + h)
+    th = imaging.get_thumbnail(img, box)
+    # the same two calls on a PIL image, written out independently
+    im = Image.fromarray(img)
+    if w > h:
+        new = (box[0], int((box[0] / float(w)) * h))
+    else:
+        new = (int((box[1] / float(h)) * w), box[1])
+    im.thumbnail((new[0] * 2, new[1] * 2))
+    im.thumbnail(new, Image.LANCZOS)
+    assert th.dtype == np.uint8 and th.shape == (im.size[1], im.size[0], 3)
+    assert np.array_equal(th, np.asarray(im))
+    assert th.shape[1] <= max(new[0], 1) and th.shape[0] <= max(new[1], 1) or (w <= new[0] and h <= new[1])
+    assert imaging.get_size(img) == (w, h)
+
+
+def test_open_img_and_get_size_on_files(tmp_path):
+    from PIL import Image
+    img = texture(320, 200, seed=9)
+    img[:, :, 0] //= 2                                   # make the channels differ
+    path = str(tmp_path / "img1.ppm")
+    Image.fromarray(img[:, :, ::-1]).save(path)          # file holds RGB; cv2.imread would return BGR
+    assert imaging.get_size(path) == (320, 200)
+    assert np.array_equal(imaging.open_img(path), img)
+    assert np.array_equal(imaging.open_img(path, -1), img)
+    assert imaging.open_img(path, (160, 160)).shape == (100, 160, 3)
+    th = imaging.get_thumbnail(path, (100, 100))         # target (100, 62); PIL's own aspect rounding may give 99
+    assert th.shape[0] == 62 and th.shape[1] in (99, 100) and th.shape[2] == 3
+
+
+def test_homography_scorer_on_the_graf_homography():
+    """H1to4p maps img1 (target in the README flow) to img4 (query) coordinates."""
+    rng = np.random.default_rng(4)
+    p1 = rng.uniform([50, 50], [750, 590], (400, 2))
+    q = np.concatenate([p1, np.ones((400, 1))], axis=1) @ H1TO4P.T
+    p4 = q[:, :2] / q[:, 2:3]
+    noise = rng.normal(0, 0.3, (400, 2))      # measured in the target image after H^-1 (scale ~1.5)
+    wrong = rng.random(400) < 0.25
+    p4n = p4 + noise + wrong[:, None] * rng.choice([-40.0, 40.0], (400, 2))
+    positions = np.stack([p4n, p1], axis=1)              # (query = img4, target = img1), as do_iter returns them
+    score = evaluate.homography_scorer(H1TO4P, distance_threshold=5.0, query_is_source=False)
+    good = score(np.arange(400), positions, np.zeros(400))
+    assert np.array_equal(good, ~wrong)
+    # the file format of images/graf/H1toNp (three whitespace-separated rows)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix="H1to4p", delete=False) as f:
+        for row in H1TO4P:
+            f.write("   " + "   ".join("%.7e" % v for v in row) + "\n")
+    assert np.array_equal(evaluate.load_homography(f.name), H1TO4P)
+    os.unlink(f.name)
+
+
+def test_standin_features_format():
+    img = texture(400, 300, seed=2)
+    kp, d = standin.standin_features(img)
+    assert len(kp) == len(d) > 300 and d.dtype == np.float32 and d.shape[1] == 128
+    assert np.array_equal(d, np.rint(d)) and d.min() >= 0 and d.max() <= 255       # SIFT's value range
+    assert all(8 <= k.pt[0] < 392 and 8 <= k.pt[1] < 292 for k in kp)
+    kp2, d2 = standin.standin_features(img)
+    assert [k.pt for k in kp] == [k.pt for k in kp2] and np.array_equal(d, d2)      # deterministic
+    assert standin.standin_features(np.zeros((50, 50, 3), np.uint8)) == ([], None)
+    assert standin.standin_features(img[:10, :10]) == ([], None)
+
+
+# ---- the README flow on the device --------------------------------------------------------------
+@pytest.mark.gpu
+def test_readme_flow_on_pixels_equals_oracle(ctx, tmp_path, monkeypatch):
+    from PIL import Image
+    from fastmatch_amd import cache, fastmatch
+    import oracle
+    from oracle import fastmatch_oracle as fo
+    monkeypatch.chdir(tmp_path)
+    calls = []
+
+    def feat(data):
+        calls.append(data.shape)
+        return standin.standin_features(data)
+    img1 = texture(800, 640, seed=1)                                       # "img1": target
+    mild = np.array([[1.0, 0.01, 18.0], [-0.008, 1.0, -11.0], [1e-5, -5e-6, 1.0]])   # the stand-in is not rotation invariant
+    img4 = warp(img1, mild)                                                # "img4": query
+    os.makedirs("images/graf")
+    Image.fromarray(img1[:, :, ::-1]).save("images/graf/img1.ppm")
+    Image.fromarray(img4[:, :, ::-1]).save("images/graf/img4.ppm")
+
+    # README.md:41-50
+    target_path, query_path = "images/graf/img1.ppm", "images/graf/img4.ppm"
+    opts = {"context": ctx, "feature_function": feat}
+    query_cache = cache.Metric_Cache(query_path, opts)                    # features + self 2-NN on the device + save()
+    target_img = imaging.open_img(target_path)
+    log, stats = [], {}
+    match_fun = fastmatch.match(query_cache, target_img, dict(opts, log=log, stats=stats))
+    matches = list(match_fun(0.7))
+    # query image + query thumbnail + target thumbnail + one call per grid cell the expansion
+    # reached (lazy: cache.pyx:102-106), far fewer than the 17 x 13 cells of the grid
+    n_cells = len(calls) - 3
+    assert calls[0] == (640, 800, 3) and 10 < n_cells < 17 * 13
+    assert all(c[0] <= 100 and c[1] <= 100 for c in calls[3:])
+    assert os.path.isfile("data/image_data/%s.npz" % cache._ripemd160(query_path.encode()))
+    again = cache.Metric_Cache(query_path, {"context": ctx})              # second time: load() hit, no features needed
+    assert np.array_equal(again.original["descriptors"], query_cache.original["descriptors"])
+    assert np.array_equal(again.original["distances"], query_cache.original["distances"])
+
+    # the oracle on the same pixels / features
+    feat = standin.standin_features
+    kq, dq = feat(imaging.open_img(query_path))
+    thumb_q = imaging.get_thumbnail(query_path, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    assert np.array_equal(query_cache.original["descriptors"], dq) and np.array_equal(query_cache.thumb["descriptors"], dtq)
+    oq = fo.OQuery(dq, pos(kq), (800, 640),
+                   thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    assert np.array_equal(query_cache.original["distances"], oq.distances)
+    assert np.array_equal(query_cache.thumb["distances"], oq.thumb["distances"])
+    thumb_t = imaging.get_thumbnail(target_img, (400, 400))
+    ktt, dtt = feat(thumb_t)
+    ot = {"size": (800, 640), "image": target_img, "feature_function": feat,
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    olog = []
+    oget = fo.o_match(oq, ot, {"log": olog})
+    exp = oget(0.7)
+    assert len(matches) == len(exp) > 50
+    for (ia, da), (ib, db) in zip(matches, exp):
+        assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    assert stats["rounds"] == oget.rounds == len(log) == len(olog) > 10
+    for a, b in zip(log, olog):
+        assert a["target_grid"] == b["target_grid"] and np.array_equal(a["matches"], b["matches"])
+    # plumbing-level sanity against the known warp: most accepted matches obey it
+    good = evaluate.homography_scorer(mild, 4.0, query_is_source=False)(
+        np.array([m[0] for m in matches]), np.array([m[1]["positions"] for m in matches]), None)
+    assert good.mean() > 0.8

@@ -212,6 +212,31 @@ def test_matchutil_surface(ctx):
         matchutil.bf_match(Q, T[:, :64], k=2, options=opts)
 
 
+def test_matchutil_mixed_integer_and_non_integer_float32(ctx):
+    """cv2.BFMatcher accepts any two float32 arrays; one of them being integer valued (here a
+    one-row all-zero bank and a bank of rounded values) must not fail on the bank-kind pairing:
+    the pair runs on the float32 route and equals the oracle's float32 chain."""
+    rng = np.random.default_rng(12)
+    F = (synth.synth_sift(200, rng).astype(np.float32) / 512.0).astype(np.float32)      # non-integer
+    I = synth.synth_sift(150, rng).astype(np.float32)                                    # integer valued
+    Z = np.zeros((1, 128), dtype=np.float32)
+    opts = {"context": ctx}
+    for A, B in ((Z, F), (F, Z), (I, F), (F, I)):
+        for k in (1, 2):
+            idx, dist = matchutil.bf_match_arrays(A, B, k=k, options=opts)
+            oidx, odist = oracle.bf_knn(A, B, k, order=1)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+        tidx, d = matchutil.bf_match_arrays(A, B, k=1, options={"crossCheck": True, "context": ctx})
+        otidx, od = oracle.bf_xcheck1(A, B, order=1)
+        assert np.array_equal(tidx, otidx) and np.array_equal(d, od)
+        q, t, dd, r = matchutil.ratio_match_arrays(A, B, 0.9, options=opts)
+        assert len(q) == len(t) == len(dd) == len(r)
+    # integer valued on both sides still takes the exact int8 route and agrees with it
+    idx, dist = matchutil.bf_match_arrays(I, I[:70], k=2, options=opts)
+    oidx, odist = oracle.bf_knn(I, I[:70], 2)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+
+
 def test_deterministic_replay(ctx):
     Q, T, _ = synth.planted_pair(4000, 4000, seed=99)
     qb, tb = ctx.bank(Q), ctx.bank(T)
