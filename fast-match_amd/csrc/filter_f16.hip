@@ -240,10 +240,17 @@ void filter_kernel(FParams p)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
+                        // A unit reaches this point because SOME lane of the wave holds a row at
+                        // or above its threshold -- typically one lane and one of its 8 rows.  The
+                        // P-step insertion costs ~6 VALU per step, so it runs only for the rows
+                        // that some lane actually wants (wave-uniform skip; a row below the lane's
+                        // threshold leaves its list unchanged either way).
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {                   // ascending row order
                             const float av = acc[r >> 2][j][r & 3];
-                            float a = (av >= thr[j]) ? av : -INFINITY;
+                            const bool want = av >= thr[j];
+                            if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
+                            float a = want ? av : -INFINITY;
                             int id = row0 + 16 * (r >> 2) + (r & 3);
 #pragma unroll
                             for (int i = 0; i < kFP; ++i) {
