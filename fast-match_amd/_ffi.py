@@ -43,7 +43,8 @@ class fm_expand_desc(ctypes.Structure):
 
 
 EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 2048 rows",
-                 3: "target position outside the image", 4: "result list full", 5: "hash table full"}
+                 3: "target position outside the image", 4: "result list full", 5: "hash table full",
+                 6: "float32 round: candidate list full"}
 
 # name -> (restype, argtypes); every symbol include/fastmatch_hip.h declares
 _P = ctypes.c_void_p

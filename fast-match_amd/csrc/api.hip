@@ -6,6 +6,7 @@
 // Reference call sites are cited in the header next to each entry point.
 #include "fm_internal.h"
 #include "expand_pair.h"
+#include "round_body_f32.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -1283,13 +1284,28 @@ extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* sel
     return FM_OK;
 }
 
+// Planes and scale terms of a (query = reduced, train = output rows) pair of float32 banks for
+// x1_round_f32: the same margin / accumulator-init factors launch_filter (filter_f16.hip) uses.
+static void fill_round_f32(RoundF32* r, const Bank& q, const Bank& t)
+{
+    const float eps = 1.1f / 1024.0f;
+    const int dk = t.kscale - q.kscale;               // acc units are 2^(kt + kq)
+    r->q_rowsh = (const char*)q.rowsh; r->q_auxf = q.auxf; r->q_rowsf = q.rowsf;
+    r->t_rowsh = (const char*)t.rowsh; r->t_normf = t.normf; r->t_rowsf = t.rowsf;
+    r->eps_c = ldexpf(eps, -dk);
+    r->eps_nm = ldexpf(eps * q.nm_max, dk);
+    r->aux_mul = ldexpf(1.0f, dk);
+}
+
 extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows, const int64_t* q_off,
                                   const fm_bank* t, const int64_t* t_off, int64_t n_rounds,
                                   int32_t* tidx, float* dist, double* ratio)
 {
     int rc = check_pair(ctx, q, t, "fm_xcheck1_batched");
     if (rc != FM_OK) return rc;
-    if (q->kind != FM_BANK_I8) return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: float32 (non-integer) banks take the dense path (fm_xcheck1 / fm_match_ratio)");
+    const bool f32 = q->kind == FM_BANK_F32;
+    if (f32 && !filter_usable(*t, *q))
+        return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: float32 banks without usable fp16 filter planes take the dense path (fm_xcheck1 / fm_match_ratio)");
     if (n_rounds < 0) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: n_rounds < 0");
     if (n_rounds == 0) return FM_OK;
     if (!q_off || !t_off) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: NULL offsets");
@@ -1320,9 +1336,17 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
     HIP_TRY(ctx, hipMemcpyAsync(ib + i_toff, t_off, (size_t)(n_rounds + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ib + i_rows, q_rows, (size_t)tot * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_rounds(*q, *t, (const int32_t*)(ib + i_rows), (const int64_t*)(ib + i_qoff),
-                               (const int64_t*)(ib + i_toff), n_rounds, (int32_t*)(ob + o_tidx),
-                               (float*)(ob + o_dist), (double*)(ob + o_ratio), ctx->stream));
+    if (f32) {
+        RoundF32 rf;
+        fill_round_f32(&rf, *q, *t);
+        HIP_TRY(ctx, launch_rounds_f32(rf, q->selfdist, (const int32_t*)(ib + i_rows), (const int64_t*)(ib + i_qoff),
+                                       (const int64_t*)(ib + i_toff), n_rounds, (int32_t*)(ob + o_tidx),
+                                       (float*)(ob + o_dist), (double*)(ob + o_ratio), ctx->stream));
+    } else {
+        HIP_TRY(ctx, launch_rounds(*q, *t, (const int32_t*)(ib + i_rows), (const int64_t*)(ib + i_qoff),
+                                   (const int64_t*)(ib + i_toff), n_rounds, (int32_t*)(ob + o_tidx),
+                                   (float*)(ob + o_dist), (double*)(ob + o_ratio), ctx->stream));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += pairs;
@@ -1352,8 +1376,11 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (!d || !out) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL argument");
     *out = nullptr;
     if (!d->query || !d->target) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL bank");
-    if (d->query->kind != FM_BANK_I8 || d->target->kind != FM_BANK_I8)
-        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: the device loop needs integer-valued (int8 route) banks");
+    if (d->query->kind != d->target->kind)
+        return fail(ctx, FM_EINVAL, "fm_expand_create: query/target kind mismatch");
+    const bool f32 = d->query->kind == FM_BANK_F32;
+    if (f32 && !filter_usable(*d->target, *d->query))
+        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: float32 banks without usable fp16 filter planes (non-finite values or scales more than 2^40 apart)");
     if (d->query->dim != d->target->dim) return fail(ctx, FM_EINVAL, "fm_expand_create: dim mismatch");
     if (!d->query->selfdist) return fail(ctx, FM_EINVAL, "fm_expand_create: query bank has no self distances");
     const int64_t nq = d->query->n, nt = d->target->n;
@@ -1412,6 +1439,9 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.idx_bucket = d->index_bucket; P.idx_x0 = d->index_x0; P.idx_y0 = d->index_y0;
     P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;
     P.t_rows8 = d->target->rows8; P.t_norm = d->target->norm;
+    P.f32 = f32 ? 1 : 0;
+    P.rf = RoundF32{};
+    if (f32) fill_round_f32(&P.rf, *d->query, *d->target);
     P.cell_off = (const int64_t*)(b + o_coff); P.t_pos = (const double*)(b + o_tpos);
     P.width = d->width; P.height = d->height; P.cell_w = d->cell_w; P.cell_h = d->cell_h;
     P.rows = d->rows; P.cols = d->cols; P.margin = d->margin; P.radius = d->radius;

@@ -31,7 +31,11 @@ constexpr int kExpSR = 512;               // query rows gathered per staging ste
 constexpr int kExpStageBytes = kExpSR * kDim + kExpSR / 32 * 256;
 constexpr int kExpLdsBytes = kExpStageBytes + kExpCand * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
 
-enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5 };
+enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
+       kExpListFull = 6 };
+static_assert(kRF_StageBytes <= kExpStageBytes, "the float32 round's gather image must fit the stage buffer");
+// float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
+constexpr int kExpClistCap = (kExpCand * (8 + 4) + 2 * 1024 * 4) / 4;
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 {
@@ -229,14 +233,16 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     char* smem = dyn_lds;                                                         // kExpStageBytes
     unsigned long long* keys = (unsigned long long*)(dyn_lds + kExpStageBytes);   // sort keys, then qbest
-    unsigned long long* nkey = keys + kExpCand;                                   // ratio bits of accepted matches
-    int* cand = (int*)(nkey + kExpCand);                                          // candidate / sorted query rows
-    int* tix  = cand + kExpCand;                                                  // sort scratch, then accepted list
+    int* cand = (int*)(keys + kExpCand);                                          // candidate / sorted query rows
+    unsigned long long* nkey = (unsigned long long*)(cand + kExpCand);            // ratio bits of accepted matches
+    int* tix  = (int*)(nkey + kExpCand);                                          // sort scratch, then accepted list
     int* hist = tix + kExpCand;                                                   // counting-sort buckets
+    // (nkey, tix, hist are contiguous: the float32 round's candidate list aliases them during step 3)
     __shared__ double cur[4];                         // query_pos, target_pos of the round
     __shared__ int sh_i[8];
     __shared__ long long sh_top;
     __shared__ int wave_tot[4];
+    __shared__ int sh_rf[4];                          // per-wave candidate counts of the float32 round
 
     const ExpandPair& P = pairs[blockIdx.x];
     const int tid = threadIdx.x;
@@ -340,8 +346,17 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
         for (int i = tid; i < nq; i += 256) keys[i] = ~0ull;     // keys[] becomes the qbest table
-        x1_round_wsplit<kExpSR>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
-                                (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
+        if (P.f32) {
+            // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
+            __syncthreads();
+            const bool ok = x1_round_f32(P.rf, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
+                                         (unsigned long long*)(hist + 2 * kSortBuckets + 16), sh_rf,
+                                         P.prof ? pt : nullptr, &tstamp);
+            if (!ok) { status = kExpListFull; break; }
+        } else {
+            x1_round_wsplit<kExpSR>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
+                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
+        }
         __syncthreads();
 
         EXP_STAMP(3);
@@ -358,7 +373,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
-                    const float d = sqrtf((float)(unsigned)(qb >> 32));
+                    // high word: exact integer d^2 (int8 route) or the float32 distance bits (float32 route)
+                    const float d = P.f32 ? __uint_as_float((unsigned)(qb >> 32)) : sqrtf((float)(unsigned)(qb >> 32));
                     ratio = (double)d / P.q_selfdist[cand[i]];
                     acc = ratio < P.tau;
                     t_local = (int)(unsigned)qb;

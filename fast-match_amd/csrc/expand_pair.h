@@ -1,6 +1,7 @@
 // Device-side descriptor of one image pair for expand_kernel (expand.hip); filled by api.hip.
 #pragma once
 #include <stdint.h>
+#include "round_body_f32.h"
 
 namespace fm {
 
@@ -20,6 +21,9 @@ struct ExpandPair {
     const int64_t* cell_off;       // [cols*rows + 1], cell id = col * rows + row
     const double*  t_pos;          // [nt_total][2] full-image coordinates (offset() applied)
     int width, height, cell_w, cell_h, rows, cols, margin, radius;
+    // float32 route (banks that are not integer valued): planes and scale terms of both banks
+    int      f32;                  // non-zero: x1_round_f32 instead of the int8 round
+    RoundF32 rf;
     // run inputs
     const double* seeds;           // [n_seeds][2][2]
     int64_t n_seeds;

@@ -97,6 +97,10 @@ hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, 
                          const int64_t* d_t_off, int64_t n_rounds, int32_t* d_tidx, float* d_dist,
                          double* d_ratio, hipStream_t stream);
 int round_qcap();
+struct RoundF32;   // round_body_f32.h
+hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const int32_t* d_q_rows, const int64_t* d_q_off,
+                             const int64_t* d_t_off, int64_t n_rounds, int32_t* d_tidx, float* d_dist,
+                             double* d_ratio, hipStream_t stream);
 
 // ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
 hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream);

@@ -17,6 +17,7 @@
 // Rounds are tiny (~400 x 125 descriptors), so the kernel is latency bound; what matters
 // is that a round costs one launch and no host round trip between its three steps.
 #include "round_body.h"
+#include "round_body_f32.h"
 
 namespace fm {
 
@@ -68,6 +69,79 @@ void round_kernel(RoundParams p)
         p.dist[q0 + i] = d;
         if (p.ratio) p.ratio[q0 + i] = r;
     }
+}
+
+// The same launch for banks that are not integer valued (float32 route, round_body_f32.h).  A
+// round whose candidate list overflows (pathological: thousands of query rows within the fp16
+// margin of a train row's nearest) reports tidx = -2 for all its slots; the caller redoes it on
+// the dense route.
+constexpr int kRoundF32Clist = 8192;
+constexpr int kRoundF32Lds = kRF_StageBytes + kRoundQCap * 8 + kRoundF32Clist * 4 + 128 * 8 + 64;
+
+struct RoundF32Params {
+    RoundF32       rf;
+    const double*  q_selfdist;
+    const int32_t* q_rows;
+    const int64_t* q_off;
+    const int64_t* t_off;
+    int32_t*       tidx;
+    float*         dist;
+    double*        ratio;
+};
+
+__global__ __launch_bounds__(256)
+void round_f32_kernel(RoundF32Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    char* smem = dyn;
+    unsigned long long* qbest = (unsigned long long*)(dyn + kRF_StageBytes);
+    unsigned* clist = (unsigned*)(qbest + kRoundQCap);
+    unsigned long long* tbest = (unsigned long long*)(clist + kRoundF32Clist);
+    int* sh = (int*)(tbest + 128);
+
+    const int tid = threadIdx.x;
+    const int b   = blockIdx.x;
+    const int64_t q0 = p.q_off[b];
+    const int nq = (int)(p.q_off[b + 1] - q0);
+    const int64_t t0 = p.t_off[b];
+    const int nt = (int)(p.t_off[b + 1] - t0);
+    for (int i = tid; i < nq; i += 256) qbest[i] = ~0ull;
+    __syncthreads();
+    bool ok = true;
+    if (nq > 0 && nt > 0) ok = x1_round_f32(p.rf, p.q_rows + q0, nq, t0, nt, smem, qbest, clist, kRoundF32Clist, tbest, sh);
+    __syncthreads();
+    for (int i = tid; i < nq; i += 256) {
+        const unsigned long long key = qbest[i];
+        int32_t ti = ok ? -1 : -2;
+        float d = INFINITY;
+        double r = NAN;
+        if (ok && key != ~0ull) {
+            ti = (int32_t)(unsigned)key;
+            d = __uint_as_float((unsigned)(key >> 32));
+            if (p.q_selfdist) r = (double)d / p.q_selfdist[p.q_rows[q0 + i]];
+        }
+        p.tidx[q0 + i] = ti;
+        p.dist[q0 + i] = d;
+        if (p.ratio) p.ratio[q0 + i] = r;
+    }
+}
+
+hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const int32_t* d_q_rows, const int64_t* d_q_off,
+                             const int64_t* d_t_off, int64_t n_rounds, int32_t* d_tidx, float* d_dist,
+                             double* d_ratio, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)round_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRoundF32Lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    RoundF32Params p;
+    p.rf = rf; p.q_selfdist = q_selfdist;
+    p.q_rows = d_q_rows; p.q_off = d_q_off; p.t_off = d_t_off;
+    p.tidx = d_tidx; p.dist = d_dist; p.ratio = d_ratio;
+    hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)n_rounds), dim3(256), kRoundF32Lds, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,

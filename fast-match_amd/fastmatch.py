@@ -80,14 +80,17 @@ def match(query_cache, target_img, options={}):
 
 def make_expander(query_cache, target_grid, radius, context):
     """Device-resident expansion state for (query_cache, target_grid), or False when the
-    pair cannot use the device loop (non-integer descriptors, oversize geometry)."""
+    pair cannot use the device loop (oversize geometry, float32 banks the fp16 filter cannot
+    take).  Integer-valued descriptors run the int8 round, others (RootSIFT-style float32)
+    the float32 round -- both banks then take the float32 route."""
     from . import _ffi
     q_bank = query_cache.bank(context)
-    if q_bank.kind != _ffi.FM_BANK_I8:
-        return False
     descs, t_pos, cell_off = target_grid.pack_cells()
-    t_bank = context.bank(descs)
-    if t_bank.kind != _ffi.FM_BANK_I8 or t_bank.dim != q_bank.dim:
+    t_bank = context.bank(descs, float_route=(q_bank.kind == _ffi.FM_BANK_F32))
+    if t_bank.kind != q_bank.kind:                 # integer-valued query bank, target not: pair on the float route
+        q_bank = context.bank(query_cache.original["descriptors"], float_route=True)
+        q_bank.set_selfdist(query_cache.original["distances"])
+    if t_bank.kind != q_bank.kind or t_bank.dim != q_bank.dim:
         return False
     grid = {"width": target_grid.width, "height": target_grid.height, "cell_w": target_grid.cell_width,
             "cell_h": target_grid.cell_height, "rows": target_grid.rows, "cols": target_grid.cols,
@@ -316,11 +319,21 @@ def _match_position(pos, query_cache, target, radius, context):
         return (np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64), 0)
     offset_x, offset_y = target.offset(target_x, target_y)
 
-    if nq <= 4096 and not float_route and t_bank.kind == _ffi.FM_BANK_I8:
-        tidx, dist, ratio = context.xcheck1_batched(q_bank, query_idx, [0, nq], t_bank, [0, nt])
-    else:
-        # oversize radius subset, or descriptors that are not integer valued (the per-round
-        # kernel is int8 only): gather the subset into a bank of its own and use the dense path
+    tidx = None
+    if nq <= 4096 and t_bank.kind == q_bank.kind:
+        # one launch of the round kernel on the resident banks (int8 round, or the float32 round
+        # for descriptors that are not integer valued)
+        try:
+            tidx, dist, ratio = context.xcheck1_batched(q_bank, query_idx, [0, nq], t_bank, [0, nt])
+            if len(tidx) and tidx[0] == -2:          # float32 round gave up (candidate list overflow)
+                tidx = None
+        except _ffi.FastMatchHipError:
+            if not float_route:
+                raise
+            tidx = None                              # banks the fp16 filter cannot take: dense path
+    if tidx is None:
+        # oversize radius subset, or an integer-valued query bank against a cell that is not:
+        # gather the subset into a bank of its own and use the dense path
         if not float_route and t_bank.kind != _ffi.FM_BANK_I8:
             t_bank = target.cell_bank(col, row, context, float_route=True)
             float_route = True

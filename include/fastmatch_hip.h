@@ -171,7 +171,10 @@ int  fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, doub
  * Output is per query slot i in [0, q_off[B]):  tidx[i] = train row index LOCAL to the
  * round's cell (-1 = none), dist[i], and ratio[i] = dist / selfdist[q_rows[i]] when q
  * carries self distances (else nan).  Semantics per round are exactly fm_xcheck1 on the
- * gathered sub-matrices.                                                                */
+ * gathered sub-matrices.  Both routes: integer-valued banks run the int8 round; float32 banks
+ * the float32 round (fp16 MFMA filter + exact float32 chain, bit-identical to fm_xcheck1); a
+ * float32 round that cannot be completed on the device reports tidx = -2 for all its slots
+ * (redo it with fm_xcheck1 on gathered banks).  At most 4096 query rows per round.        */
 int  fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows,
                         const int64_t* q_off /*[B+1]*/, const fm_bank* t,
                         const int64_t* t_off /*[B+1]*/, int64_t n_rounds,
@@ -183,7 +186,8 @@ int  fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* q_rows,
  * keypoint positions and position index (Metric_Cache.original, cache.pyx:278-284) and
  * every Grid_Cache cell's descriptors packed back to back (cache.pyx:124-138).  One
  * persistent workgroup per pair replays the reference's depth-first order exactly; many
- * pairs run concurrently in one launch.  Results come back in discovery order.            */
+ * pairs run concurrently in one launch.  Results come back in discovery order.  The two banks
+ * must be of one kind: integer valued (int8 round) or float32 (float32 round).            */
 typedef struct fm_expand fm_expand;
 
 typedef struct fm_expand_desc {
@@ -211,6 +215,7 @@ typedef struct fm_expand_desc {
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
 #define FM_EXPAND_MATCH_FULL    4
 #define FM_EXPAND_TABLE_FULL    5
+#define FM_EXPAND_LIST_FULL     6  /* float32 round: more candidates inside the fp16 margin than fit  */
 
 int  fm_expand_create(fm_ctx* ctx, const fm_expand_desc* desc, fm_expand** out);
 int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);

@@ -182,9 +182,9 @@ def test_evaluate_many_thresholds_reuses_state(ctx):
 
 
 def test_match_on_non_integer_descriptors_takes_the_float_route(ctx, monkeypatch):
-    """RootSIFT-style (non-integer float32) descriptors: fastmatch.match() runs on the float32
-    route (host loop, one dense call per round) and equals the oracle's transcription with
-    the device's accumulation order."""
+    """RootSIFT-style (non-integer float32) descriptors: fastmatch.match() runs the
+    device-resident loop with the float32 round, the host loop runs one float32 round launch
+    per round, and both equal the oracle's transcription with the device's accumulation order."""
     from fastmatch_amd import _ffi
     monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
     q, t = synth.image_pair((640, 480), 2500, 777)
@@ -203,9 +203,57 @@ def test_match_on_non_integer_descriptors_takes_the_float_route(ctx, monkeypatch
     ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
           "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
     assert np.array_equal(mc.original["distances"], oq.distances)
-    stats = {}
-    got = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})(0.8)
+    ran, batched = [], []
+    orig = fastmatch.run_device_loops
+    monkeypatch.setattr(fastmatch, "run_device_loops",
+                        lambda *a, **k: (lambda r: (ran.append([x is not None for x in r]), r)[1])(orig(*a, **k)))
+    orig_b = type(ctx).xcheck1_batched
+    monkeypatch.setattr(type(ctx), "xcheck1_batched",
+                        lambda self, *a, **k: (lambda r: (batched.append(int(r[0][0]) if len(r[0]) else 0), r)[1])(orig_b(self, *a, **k)))
+    stats, hstats = {}, {}
     oget = fo.o_match(oq, ot, {})
-    exp = oget(0.8)
-    _same_matches(got, exp)
-    assert len(got) > 20 and stats["rounds"] == oget.rounds
+    for tau in (0.8, 0.95):
+        stats.clear()
+        hstats.clear()
+        del ran[:], batched[:]
+        got = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})(tau)
+        assert ran == [[True]], "the device loop did not run on the float32 banks"
+        host = fastmatch.match(mc, fi, {"context": ctx, "stats": hstats, "device_loop": False})(tau)
+        assert len(batched) == hstats["rounds"] > 0 and -2 not in batched      # every host round = one float32 round launch
+        exp = oget(tau)
+        _same_matches(got, exp)
+        _same_matches(host, exp)
+        assert len(got) > 20 and stats["rounds"] == hstats["rounds"] == oget.rounds
+
+
+def test_device_loop_float32_banks_with_an_integer_valued_side(ctx, monkeypatch):
+    """Query descriptors integer valued, target descriptors not (and the reverse): the pair is
+    matched on the float32 route, device loop included, and equals the oracle."""
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    q, t = synth.image_pair((500, 400), 1800, 4242)
+    rng = np.random.default_rng(1)
+    for noisy_query in (False, True):
+        qd = q["descriptors"].astype(np.float32)
+        td = t["descriptors"].astype(np.float32)
+        qtd, ttd = q["thumb_descriptors"].astype(np.float32), t["thumb_descriptors"].astype(np.float32)
+        if noisy_query:
+            qd = qd + rng.uniform(-0.4, 0.4, qd.shape).astype(np.float32)
+            qtd = qtd + rng.uniform(-0.4, 0.4, qtd.shape).astype(np.float32)
+        else:
+            td = td + rng.uniform(-0.4, 0.4, td.shape).astype(np.float32)
+            ttd = ttd + rng.uniform(-0.4, 0.4, ttd.shape).astype(np.float32)
+        mc = cache.Metric_Cache.from_arrays(qd, q["positions"], q["size"], qtd, q["thumb_positions"], q["thumb_size"],
+                                            options={"context": ctx})
+        fi = cache.Feature_Image(t["size"], t["positions"], td, t["thumb_positions"], ttd, t["thumb_size"])
+        oq = fo.OQuery(qd, q["positions"], q["size"],
+                       thumb={"descriptors": qtd, "positions": q["thumb_positions"], "size": q["thumb_size"]})
+        ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
+              "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+        stats = {}
+        got = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})(0.8)
+        host = fastmatch.match(mc, fi, {"context": ctx, "device_loop": False})(0.8)
+        oget = fo.o_match(oq, ot, {})
+        exp = oget(0.8)
+        _same_matches(got, exp)
+        _same_matches(host, exp)
+        assert len(got) > 20 and stats["rounds"] == oget.rounds

@@ -185,6 +185,62 @@ def test_batched_rounds_match_oracle_per_round(ctx):
     assert _eq(tidx2[:393], tidx[:393]) and np.all(tidx2[393:] == -1)
 
 
+@pytest.mark.parametrize("kind", ["noisy_sift", "rootsift", "duplicates", "tiny_scale"])
+def test_batched_rounds_float32_route_match_oracle_per_round(ctx, kind):
+    """fm_xcheck1_batched on banks that are not integer valued: the float32 round (fp16 MFMA
+    filter + exact float32 chain) must equal the oracle's order-1 chain bit for bit, per round."""
+    rng = np.random.default_rng(77)
+    base_q = synth.synth_sift(5000, rng).astype(np.float32)
+    base_t = synth.synth_sift(4000, rng).astype(np.float32)
+    base_q[:1500] = base_t[:1500] + rng.normal(0, 4, (1500, 128)).astype(np.float32)     # planted near pairs
+    if kind == "noisy_sift":
+        Q = base_q + rng.uniform(-0.5, 0.5, base_q.shape).astype(np.float32)
+        T = base_t + rng.uniform(-0.5, 0.5, base_t.shape).astype(np.float32)
+    elif kind == "rootsift":
+        f = lambda d: np.sqrt(np.abs(d) / np.maximum(np.abs(d).sum(1, keepdims=True), 1)).astype(np.float32)
+        Q, T = f(base_q), f(base_t)
+    elif kind == "duplicates":                       # ties: equal rows on both sides -> lowest index wins
+        Q = (base_q + 0.25).astype(np.float32)
+        T = (base_t + 0.25).astype(np.float32)
+        Q[100:140] = Q[100]
+        Q[2000:2100] = T[7]
+        T[50:60] = T[50]
+        T[300:340] = Q[3]
+    else:
+        Q = ((base_q + 0.25) * 1e-4).astype(np.float32)
+        T = ((base_t + 0.25) * 1e-4).astype(np.float32)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    assert qb.kind == _ffi.FM_BANK_F32 and tb.kind == _ffi.FM_BANK_F32
+    sd = oracle.self_dist(Q, order=1)
+    qb.set_selfdist(sd)
+    sizes = [(393, 125), (1, 1), (0, 40), (50, 0), (130, 257), (1000, 33), (4096, 100), (37, 300), (256, 128), (257, 129)]
+    q_rows, q_off, t_off = [], [0], [0]
+    for nq, nt in sizes:
+        rows = rng.choice(5000, nq, replace=False)
+        if kind == "duplicates" and nq >= 130:
+            rows[:60] = np.arange(100, 160)          # duplicate query rows inside one round
+            rows[60:100] = np.arange(2000, 2040)
+        q_rows.append(rows)
+        q_off.append(q_off[-1] + nq)
+        t_off.append(t_off[-1] + nt)
+    q_rows = np.concatenate(q_rows).astype(np.int32)
+    tidx, dist, ratio = ctx.xcheck1_batched(qb, q_rows, q_off, tb, t_off)
+    for b, (nq, nt) in enumerate(sizes):
+        rows = q_rows[q_off[b]:q_off[b + 1]]
+        ot, od = oracle.bf_xcheck1(Q[rows], T[t_off[b]:t_off[b + 1]], order=1)
+        sl = slice(q_off[b], q_off[b + 1])
+        assert _eq(tidx[sl], ot) and _eq(dist[sl], od), "round %d" % b
+        m = ot >= 0
+        orat, _ = oracle.ratio_filter(od[m], sd, 0.7, qrows=rows[m])
+        assert _eq(ratio[sl][m], orat) and np.all(np.isnan(ratio[sl][~m]))
+    # and the dense float32 route gives the same answers on the gathered sub-matrices
+    rows = q_rows[:393]
+    sub = ctx.bank(Q[rows], float_route=True)
+    cell = ctx.bank(T[:125], float_route=True)
+    dt, dd = ctx.xcheck1(sub, cell)
+    assert _eq(dt, tidx[:393]) and _eq(dd, dist[:393])
+
+
 def test_matchutil_surface(ctx):
     Q, T, _ = synth.planted_pair(300, 280, seed=3)
     opts = {"context": ctx}
