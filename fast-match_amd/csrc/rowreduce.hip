@@ -26,6 +26,7 @@
 // the ds_read_b128 A-fragment reads are bank-conflict free.
 #include "tile_ops.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace fm {
 
@@ -48,6 +49,15 @@ struct RRParams {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Relaxed agent-scope load of a shared bound whose completion the CALLER tracks (NBUF == 3): the
+// compiler would put s_waitcnt vmcnt(0) in front of the first use, which also waits for the LDS-DMA
+// issued after the load.  The value is valid after a later s_waitcnt vmcnt(k) with k <= number of
+// VMEM operations issued after it (wait_dma_and_bounds below ties the registers to that wait).
+__device__ __forceinline__ void load_bound_untracked(int& dst, const int* ptr)
+{
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");
+}
+
 template <bool GLDS, int NW>
 __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* buf, int wave, int lane)
 {
@@ -58,7 +68,8 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
     for (int i = 0; i < kPieces; ++i) {
         const int g   = wave * kPieces + i;
         const int row = g * 8 + (lane >> 3);
-        const int8_t* src = src_rows + row * kDim + 16 * (slot ^ ((row >> 1) & 7));
+        // (uniform base + unsigned 32-bit lane offset: scalar-base addressing, no 64-bit VGPR pointers)
+        const int8_t* src = src_rows + (unsigned)(row * kDim + 16 * (slot ^ ((row >> 1) & 7)));
         if constexpr (GLDS) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(buf + g * 1024), 16, 0, 0);
         } else {
@@ -66,7 +77,7 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
         }
     }
     if (wave == NW - 1) {
-        const int32_t* src = p.red_aux + (size_t)stage * (kStageAuxBytes / 4) + lane * 4;
+        const int32_t* src = p.red_aux + (size_t)stage * (kStageAuxBytes / 4) + (unsigned)(lane * 4);
         if constexpr (GLDS) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(buf + kStageRowBytes), 16, 0, 0);
         } else {
@@ -76,11 +87,15 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 }
 
 // NW waves per workgroup share every staged tile; each wave owns NC blocks of 16 output rows.
-template <int NC, int KTOP, bool GLDS, int NW>
+// NBUF = LDS stage buffers: 2 = the stage consumed next is the one prefetched last (its LDS-DMA is
+// waited for with vmcnt(0) at every stage hand-over); 3 = prefetch two stages ahead, so the
+// hand-over only waits for a DMA issued a whole stage earlier and the newest one stays in flight.
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
 void rowreduce_kernel(RRParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
+    static_assert(NBUF == 2 || (NBUF == 3 && GLDS), "three stage buffers need the LDS-DMA path");
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -125,7 +140,8 @@ void rowreduce_kernel(RRParams p)
     for (int c = 0; c < 2; ++c) aoff[c] = c16 * kDim + 16 * ((g + 4 * c) ^ sw);
     const int xoff = kStageRowBytes + 16 * g;
 
-    if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
+    constexpr int kDmaPerWave = 16 / NW;
+    const int share_mask = p.share_every - 1;     // KTOP == 2: in-wave exchange of the lane groups' top-2 every N stages (0 = never)          // LDS-DMA instructions a wave issues per stage (+1 aux on the last wave)
 
     // Bounds published by the blocks that reduce other slices for the same output rows:
     // bound[n] is the K-th best hi some block has reached, so the final K-th best is
@@ -141,27 +157,58 @@ void rowreduce_kernel(RRParams p)
         gnext[j] = (p.bound && n < p.ncols_alloc)
             ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
     }
+    // prologue prefetch (issued AFTER the bound loads: vmcnt retires in order, so "at most the newest
+    // stage's DMA outstanding" implies that the bound loads and every older DMA have landed)
+    if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
+    if constexpr (NBUF == 3) {
+        if (st0 + 1 < st1) issue_stage<GLDS, NW>(p, st0 + 1, smem + kStageBytes, wave, lane);
+    }
 
     // One pipeline step on LDS buffer BUF (compile-time, so every ds_read address is
     // base register + immediate); the stage loop below is unrolled by two.
     auto stage = [&](auto buf_tag, int st) {
         constexpr int BUF = decltype(buf_tag)::value;
         char* buf = smem + BUF * kStageBytes;
-        if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // stage st landed; every wave is done with the other buffer
+        if constexpr (NBUF == 3) {
+            // stage st's DMA was issued two hand-overs ago; only the DMA of stage st + 1 (the newest
+            // VMEM operations of this wave, unless an exact path published a bound since) may still
+            // be in flight.  The bound loads (gnext) are older than that DMA, so they have landed too.
+            static_assert(NC == 4, "the wait below names four bound registers");
+            if (st + 1 < st1) {
+                if (wave == NW - 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) : "n"(kDmaPerWave + 1) : "memory");
+                else                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) : "n"(kDmaPerWave) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) :: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // stage st landed; every wave is done with the other buffer
+        }
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             gthr[j] = gnext[j] >> 1;                    // hi >= g possible iff acc >= floor(g / 2)
             thr[j] = max(thr[j], gthr[j]);
         }
-        if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
+        if constexpr (NBUF == 2) {
+            if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
+        }
         if (p.bound) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int n = cb + 16 * j + c16;
-                if (n < p.ncols_alloc)
-                    gnext[j] = __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (NBUF == 3) {
+                    // (ncols_alloc is a multiple of the chunk, so n is always inside the array)
+                    load_bound_untracked(gnext[j], p.bound + n);
+                } else {
+                    if (n < p.ncols_alloc)
+                        gnext[j] = __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
+        }
+        if constexpr (NBUF == 3) {
+            // (after the bound loads, see the prologue) into the buffer every wave left at the barrier above
+            if (st + 2 < st1) issue_stage<GLDS, NW>(p, st + 2, smem + ((BUF + 2) % 3) * kStageBytes, wave, lane);
         }
 
 #pragma unroll
@@ -207,9 +254,17 @@ void rowreduce_kernel(RRParams p)
         }
     };
 
-    for (int st = st0; st < st1; st += 2) {
-        stage(std::integral_constant<int, 0>{}, st);
-        if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+    if constexpr (NBUF == 3) {
+        for (int st = st0; st < st1; st += 3) {
+            stage(std::integral_constant<int, 0>{}, st);
+            if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+            if (st + 2 < st1) stage(std::integral_constant<int, 2>{}, st + 2);
+        }
+    } else {
+        for (int st = st0; st < st1; st += 2) {
+            stage(std::integral_constant<int, 0>{}, st);
+            if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+        }
     }
 
     // Merge the four lane groups (same output row, interleaved reduced rows), then emit.
@@ -298,9 +353,23 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     return pl;
 }
 
+// stage buffers: 3 for the top-1 kernel (its DMA wait leaves the hand-over), 2 for top-2 (at the
+// 128-VGPR limit the third buffer's bookkeeping spills); FM_NBUF overrides (read per launch)
+static int nbuf_choice(int ktop)
+{
+    if (const char* e = getenv("FM_NBUF")) { const int v = atoi(e); if (v == 2 || v == 3) return v; }
+    return ktop == 1 ? 3 : 2;
+}
+
 template <int NC, int KTOP, int NW>
 static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
 {
+    if constexpr (NC == 4 && NW == 8) {
+        if (glds && nbuf_choice(KTOP) == 3) {
+            hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3>), dim3(grid), dim3(64 * NW), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (glds) hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
     else      hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, false, NW>), dim3(grid), dim3(64 * NW), 0, stream, p);
     return hipGetLastError();

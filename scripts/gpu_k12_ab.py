@@ -1,0 +1,34 @@
+"""A/B of K1 / K2 launch knobs in ONE process on one box (run-to-run and box-to-box variance is
++-3 %): kernel time of fm_xcheck1 (K1) and fm_knn2 (K2) on the 100k x 100k pair, interleaved."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fastmatch_amd as fm
+from fastmatch_amd import synth
+
+ctx = fm.Context(0)
+Q, T, _ = synth.planted_pair(100000, 100000, 20250002)
+qb, tb = ctx.bank(Q), ctx.bank(T)
+variants = [dict(s.split("=") for s in v.split(",") if s) for v in (sys.argv[1:] or ["FM_NBUF=2", "FM_NBUF=3"])]
+res = {i: {"k1": [], "k2": []} for i in range(len(variants))}
+ref = None
+for rep in range(6):
+    for i, env in enumerate(variants):
+        for k in ("FM_NBUF", "FM_K2_SHARE", "FM_NSPLIT", "FM_NW"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for name, fn in (("k1", lambda: ctx.xcheck1(qb, tb)), ("k2", lambda: ctx.knn2(qb, tb))):
+            fn()
+            ctx.reset_stats()
+            for _ in range(10):
+                out = fn()
+            st = ctx.stats()
+            res[i][name].append(st["kernel_ms"] / st["kernel_launches"])
+        if ref is None:
+            ref = (ctx.xcheck1(qb, tb), ctx.knn2(qb, tb))
+        else:
+            a, b = ctx.xcheck1(qb, tb), ctx.knn2(qb, tb)
+            assert all(np.array_equal(x, y) for x, y in zip(a, ref[0])) and all(np.array_equal(x, y) for x, y in zip(b, ref[1])), "results differ"
+for i, env in enumerate(variants):
+    print("%-40s K1 min %.4f med %.4f ms | K2 min %.4f med %.4f ms" % (env, min(res[i]["k1"]), float(np.median(res[i]["k1"])),
+                                                                   min(res[i]["k2"]), float(np.median(res[i]["k2"]))), flush=True)
