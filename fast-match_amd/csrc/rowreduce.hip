@@ -140,8 +140,7 @@ void rowreduce_kernel(RRParams p)
     for (int c = 0; c < 2; ++c) aoff[c] = c16 * kDim + 16 * ((g + 4 * c) ^ sw);
     const int xoff = kStageRowBytes + 16 * g;
 
-    constexpr int kDmaPerWave = 16 / NW;
-    const int share_mask = p.share_every - 1;     // KTOP == 2: in-wave exchange of the lane groups' top-2 every N stages (0 = never)          // LDS-DMA instructions a wave issues per stage (+1 aux on the last wave)
+    constexpr int kDmaPerWave = 16 / NW;          // LDS-DMA instructions a wave issues per stage (+1 aux on the last wave)
 
     // Bounds published by the blocks that reduce other slices for the same output rows:
     // bound[n] is the K-th best hi some block has reached, so the final K-th best is
