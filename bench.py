@@ -249,11 +249,29 @@ def main():
     # the timed region.  On GPUs the rows never leave HBM (fm_match_accepted_dev).
     gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank)) if world > 1 else None
     device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
+    # FM_BENCH_GATHER=rccl: the library's own all-gather (fm_comm_init / fm_gather_matches, RCCL on the
+    # matching stream) instead of torch.distributed's; the id travels by a torch broadcast
+    abi_gather = None
+    if world > 1 and backend == "nccl" and os.environ.get("FM_BENCH_GATHER") == "rccl":
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+        cdev = torch.device("cuda", local_rank)
+        abi_gather = {"rows": torch.zeros((NQ, 3), dtype=torch.int32, device=cdev),
+                      "count": torch.zeros(1, dtype=torch.int64, device=cdev),
+                      "all_rows": torch.zeros((world, NQ, 3), dtype=torch.int32, device=cdev),
+                      "all_counts": torch.zeros(world, dtype=torch.int64, device=cdev)}
+        gatherer = None
 
     def step():
         n_acc = 0
         for qb, tb in banks:
-            if device_gather:
+            if abi_gather is not None:
+                g = abi_gather
+                n_acc += ctx.match_accepted_dev(qb, tb, TAU, g["rows"].data_ptr(), g["count"].data_ptr(), NQ)
+                ctx.gather_matches(g["rows"].data_ptr(), g["count"].data_ptr(), NQ, g["all_rows"].data_ptr(),
+                                   g["all_counts"].data_ptr(), wait=False)
+            elif device_gather:
                 rows, count = gatherer.send_buffers()
                 n_acc += ctx.match_accepted_dev(qb, tb, TAU, rows.data_ptr(), count.data_ptr(), NQ)
                 gatherer.submit_device()
@@ -281,6 +299,8 @@ def main():
         npass = step()
     if gatherer is not None:
         gatherer.finish()
+    if abi_gather is not None:
+        ctx.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -393,7 +413,8 @@ def main():
                                    % PAIRS_PER_STEP,
                        "nq": NQ, "nt": NT, "dim": 128, "tau": TAU, "pairs_per_gpu": PAIRS_PER_STEP,
                        "parallelism": "independent image pairs sharded over GPUs; RCCL all-gather of accepted matches"
-                                      + (" from device buffers" if device_gather else "")},
+                                      + (" (fm_gather_matches, C-ABI)" if abi_gather is not None else
+                                         " from device buffers" if device_gather else "")},
             "matches_per_s": npass_all * args.steps / elapsed,
             "accepted_matches_per_step": npass_all,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,

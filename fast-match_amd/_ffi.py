@@ -81,6 +81,10 @@ SYMBOLS = {
     "fm_expand_destroy": (_INT, [_P, _P]),
     "fm_expand_run": (_INT, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fm_expand_fetch": (_INT, [_P, _P, _I64, _P, _P, _P]),
+    "fm_comm_unique_id": (_INT, [_P]),
+    "fm_comm_init": (_INT, [_P, _INT, _INT, _P]),
+    "fm_comm_destroy": (_INT, [_P]),
+    "fm_gather_matches": (_INT, [_P, _P, _P, _I64, _P, _P, _INT]),
 }
 
 _lib = None
@@ -447,6 +451,29 @@ class Context(object):
         self._check(self.lib.fm_expand_run(self.handle, n, hs, sp, _ptr(ns), _ptr(tau), _ptr(nm), _ptr(nr),
                                            _ptr(npairs), _ptr(st)))
         return [(int(nm[i]), int(nr[i]), int(npairs[i]), int(st[i])) for i in range(n)]
+
+    # -- result gather over RCCL (fm_comm_*, fm_gather_matches) ----------------------------
+    def comm_unique_id(self):
+        """128 opaque bytes drawn by ONE rank; hand them to every rank's ``comm_init``."""
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.fm_comm_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.fm_last_error(None)
+            raise FastMatchHipError("fm_comm_unique_id failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        uid = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.fm_comm_init(self.handle, int(nranks), int(rank), uid))
+
+    def comm_destroy(self):
+        self._check(self.lib.fm_comm_destroy(self.handle))
+
+    def gather_matches(self, rows_ptr, count_ptr, cap, all_rows_ptr, all_counts_ptr, wait=True):
+        """All-gather the device rows / count left by ``match_accepted_dev`` into device buffers
+        [nranks, cap, 3] int32 and [nranks] int64 (addresses, e.g. ``tensor.data_ptr()``)."""
+        self._check(self.lib.fm_gather_matches(self.handle, _P(int(rows_ptr)), _P(int(count_ptr)), int(cap),
+                                               _P(int(all_rows_ptr)), _P(int(all_counts_ptr)), 1 if wait else 0))
 
     # -- bookkeeping ---------------------------------------------------------------------
     def stats(self):

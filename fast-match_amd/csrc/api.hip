@@ -45,6 +45,8 @@ struct fm_ctx {
     char*  h_stage = nullptr; size_t h_stage_bytes = 0, h_stage_used = 0;
     struct StagedCopy { void* dst; size_t off, bytes; };
     std::vector<StagedCopy> staged;
+    void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
+    int   comm_ranks = 0;
     fm_stats stats{};
     bool kernel_timed = false;
     int64_t pending_pairs = 0;
@@ -526,6 +528,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (!ctx) return FM_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
     if (ctx->ws_partial) (void)hipFree(ctx->ws_partial);
     if (ctx->ws_out) (void)hipFree(ctx->ws_out);
     if (ctx->ws_in) (void)hipFree(ctx->ws_in);
@@ -1549,5 +1552,58 @@ extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int3
     if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ex->dev.m_ratio, (size_t)n * 8));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// result gather over RCCL (comm.hip)
+// ---------------------------------------------------------------------------------------
+extern "C" int fm_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(nullptr, FM_EINVAL, "fm_comm_unique_id: NULL buffer");
+    std::string err;
+    const int rc = comm_unique_id(id128, &err);
+    return rc == FM_OK ? FM_OK : fail(nullptr, rc, "fm_comm_unique_id: " + err);
+}
+
+extern "C" int fm_comm_init(fm_ctx* ctx, int nranks, int rank, const void* id128)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_comm_init: ctx is NULL");
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, FM_EINVAL, "fm_comm_init: bad argument");
+    if (ctx->comm) return fail(ctx, FM_EINVAL, "fm_comm_init: the context already has a communicator (fm_comm_destroy first)");
+    std::string err;
+    void* comm = nullptr;
+    const int rc = comm_init(ctx->device, nranks, rank, id128, &comm, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_comm_init: " + err);
+    ctx->comm = comm;
+    ctx->comm_ranks = nranks;
+    return FM_OK;
+}
+
+extern "C" int fm_comm_destroy(fm_ctx* ctx)
+{
+    if (!ctx) return FM_OK;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        comm_destroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_ranks = 0;
+    }
+    return FM_OK;
+}
+
+extern "C" int fm_gather_matches(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                                 int32_t* d_all_rows, int64_t* d_all_counts, int wait)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_gather_matches: ctx is NULL");
+    if (!ctx->comm) return fail(ctx, FM_EINVAL, "fm_gather_matches: no communicator (fm_comm_init)");
+    if (cap < 0 || !d_count || !d_all_counts || (cap > 0 && (!d_rows || !d_all_rows)))
+        return fail(ctx, FM_EINVAL, "fm_gather_matches: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = comm_gather(ctx->comm, d_rows, d_count, cap, d_all_rows, d_all_counts, ctx->stream, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches: " + err);
+    if (wait) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FM_OK;
 }

@@ -106,6 +106,13 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
 hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream);
 int expand_cand_cap();
 
+// ---- result gather over RCCL (comm.hip; RCCL is dlopen'ed on first use) -----------------------
+int comm_unique_id(void* id128, std::string* err);
+int comm_init(int device, int nranks, int rank, const void* id128, void** comm_out, std::string* err);
+int comm_destroy(void* comm);
+int comm_gather(void* comm, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                int32_t* d_all_rows, int64_t* d_all_counts, hipStream_t stream, std::string* err);
+
 }  // namespace fm
 
 struct fm_bank : fm::Bank {};

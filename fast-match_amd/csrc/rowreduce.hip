@@ -44,6 +44,7 @@ struct RRParams {
     int            ncols_alloc;
     unsigned long long* partial;
     int*           bound;         // [ncols_alloc] shared K-th-best bounds (INT32_MIN filled) or null
+    int            prio;          // bit 0: s_setprio around the MFMA burst of a unit
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -213,6 +214,7 @@ void rowreduce_kernel(RRParams p)
 #pragma unroll
         for (int u = 0; u < kStageRows / kTileRows; ++u) {          // 32-row units
             v4i acc[2][NC];
+            if (p.prio & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const char* rows = buf + (32 * u + 16 * s) * kDim;
@@ -224,6 +226,7 @@ void rowreduce_kernel(RRParams p)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) acc[s][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j][1], acc[s][j], 0, 0, 0);
             }
+            if (p.prio & 1) __builtin_amdgcn_s_setprio(0);
             int tmax[NC];
             bool any = false;
 #pragma unroll
@@ -408,6 +411,8 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
     p.stages_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
+    p.prio = 1;       // raise the wave's priority while it issues a unit's MFMAs (A/B: -0.3 %); FM_PRIO=0 turns it off
+    if (const char* e = getenv("FM_PRIO")) p.prio = atoi(e);
     const int grid = plan.nchunks * plan.nsplit;
     return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, stream)
                      : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, stream);

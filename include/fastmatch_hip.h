@@ -231,6 +231,24 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
 int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index,
                      double* positions, double* ratio);
 
+/* ---- result gather across the GPUs of a node (RCCL over xGMI) --------------------------------
+ * Independent image pairs are sharded over ranks (one process per GPU, pair i -> rank i mod N);
+ * matching needs no communication and the per-pair match lists come back with ONE exchange: an
+ * all-gather of every rank's accepted rows and their counts.  The reference is single process
+ * (turntable.py:59 maps the matcher over its pairs sequentially); this is the data-parallel axis
+ * it implies.  RCCL is bound at run time (dlopen), so a process that never gathers needs none.
+ *   fm_comm_unique_id : rank 0 draws the 128-byte id; the launcher hands it to every rank.
+ *   fm_comm_init      : collective; binds the context's device and stream to the communicator.
+ *   fm_gather_matches : d_rows / d_count as fm_match_accepted_dev leaves them (device memory);
+ *                       d_all_rows [nranks][cap][3] int32, d_all_counts [nranks] int64 (device).
+ *                       Runs on the context's stream behind the matching kernels; wait != 0
+ *                       synchronises before returning, wait == 0 returns at once (fm_sync later).  */
+int  fm_comm_unique_id(void* id128);
+int  fm_comm_init(fm_ctx* ctx, int nranks, int rank, const void* id128);
+int  fm_comm_destroy(fm_ctx* ctx);
+int  fm_gather_matches(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                       int32_t* d_all_rows, int64_t* d_all_counts, int wait);
+
 #ifdef __cplusplus
 }
 #endif

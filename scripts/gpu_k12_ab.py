@@ -14,7 +14,7 @@ res = {i: {"k1": [], "k2": []} for i in range(len(variants))}
 ref = None
 for rep in range(6):
     for i, env in enumerate(variants):
-        for k in ("FM_NBUF", "FM_K2_SHARE", "FM_NSPLIT", "FM_NW"):
+        for k in ("FM_NBUF", "FM_PRIO", "FM_NSPLIT", "FM_NW", "FM_NB"):
             os.environ.pop(k, None)
         os.environ.update(env)
         for name, fn in (("k1", lambda: ctx.xcheck1(qb, tb)), ("k2", lambda: ctx.knn2(qb, tb))):

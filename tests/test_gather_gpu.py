@@ -66,6 +66,39 @@ def test_device_rows_capacity_and_errors(ctx):
         ctx.match_accepted_dev(qb, tb, 0.9, 0, count.data_ptr(), cap)
 
 
+def test_rccl_gather_through_the_c_abi_one_rank():
+    """fm_comm_unique_id / fm_comm_init / fm_gather_matches: the library's own RCCL all-gather of
+    the device rows (world size 1 here; RCCL refuses two ranks on one GPU)."""
+    import torch
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)                      # own context: the communicator binds to it
+    Q, T, qb, tb = _banks(c, 3000, 2600, seed=5)
+    dev = torch.device("cuda", 0)
+    cap = 3000
+    rows = torch.full((cap, 3), -7, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    all_rows = torch.full((1, cap, 3), -9, dtype=torch.int32, device=dev)
+    all_counts = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    uid = c.comm_unique_id()
+    assert len(uid) == 128
+    c.comm_init(1, 0, uid)
+    try:
+        for tau in (0.7, 0.9):
+            n = c.match_accepted_dev(qb, tb, tau, rows.data_ptr(), count.data_ptr(), cap)
+            c.gather_matches(rows.data_ptr(), count.data_ptr(), cap, all_rows.data_ptr(), all_counts.data_ptr())
+            qa, ta, da, _ = c.match_accepted(qb, tb, tau)
+            assert int(all_counts[0].item()) == n == len(qa) > 100
+            assert np.array_equal(all_rows[0, :n].cpu().numpy(), sharding.pack_matches(qa, ta, da))
+        from fastmatch_amd import _ffi
+        with pytest.raises(_ffi.FastMatchHipError):   # a second communicator on the same context
+            c.comm_init(1, 0, uid)
+    finally:
+        c.comm_destroy()
+    with pytest.raises(fastmatch_amd.FastMatchHipError):
+        c.gather_matches(rows.data_ptr(), count.data_ptr(), cap, all_rows.data_ptr(), all_counts.data_ptr())
+    c.close()
+
+
 _RANK_SCRIPT = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
