@@ -12,7 +12,8 @@ scaling: the batch per GPU is fixed as N grows; SURVEY.md 8(d) C2, seed 20250002
 A step = one pass of the hot path over that batch: per pair, cross-checked 1-NN (OpenCV
 BFMatcher crossCheck semantics) + float64 ratio test at tau = 0.7 against the query bank's
 self distances + ordered compaction of the accepted matches on the device.  N = 1: the
-accepted matches land in caller-owned page-locked host buffers (fm_match_accepted); N > 1:
+accepted matches land in caller-owned page-locked host buffers, the pairs of a step enqueued back
+to back with one synchronisation per step (fm_match_accepted_async); N > 1:
 they stay on the device as packed 12-byte rows (fm_match_accepted_dev) and go straight into
 the RCCL all-gather, overlapped with the next pair's kernels.
 Prints ONE JSON line (rank 0).  Beside the headline it carries legs for the other BASELINE
@@ -240,9 +241,14 @@ def main():
         banks.append((qb, tb))
         del Qj, Tj
 
-    # N = 1: caller-owned output buffers in page-locked memory (results arrive by direct DMA)
-    outbuf = (ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
-              ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64))
+    # N = 1: caller-owned output buffers in page-locked memory, one set per pair of the batch: the
+    # compaction kernel writes them directly and the pairs of a step are enqueued back to back
+    # (fm_match_accepted_async), one synchronisation per step
+    outbufs = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
+                ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64)) for _ in range(PAIRS_PER_STEP)]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
+    outbuf = outbufs[0]
+    use_async = world == 1 and os.environ.get("FM_BENCH_SYNC") != "1"
 
     # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
@@ -265,6 +271,11 @@ def main():
 
     def step():
         n_acc = 0
+        if use_async:
+            for j, (qb, tb) in enumerate(banks):
+                ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
+            ctx.sync()                                      # results of the whole batch are on the host now
+            return int(sum(int(c[0]) for c in counts))
         for qb, tb in banks:
             if abi_gather is not None:
                 g = abi_gather

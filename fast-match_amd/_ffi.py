@@ -75,6 +75,7 @@ SYMBOLS = {
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "fm_expand_create": (_INT, [_P, ctypes.POINTER(fm_expand_desc), ctypes.POINTER(_P)]),
@@ -374,6 +375,17 @@ class Context(object):
                     or not a.flags.writeable:
                 raise ValueError("out buffers must be writable contiguous 1-D int32/int32/float32/float64 of one length")
         return cap
+
+    def match_accepted_async(self, q, t, tau, out, count):
+        """Enqueue X1 + R1 + compaction and return at once.  ``out`` = (qidx, tidx, dist, ratio)
+        and ``count`` (int64[1]) must come from ``pinned_empty``; they are valid after ``sync()``:
+        ``m = int(count[0])`` accepted matches in ``out[i][:m]``."""
+        cap = self._check_accepted_out(out)
+        if not isinstance(count, np.ndarray) or count.dtype != np.int64 or count.size < 1:
+            raise ValueError("count must be an int64 array (pinned_empty(1, np.int64))")
+        qidx, tidx, dist, ratio = out
+        self._check(self.lib.fm_match_accepted_async(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx),
+                                                     _ptr(tidx), _ptr(dist), _ptr(ratio), _ptr(count)))
 
     def match_accepted_dev(self, q, t, tau, rows_ptr, count_ptr, cap):
         """X1 + R1 with the accepted matches left on the device: ``rows_ptr`` = device address of

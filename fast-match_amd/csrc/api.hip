@@ -45,6 +45,10 @@ struct fm_ctx {
     char*  h_stage = nullptr; size_t h_stage_bytes = 0, h_stage_used = 0;
     struct StagedCopy { void* dst; size_t off, bytes; };
     std::vector<StagedCopy> staged;
+    // calls enqueued without a synchronisation (fm_match_accepted_async): their events, read at fm_sync
+    struct PendingTimer { hipEvent_t c0, c1, k0, k1; bool timed; int64_t pairs; };
+    std::vector<PendingTimer> pending;       // in flight
+    std::vector<PendingTimer> timer_pool;    // idle event sets
     void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
     int   comm_ranks = 0;
     fm_stats stats{};
@@ -529,6 +533,8 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
+    for (auto* v : {&ctx->pending, &ctx->timer_pool})
+        for (auto& t : *v) { (void)hipEventDestroy(t.c0); (void)hipEventDestroy(t.c1); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
     if (ctx->ws_partial) (void)hipFree(ctx->ws_partial);
     if (ctx->ws_out) (void)hipFree(ctx->ws_out);
     if (ctx->ws_in) (void)hipFree(ctx->ws_in);
@@ -544,17 +550,42 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     return FM_OK;
 }
 
+// Account the calls that were enqueued without a synchronisation; the stream must be idle.
+static int drain_pending(fm_ctx* ctx)
+{
+    for (auto& t : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.c0, t.c1) == hipSuccess) { ctx->stats.total_ms += ms; ctx->stats.calls += 1; }
+        else (void)hipGetLastError();
+        if (t.timed) {
+            if (hipEventElapsedTime(&ms, t.k0, t.k1) == hipSuccess) {
+                ctx->stats.kernel_ms += ms;
+                ctx->stats.kernel_launches += 1;
+                ctx->stats.pairs += t.pairs;
+            } else (void)hipGetLastError();
+        }
+        ctx->timer_pool.push_back(t);
+    }
+    ctx->pending.clear();
+    return FM_OK;
+}
+
 extern "C" int fm_sync(fm_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_sync: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return FM_OK;
+    return drain_pending(ctx);
 }
 
 extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)
 {
     if (!ctx || !out) return fail(ctx, FM_EINVAL, "fm_get_stats: NULL argument");
+    if (!ctx->pending.empty()) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        drain_pending(ctx);
+    }
     *out = ctx->stats;
     return FM_OK;
 }
@@ -1038,7 +1069,7 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
                          const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr,
-                         int32_t* dev_rows = nullptr, long long* dev_count = nullptr)
+                         int32_t* dev_rows = nullptr, long long* dev_count = nullptr, bool async_mode = false)
 {
     const bool compact = compact_cap >= 0;
     const bool to_device = dev_rows != nullptr;
@@ -1078,6 +1109,51 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
     }
 
+    if (async_mode) {
+        // Enqueue and return: outputs (and the count) are page-locked caller memory the compaction
+        // kernel writes directly; the events of this call are read at fm_sync.
+        void* a_q = pinned_device_alias(c_qidx); void* a_t = pinned_device_alias(tidx);
+        void* a_d = pinned_device_alias(dist);   void* a_r = pinned_device_alias(ratio);
+        void* a_c = pinned_device_alias(n_pass);
+        if (!a_q || !a_t || !a_d || !a_r || !a_c || f32)
+            return fail(ctx, FM_EINVAL, std::string(who) + ": needs integer-valued banks and page-locked outputs (fm_host_alloc)");
+        fm_ctx::PendingTimer tm;
+        if (!ctx->timer_pool.empty()) { tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back(); }
+        else {
+            if (ctx->pending.size() >= 1024) {                 // bound the number of live events
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                drain_pending(ctx);
+                tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back();
+            } else {
+                HIP_TRY(ctx, hipEventCreate(&tm.c0)); HIP_TRY(ctx, hipEventCreate(&tm.c1));
+                HIP_TRY(ctx, hipEventCreate(&tm.k0)); HIP_TRY(ctx, hipEventCreate(&tm.k1));
+            }
+        }
+        tm.timed = nt > 0;
+        tm.pairs = nq * nt;
+        HIP_TRY(ctx, hipEventRecord(tm.c0, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
+        if (nt > 0) {
+            if (d_bound)
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(tm.k1, ctx->stream));
+            hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest);
+        }
+        hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)d_qbest, nq, (const double*)q->selfdist, tau, d_tidx, d_dist, d_ratio,
+                           d_pass, d_cnt, f32, (int*)(base + o_bc));
+        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                           (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
+                           (const int*)(base + o_bc), nq, compact_cap < nq ? compact_cap : nq, (int32_t*)a_q, (int32_t*)a_t,
+                           (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream));
+        ctx->pending.push_back(tm);
+        return FM_OK;
+    }
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
     if (!compact) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
@@ -1228,6 +1304,16 @@ extern "C" int fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t
 {
     if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted: cap < 0");
     return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, nullptr, n_accepted, "fm_match_accepted", cap, qidx);
+}
+
+extern "C" int fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                                       int32_t* qidx, int32_t* tidx, float* dist, double* ratio, int64_t* n_accepted)
+{
+    if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted_async: cap < 0");
+    if (!n_accepted) return fail(ctx, FM_EINVAL, "fm_match_accepted_async: n_accepted is NULL");
+    if (q && q->n == 0) { *n_accepted = 0; }
+    return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, nullptr, n_accepted, "fm_match_accepted_async", cap, qidx,
+                         nullptr, nullptr, true);
 }
 
 extern "C" int fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,

@@ -153,6 +153,16 @@ int  fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double t
                        int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
                        int64_t* n_accepted);
 
+/* As fm_match_accepted, but the call only ENQUEUES the work on the context's stream and returns:
+ * the results are valid after the next fm_sync(ctx) (or any synchronous call on the context).
+ * Every output -- qidx, tidx, dist, ratio and *n_accepted -- must be page-locked host memory
+ * (fm_host_alloc), which the compaction kernel writes directly; banks must be integer valued.
+ * A stream of image pairs then runs back to back on the GPU with no host round
+ * trip between pairs (the reference maps its matcher over pairs sequentially, turntable.py:59).  */
+int  fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                             int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
+                             int64_t* n_accepted /*page-locked*/);
+
 /* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
  * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
  * them) and *d_count = total accepted, both in caller-supplied DEVICE memory -- the send

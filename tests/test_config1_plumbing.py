@@ -119,7 +119,7 @@ def test_readme_flow_on_pixels_equals_oracle(ctx, tmp_path, monkeypatch):
     # query image + query thumbnail + target thumbnail + one call per grid cell the expansion
     # reached (lazy: cache.pyx:102-106), far fewer than the 17 x 13 cells of the grid
     n_cells = len(calls) - 3
-    assert calls[0] == (640, 800, 3) and 10 < n_cells < 17 * 13
+    assert calls[0] == (480, 600, 3) and calls[1] == (640, 800, 3) and 10 < n_cells < 17 * 13   # thumbnail, then full image (cache.pyx:168-169)
     assert all(c[0] <= 100 and c[1] <= 100 for c in calls[3:])
     assert os.path.isfile("data/image_data/%s.npz" % cache._ripemd160(query_path.encode()))
     again = cache.Metric_Cache(query_path, {"context": ctx})              # second time: load() hit, no features needed

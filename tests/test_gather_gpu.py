@@ -66,6 +66,37 @@ def test_device_rows_capacity_and_errors(ctx):
         ctx.match_accepted_dev(qb, tb, 0.9, 0, count.data_ptr(), cap)
 
 
+def test_async_stream_of_pairs_equals_the_synchronous_calls(ctx):
+    """fm_match_accepted_async: several image pairs enqueued back to back, one fm_sync; every
+    pair's accepted matches equal the synchronous call's, and the stats account every launch."""
+    from fastmatch_amd import _ffi
+    pairs = [_banks(ctx, 2500 + 300 * k, 2000 + 250 * k, seed=40 + k) for k in range(5)]
+    outs = [(ctx.pinned_empty(4000, np.int32), ctx.pinned_empty(4000, np.int32),
+             ctx.pinned_empty(4000, np.float32), ctx.pinned_empty(4000, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    ctx.sync()
+    ctx.reset_stats()
+    for rep in range(2):
+        for (Q, T, qb, tb), out, cnt in zip(pairs, outs, counts):
+            cnt[0] = -1
+            ctx.match_accepted_async(qb, tb, 0.7, out, cnt)
+        ctx.sync()
+        for (Q, T, qb, tb), out, cnt in zip(pairs, outs, counts):
+            m = int(cnt[0])
+            qa, ta, da, ra = ctx.match_accepted(qb, tb, 0.7)
+            assert m == len(qa) > 50
+            assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta)
+            assert np.array_equal(out[2][:m], da) and np.array_equal(out[3][:m], ra)
+    st = ctx.stats()
+    assert st["kernel_launches"] == 20 and st["calls"] == 20           # 10 async + 10 sync
+    assert st["pairs"] == 4 * sum(len(p[0]) * len(p[1]) for p in pairs)
+    with pytest.raises(_ffi.FastMatchHipError):                        # pageable outputs are refused
+        ctx.match_accepted_async(pairs[0][2], pairs[0][3], 0.7,
+                                 (np.empty(4000, np.int32), np.empty(4000, np.int32), np.empty(4000, np.float32), np.empty(4000, np.float64)),
+                                 counts[0])
+    ctx.sync()
+
+
 def test_rccl_gather_through_the_c_abi_one_rank():
     """fm_comm_unique_id / fm_comm_init / fm_gather_matches: the library's own RCCL all-gather of
     the device rows (world size 1 here; RCCL refuses two ranks on one GPU)."""
