@@ -44,7 +44,6 @@ struct RRParams {
     int            ncols_alloc;
     unsigned long long* partial;
     int*           bound;         // [ncols_alloc] shared K-th-best bounds (INT32_MIN filled) or null
-    int            prio;          // bit 0: s_setprio around the MFMA burst of a unit
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -91,7 +90,7 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 // NBUF = LDS stage buffers: 2 = the stage consumed next is the one prefetched last (its LDS-DMA is
 // waited for with vmcnt(0) at every stage hand-over); 3 = prefetch two stages ahead, so the
 // hand-over only waits for a DMA issued a whole stage earlier and the newest one stays in flight.
-template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2>
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2, int PRIO = 0>
 __global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
 void rowreduce_kernel(RRParams p)
 {
@@ -214,7 +213,7 @@ void rowreduce_kernel(RRParams p)
 #pragma unroll
         for (int u = 0; u < kStageRows / kTileRows; ++u) {          // 32-row units
             v4i acc[2][NC];
-            if (p.prio & 1) __builtin_amdgcn_s_setprio(2);
+            if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const char* rows = buf + (32 * u + 16 * s) * kDim;
@@ -226,7 +225,7 @@ void rowreduce_kernel(RRParams p)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) acc[s][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j][1], acc[s][j], 0, 0, 0);
             }
-            if (p.prio & 1) __builtin_amdgcn_s_setprio(0);
+            if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
             int tmax[NC];
             bool any = false;
 #pragma unroll
@@ -367,8 +366,13 @@ template <int NC, int KTOP, int NW>
 static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
 {
     if constexpr (NC == 4 && NW == 8) {
+        // PRIO: s_setprio 2 while a wave issues a unit's 16 MFMAs as one burst, back to 0 for the
+        // epilogue (A/B on one box: 0.897 -> 0.887 ms); FM_PRIO=0 selects the variant without it
+        const char* pe = getenv("FM_PRIO");
+        const bool prio = !(pe && atoi(pe) == 0);
         if (glds && nbuf_choice(KTOP) == 3) {
-            hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3>), dim3(grid), dim3(64 * NW), 0, stream, p);
+            if (prio) hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 1>), dim3(grid), dim3(64 * NW), 0, stream, p);
+            else      hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 0>), dim3(grid), dim3(64 * NW), 0, stream, p);
             return hipGetLastError();
         }
     }
@@ -411,8 +415,6 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
     p.stages_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
-    p.prio = 1;       // raise the wave's priority while it issues a unit's MFMAs (A/B: -0.3 %); FM_PRIO=0 turns it off
-    if (const char* e = getenv("FM_PRIO")) p.prio = atoi(e);
     const int grid = plan.nchunks * plan.nsplit;
     return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, stream)
                      : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, stream);
