@@ -518,7 +518,7 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
     if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
     if (const char* s = getenv("FM_COOP")) ctx->use_coop = atoi(s) != 0;
     if (const char* s = getenv("FM_F32_FILTER")) ctx->f32_filter = atoi(s);
-    if (hipMalloc((void**)&ctx->d_counters, 16 + 1024) != hipSuccess || hipMemset(ctx->d_counters, 0, 16 + 1024) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_counters, filter_flag_bytes()) != hipSuccess || hipMemset(ctx->d_counters, 0, filter_flag_bytes()) != hipSuccess) {
         (void)hipGetLastError();
         ctx->d_counters = nullptr;
         ctx->f32_filter = 0;

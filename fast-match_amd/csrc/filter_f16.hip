@@ -70,6 +70,12 @@ struct FParams {
     unsigned long long* slots; // [nsplit][ncols_alloc][4][kFP]  (acc bits << 32 | row), ~0 = none
     int*         bound;        // [2][ncols_alloc] ordered-int images: best acc, 2nd best acc (see below)
     int*         flag;
+    // nsplit == 1: the wave that owns an output row has seen all of its reduced rows, so it
+    // rescores its own entries at the end instead of emitting them for rescore_kernel
+    int          fused;
+    const float* col_rowsf;
+    const float* red_rowsf;
+    unsigned long long* partial;   // [n][KTOP] packed keys (split 0 of the caller's layout)
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -317,6 +323,71 @@ void filter_kernel(FParams p)
     // emit every entry; rescore_kernel filters them against the final bound
 #pragma unroll
     for (int j = 0; j < NC; ++j) { settle(j); publish(j); }
+    if (p.fused) {
+        // ---- exact rescoring in place (the rule of rescore_kernel below, on registers) --------------
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            settle(j);
+            const int n = cb + 16 * j + c16;
+            const bool ok = n < p.ncols;
+            // K-th best accumulator over the four lane groups (disjoint rows of the same output rows)
+            float b1 = ea[j][0], b2 = KTOP == 2 ? ea[j][1] : kFEmpty;
+#pragma unroll
+            for (int mask = 16; mask <= 32; mask <<= 1) {
+                const float o1 = __shfl_xor(b1, mask), o2 = __shfl_xor(b2, mask);
+                const float lo = fminf(b1, o1);
+                b1 = fmaxf(b1, o1);
+                b2 = fmaxf(fmaxf(b2, o2), lo);
+            }
+            const float fthr = (KTOP == 2 ? b2 : b1) - marg[j];
+            const float4* cp = (const float4*)(p.col_rowsf + (size_t)(ok ? n : 0) * kDim);
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            int redo = 0;
+#pragma unroll
+            for (int i = 0; i < kFP; ++i) {
+                const bool valid = ok && ei[j][i] >= 0 && ei[j][i] < p.nred && ea[j][i] >= fthr;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+                if (valid) {
+                    if (i == kFP - 1) redo = 1;      // the lane's last entry inside the margin: rows it dropped may be too
+                    const float4* rp = (const float4*)(p.red_rowsf + (size_t)ei[j][i] * kDim);
+                    float sum = 0.f;
+#pragma unroll 8
+                    for (int k4 = 0; k4 < kDim / 4; ++k4) {
+                        const float4 a = cp[k4];
+                        const float4 b = rp[k4];
+                        float v;
+                        v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
+                        v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
+                        v = a.z - b.z; sum = __builtin_fmaf(v, v, sum);
+                        v = a.w - b.w; sum = __builtin_fmaf(v, v, sum);
+                    }
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(sqrtf(sum)) << 32) | (unsigned)ei[j][i];
+                    if (key < k0) { k1 = k0; k0 = key; }
+                    else if (key < k1) { k1 = key; }
+                }
+            }
+#pragma unroll
+            for (int mask = 16; mask <= 32; mask <<= 1) {
+                const unsigned long long o0 = __shfl_xor(k0, mask), o1 = __shfl_xor(k1, mask);
+                const unsigned long long lo = k0 < o0 ? k0 : o0, hi = k0 < o0 ? o0 : k0;
+                const unsigned long long m1 = k1 < o1 ? k1 : o1;
+                k0 = lo;
+                k1 = hi < m1 ? hi : m1;
+                redo |= __shfl_xor(redo, mask);
+            }
+            if (ok && g == 0) {
+                p.partial[(size_t)n * KTOP] = k0;
+                if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = k1;
+                if (redo) {
+                    const int pos = atomicAdd(p.flag + 1, 1);
+                    atomicAdd(p.flag + 3, 1);
+                    if (pos < kFMaxRescan) p.flag[4 + pos] = n;
+                    else atomicOr(p.flag, 1);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         settle(j);
@@ -409,19 +480,29 @@ void rescore_kernel(RParams p)
     }
 }
 
-// Full exact scan for the few output rows whose candidate lists could be incomplete: one
-// workgroup per such row, thread t takes rows t, t + 256, ... of the reduced bank.
+// Full exact scan for the few output rows whose candidate lists could be incomplete.  A row's
+// scan is split over kFRescanSplit workgroups (thread t of part s takes rows s * chunk + t,
+// + 256, ...), each part leaves its top-2 in the scratch behind the flag words, and the part that
+// arrives last (a ticket per row) merges them: a 10k-row scan takes ~8 us instead of ~120 us.
+constexpr int kFRescanSplit = 16;
+
 template <int KTOP>
 __global__ __launch_bounds__(256)
 void rescan_kernel(RParams p, int nred)
 {
     __shared__ unsigned long long sk[256 * 2];
+    __shared__ int last;
     const int cnt = min(p.flag[1], kFMaxRescan);
-    if ((int)blockIdx.x >= cnt || p.flag[0] != 0) return;
-    const int n = p.flag[4 + blockIdx.x];
+    const int slot = blockIdx.x / kFRescanSplit, part = blockIdx.x % kFRescanSplit;
+    if (slot >= cnt || p.flag[0] != 0) return;
+    const int n = p.flag[4 + slot];
+    int* tickets = p.flag + 4 + kFMaxRescan;
+    unsigned long long* scratch = (unsigned long long*)(p.flag + 4 + 2 * kFMaxRescan) + (size_t)slot * kFRescanSplit * 2;
+    const int chunk = (nred + kFRescanSplit - 1) / kFRescanSplit;
+    const int m0 = part * chunk, m1 = min(nred, m0 + chunk);
     const float4* cp = (const float4*)(p.col_rowsf + (size_t)n * kDim);
     unsigned long long k0 = ~0ull, k1 = ~0ull;
-    for (int m = threadIdx.x; m < nred; m += 256) {
+    for (int m = m0 + threadIdx.x; m < m1; m += 256) {
         const float4* rp = (const float4*)(p.red_rowsf + (size_t)m * kDim);
         float sum = 0.f;
 #pragma unroll 8
@@ -446,15 +527,29 @@ void rescan_kernel(RParams p, int nred)
             const unsigned long long a0 = sk[2 * threadIdx.x], a1 = sk[2 * threadIdx.x + 1];
             const unsigned long long o0 = sk[2 * (threadIdx.x + w)], o1 = sk[2 * (threadIdx.x + w) + 1];
             const unsigned long long lo = a0 < o0 ? a0 : o0, hi = a0 < o0 ? o0 : a0;
-            const unsigned long long m1 = a1 < o1 ? a1 : o1;
+            const unsigned long long m1k = a1 < o1 ? a1 : o1;
             sk[2 * threadIdx.x] = lo;
-            sk[2 * threadIdx.x + 1] = hi < m1 ? hi : m1;
+            sk[2 * threadIdx.x + 1] = hi < m1k ? hi : m1k;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        p.partial[(size_t)n * KTOP] = sk[0];
-        if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = sk[1];
+        __hip_atomic_store(scratch + 2 * part, sk[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(scratch + 2 * part + 1, sk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(&tickets[slot], 1) == kFRescanSplit - 1) ? 1 : 0;
+        if (last) {
+            __threadfence();
+            unsigned long long b0 = ~0ull, b1 = ~0ull;
+            for (int q = 0; q < 2 * kFRescanSplit; ++q) {
+                const unsigned long long v = __hip_atomic_load(scratch + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v < b0) { b1 = b0; b0 = v; }
+                else if (v < b1) { b1 = v; }
+            }
+            p.partial[(size_t)n * KTOP] = b0;
+            if constexpr (KTOP == 2) p.partial[(size_t)n * KTOP + 1] = b1;
+            tickets[slot] = 0;                              // ready for the next call
+        }
     }
 }
 
@@ -491,6 +586,8 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
     pl.stages_per_split = (int)per;
     return pl;
 }
+
+size_t filter_flag_bytes() { return (size_t)(4 + 2 * kFMaxRescan) * 4 + (size_t)kFMaxRescan * kFRescanSplit * 2 * 8; }
 
 int filter_empty_bound()
 {
@@ -531,6 +628,11 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     p.slots = slots;
     p.bound = bound;
     p.flag = flag;
+    p.fused = (pl.nsplit == 1 && cols.n > 0) ? 1 : 0;
+    if (const char* e = getenv("FM_F32_FUSED")) p.fused = (atoi(e) != 0 && pl.nsplit == 1 && cols.n > 0) ? 1 : 0;
+    p.col_rowsf = cols.rowsf;
+    p.red_rowsf = red.rowsf;
+    p.partial = partial;
     const int grid = pl.nchunks * pl.nsplit;
 #define FM_LAUNCH_FILTER(NC_, NW_)                                                                         \
     do {                                                                                                   \
@@ -555,7 +657,11 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     r.ncols = (int)cols.n;
     r.partial = partial;
     r.flag = flag;
-    if (cols.n > 0) {
+    if (cols.n > 0 && p.fused) {
+        // the filter rescored its own entries; only the flagged rows are left
+        if (ktop == 1) hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan * kFRescanSplit), dim3(256), 0, stream, r, (int)red.n);
+        else           hipLaunchKernelGGL((rescan_kernel<2>), dim3(kFMaxRescan * kFRescanSplit), dim3(256), 0, stream, r, (int)red.n);
+    } else if (cols.n > 0) {
         // lanes per output row: few slots and many rows -> one lane each (every lane of a wave
         // then runs a chain), else 16 or 64 lanes share a row's slots
         const int nslots = pl.nsplit * 4 * kFP;
@@ -567,7 +673,7 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
             if (lpc == 1)       hipLaunchKernelGGL((rescore_kernel<K_, 1>), dim3(rgrid), dim3(256), 0, stream, r);  \
             else if (lpc == 16) hipLaunchKernelGGL((rescore_kernel<K_, 16>), dim3(rgrid), dim3(256), 0, stream, r); \
             else                hipLaunchKernelGGL((rescore_kernel<K_, 64>), dim3(rgrid), dim3(256), 0, stream, r); \
-            hipLaunchKernelGGL((rescan_kernel<K_>), dim3(kFMaxRescan), dim3(256), 0, stream, r, (int)red.n);   \
+            hipLaunchKernelGGL((rescan_kernel<K_>), dim3(kFMaxRescan * kFRescanSplit), dim3(256), 0, stream, r, (int)red.n);   \
         } while (0)
         if (ktop == 1) FM_LAUNCH_RESCORE(1); else FM_LAUNCH_RESCORE(2);
 #undef FM_LAUNCH_RESCORE

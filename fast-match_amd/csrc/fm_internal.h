@@ -74,7 +74,8 @@ hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, con
 // ---- K8: fp16 MFMA filter + exact rescoring for the float32 route (filter_f16.hip) --------
 // Writes the same keys as K5 into split 0 of `partial` (the caller presets the other splits to
 // ~0).  flag: device words [0] K5 must redo the call, [1] output rows rescanned in full,
-// [2] K5 runs, [3] rescans in total, [4 .. 4 + 256) the rescanned rows; [0] and [1] are reset per call.
+// [2] K5 runs, [3] rescans in total, [4 .. 4 + 256) the rescanned rows, then tickets + rescan scratch
+// (filter_flag_bytes() in all); [0] and [1] are reset per call.
 struct FilterPlan {
     int nw;            // waves per workgroup (4 or 8)
     int nc;            // blocks of 16 output rows per wave (2 or 4)
@@ -87,6 +88,7 @@ struct FilterPlan {
 };
 FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad);
 int filter_empty_bound();
+size_t filter_flag_bytes();       // size of the device words launch_filter's `flag` points at
 bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry filter planes of compatible scale
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
