@@ -1,127 +1,19 @@
-// The arithmetic of one expansion round (cross-checked 1-NN) as a
-// workgroup-wide device function shared by round_kernel (rounds.hip) and expand_kernel
-// (expand.hip).  256 threads; contains barriers: every thread of the block must call it.
+// The arithmetic of one expansion round on integer-valued banks (cross-checked 1-NN, SURVEY.md
+// Appendix A.3) as ONE workgroup-wide device function shared by round_kernel (rounds.hip) and
+// expand_kernel (expand.hip).  256 threads; contains barriers: every thread of the block must call it.
 #pragma once
 #include "tile_ops.h"
 
 namespace fm {
 
-// On return (after the caller's next __syncthreads) qbest[slot], slot in [0, nq), holds
-// (d2 << 32 | local train index) of the cross-checked match of query slot `slot`, or ~0.
-// q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
+// x1_round_wsplit: on return (after the caller's next __syncthreads) qbest[slot], slot in
+// [0, nq), holds (d2 << 32 | local train index) of the cross-checked match of query slot `slot`,
+// or ~0.  q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
 // qbest must be pre-filled with ~0 for slots [0, nq) (visible to all threads).
-// SR = query rows gathered per staging step (128, or 512 so that a typical round needs ONE
-// global round trip); smem must hold SR * 128 + SR / 32 * 256 bytes.
-template <int NB, int SR = kStageRows>
-__device__ __forceinline__ void x1_round(const int8_t* __restrict__ q_rows8, const int32_t* __restrict__ q_norm,
-                                         const int* q_rows, int nq,
-                                         const int8_t* __restrict__ t_rows8, const int32_t* __restrict__ t_norm,
-                                         int64_t t0, int nt, char* smem, unsigned long long* qbest)
-{
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int h    = lane >> 5;
-    const int sw = ((lane & 31) >> 1) & 7;
-    int aoff[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) aoff[c] = (lane & 31) * kDim + 16 * ((2 * c + h) ^ sw);
-    constexpr int kRowBytes = SR * kDim;
-    const int xoff = kRowBytes + h * 64;
-    const int nstages = (nq + SR - 1) / SR;
-
-    for (int cb0 = 0; cb0 < nt; cb0 += 128 * NB) {
-        const int cb = cb0 + wave * (32 * NB);
-        v4i bf[NB][4];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = cb + 32 * j + (lane & 31);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (n < nt) bf[j][c] = *(const v4i*)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
-                else        bf[j][c] = v4i{0, 0, 0, 0};
-            }
-        }
-        TopK<1> top[NB];
-        int thr[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; top[j].init(); }
-
-        for (int st = 0; st < nstages; ++st) {
-            __syncthreads();                       // previous stage fully consumed
-            // gather SR query rows (16 B per thread x SR/32) into the swizzled image; all loads
-            // of a step are independent, so they cost one global round trip
-#pragma unroll
-            for (int i = 0; i < SR / 32; ++i) {
-                const int g   = wave * (SR / 32) + i;
-                const int row = g * 8 + (lane >> 3);
-                const int slot = st * SR + row;
-                // unconditional (clamped) loads so that all of a step's loads are in flight
-                // together; slots past the subset are zeroed afterwards
-                const int qi = q_rows[slot < nq ? slot : (nq > 0 ? nq - 1 : 0)];
-                v4i v = *(const v4i*)(q_rows8 + (size_t)qi * kDim + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
-                if (slot >= nq) v = v4i{0, 0, 0, 0};
-                *(v4i*)(smem + g * 1024 + lane * 16) = v;
-            }
-            for (int rr = tid; rr < SR; rr += 256) {
-                const int slot = st * SR + rr;
-                const int tile = rr >> 5, mm = rr & 31;
-                const int hh = (mm >> 2) & 1, reg = (mm & 3) + 4 * (mm >> 3);
-                const int nm = q_norm[q_rows[slot < nq ? slot : (nq > 0 ? nq - 1 : 0)]];
-                int cinit = -(nm >> 1), low = ((1 - (nm & 1)) << 4) | (15 - reg);
-                if (slot >= nq) { cinit = kPadCinit; low = 15 - reg; }
-                int* aux = (int*)(smem + kRowBytes) + tile * kAuxPerTile;
-                aux[16 * hh + reg] = cinit;
-                aux[32 + 16 * hh + reg] = low;
-            }
-            __syncthreads();
-            const int ntiles = min(SR / kTileRows, (nq - st * SR + kTileRows - 1) / kTileRows);
-            for (int tt = 0; tt < ntiles; ++tt) {
-                v4i af[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(smem + tt * (kTileRows * kDim) + aoff[c]);
-                const v16i ci = lds_read16(smem + xoff + tt * (kAuxPerTile * 4));
-                v16i acc[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[j][0], ci, 0, 0, 0);
-#pragma unroll
-                for (int c = 1; c < 4; ++c)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[c], bf[j][c], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int tmax = max16(acc[j]);
-                    if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                        const v16i low = lds_read16(smem + xoff + tt * (kAuxPerTile * 4) + 128);
-                        top[j].update(acc[j], low, st * (SR / kTileRows) + tt);
-                        thr[j] = top[j].own_threshold();
-                    }
-                }
-            }
-        }
-        // cross-half merge, then scatter-min into the per-slot table
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int mh = top[j].hi(0);
-            int mi = (top[j].tile[0] >= 0) ? top[j].index(0, h) : -1;
-            if (mi >= nq) mi = -1;                  // padding slot
-            const int oh = __shfl_xor(mh, 32);
-            const int oi = __shfl_xor(mi, 32);
-            const bool mine = !better(oh, oi, mh, mi);
-            const int rh = mine ? mh : oh;
-            const int ri = mine ? mi : oi;
-            const int n = cb + 32 * j + (lane & 31);
-            if (h == 0 && n < nt && ri >= 0) {
-                const unsigned d2 = (unsigned)(t_norm[t0 + n] + 1 - rh);
-                atomicMin(&qbest[ri], ((unsigned long long)d2 << 32) | (unsigned)n);
-            }
-        }
-    }
-}
-
-
-// Variant for the latency-bound device loop (expand.hip): every wave owns ALL four 32-column
+// SR = query rows gathered per staging step (128 in round_kernel, 512 in expand_kernel so that a
+// typical round needs ONE global round trip); smem must hold SR * 128 + SR / 32 * 256 bytes.
+//
+// Every wave owns ALL four 32-column
 // blocks of a 128-column chunk (four independent MFMA chains per tile, so the dependent
 // accumulate latency is hidden) but only every fourth 32-row tile of the query subset; the
 // four waves' reverse-NN candidates meet in an LDS table tbest[128] through 64-bit

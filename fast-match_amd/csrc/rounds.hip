@@ -37,12 +37,12 @@ struct RoundParams {
     double*        ratio;         // may be null
 };
 
-template <int NB>
 __global__ __launch_bounds__(256)
 void round_kernel(RoundParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[kStageBytes];
     __shared__ unsigned long long qbest[kRoundQCap];
+    __shared__ unsigned long long tbest[128];
 
     const int tid  = threadIdx.x;
     const int b    = blockIdx.x;
@@ -53,7 +53,9 @@ void round_kernel(RoundParams p)
 
     for (int i = tid; i < nq; i += 256) qbest[i] = ~0ull;
 
-    x1_round<NB>(p.q_rows8, p.q_norm, p.q_rows + q0, nq, p.t_rows8, p.t_norm, t0, nt, smem, qbest);
+    __syncthreads();
+    if (nq > 0 && nt > 0)
+        x1_round_wsplit<kStageRows>(p.q_rows8, p.q_norm, p.q_rows + q0, nq, p.t_rows8, p.t_norm, t0, nt, smem, qbest, tbest);
     __syncthreads();
     for (int i = tid; i < nq; i += 256) {
         const unsigned long long key = qbest[i];
@@ -153,7 +155,7 @@ hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, 
     p.q_rows = d_q_rows; p.q_off = d_q_off;
     p.t_rows8 = t.rows8; p.t_norm = t.norm; p.t_off = d_t_off;
     p.tidx = d_tidx; p.dist = d_dist; p.ratio = d_ratio;
-    hipLaunchKernelGGL((round_kernel<1>), dim3((unsigned)n_rounds), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(round_kernel, dim3((unsigned)n_rounds), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
