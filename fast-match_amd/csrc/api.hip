@@ -1604,10 +1604,10 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     if (getenv("FM_EXPAND_PROF")) {
         long long pr[16];
         (void)hipMemcpy(pr, pairs[0]->dev.result, sizeof(pr), hipMemcpyDeviceToHost);
-        static const char* names[12] = {"pop+key", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "-",
+        static const char* names[12] = {"pop:barrier", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "pop:thread0",
                                         "x1:bfrag+barrier", "x1:gather", "x1:mfma", "x1:merge"};
         fprintf(stderr, "[fm_expand prof, pair 0, %lld rounds] ", pr[1]);
-        for (int k = 0; k < 12; ++k) if (k != 7) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
         fprintf(stderr, "\n");
     }
     rc = cs.finish();

@@ -22,6 +22,7 @@
 // is already matched when it is pushed, or equals the key of an earlier neighbour of the same
 // round, would be skipped when popped anyway, so it is not pushed.
 #include "round_body.h"
+#include <type_traits>
 #include "expand_pair.h"
 
 namespace fm {
@@ -51,7 +52,7 @@ __device__ __forceinline__ unsigned long long pack4x16(int a, int b, int c, int 
            ((unsigned long long)(unsigned short)c << 16) | (unsigned long long)(unsigned short)d;
 }
 
-__device__ __forceinline__ bool set_contains(const unsigned long long* tab, long long cap, unsigned long long key)
+__device__ __forceinline__ bool set_contains(gptr<const unsigned long long> tab, long long cap, unsigned long long key)
 {
     long long p = (long long)(mix64(key) & (unsigned long long)(cap - 1));
     for (long long n = 0; n < cap; ++n) {
@@ -64,7 +65,7 @@ __device__ __forceinline__ bool set_contains(const unsigned long long* tab, long
 }
 
 // Single-writer insert (thread 0 only).  Returns false when the table is full.
-__device__ __forceinline__ bool set_insert(unsigned long long* tab, long long cap, unsigned long long key)
+__device__ __forceinline__ bool set_insert(gptr<unsigned long long> tab, long long cap, unsigned long long key)
 {
     long long p = (long long)(mix64(key) & (unsigned long long)(cap - 1));
     for (long long n = 0; n < cap; ++n) {
@@ -76,7 +77,7 @@ __device__ __forceinline__ bool set_insert(unsigned long long* tab, long long ca
     return false;
 }
 
-__device__ __forceinline__ bool found_contains(const unsigned long long* tab, long long cap,
+__device__ __forceinline__ bool found_contains(gptr<const unsigned long long> tab, long long cap,
                                                unsigned long long k0, unsigned long long k1)
 {
     long long p = (long long)(mix64(k0 ^ mix64(k1)) & (unsigned long long)(cap - 1));
@@ -89,20 +90,56 @@ __device__ __forceinline__ bool found_contains(const unsigned long long* tab, lo
     return false;
 }
 
+// Both probes of an accepted match in one go: is the neighbour key `nk` in the seen set (and if
+// not, which empty slot ended its probe), and is (k0, k1) in the found set.  The first loads of
+// the two probes are issued together (two dependent memory round trips would otherwise follow
+// each other); collisions continue one probe at a time.
+__device__ __forceinline__ void probe_both(gptr<const unsigned long long> seen, long long seen_cap, unsigned long long nk,
+                                           gptr<const unsigned long long> found, long long found_cap,
+                                           unsigned long long k0, unsigned long long k1,
+                                           bool* in_seen, long long* seen_slot, bool* in_found)
+{
+    long long p1 = (long long)(mix64(nk) & (unsigned long long)(seen_cap - 1));
+    long long p2 = (long long)(mix64(k0 ^ mix64(k1)) & (unsigned long long)(found_cap - 1));
+    const bool want_seen = nk != ~0ull;
+    unsigned long long v1 = want_seen ? seen[p1] : ~0ull;
+    unsigned long long w0 = found[2 * p2], w1 = found[2 * p2 + 1];
+    bool hit = false;
+    if (want_seen) {
+        for (long long n = 0; n < seen_cap; ++n) {
+            if (v1 == nk) { hit = true; break; }
+            if (v1 == ~0ull) break;
+            p1 = (p1 + 1) & (seen_cap - 1);
+            v1 = seen[p1];
+        }
+    }
+    *in_seen = hit;
+    *seen_slot = p1;
+    bool fhit = false;
+    for (long long n = 0; n < found_cap; ++n) {
+        if (w0 == ~0ull) break;
+        if (w0 == k0 && w1 == k1) { fhit = true; break; }
+        p2 = (p2 + 1) & (found_cap - 1);
+        w0 = found[2 * p2]; w1 = found[2 * p2 + 1];
+    }
+    *in_found = fhit;
+}
+
 // Concurrent insert of keys known to be absent and mutually distinct (claim an empty slot).
-__device__ __forceinline__ bool found_insert(unsigned long long* tab, long long cap,
+__device__ __forceinline__ bool found_insert(gptr<unsigned long long> tab, long long cap,
                                              unsigned long long k0, unsigned long long k1)
 {
     long long p = (long long)(mix64(k0 ^ mix64(k1)) & (unsigned long long)(cap - 1));
     for (long long n = 0; n < cap; ++n) {
-        if (atomicCAS(&tab[2 * p], ~0ull, k0) == ~0ull) { tab[2 * p + 1] = k1; return true; }
+        unsigned long long expect = ~0ull;
+        if (__hip_atomic_compare_exchange_strong(&tab[2 * p], &expect, k0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { tab[2 * p + 1] = k1; return true; }
         p = (p + 1) & (cap - 1);
     }
     return false;
 }
 
 // Single-writer insert-if-absent in one probe sequence: 1 = inserted, 0 = was present, -1 = full.
-__device__ __forceinline__ int set_insert_new(unsigned long long* tab, long long cap, unsigned long long key)
+__device__ __forceinline__ int set_insert_new(gptr<unsigned long long> tab, long long cap, unsigned long long key)
 {
     long long p = (long long)(mix64(key) & (unsigned long long)(cap - 1));
     for (long long n = 0; n < cap; ++n) {
@@ -139,7 +176,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     int* start = hist;                       // [kSortBuckets + 1] after the scan
     int* cursor = hist + kSortBuckets + 4;   // [kSortBuckets]
     for (int b = tid; b < kSortBuckets; b += 256) { start[b] = 0; cursor[b] = 0; }
-    __syncthreads();
+    lds_barrier();
     const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
     int myb[kExpCand / 256];
 #pragma unroll
@@ -154,7 +191,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
             atomicAdd(&start[b], 1);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // exclusive scan of the bucket counts: 4 buckets per thread
     {
         int c[4], s = 0;
@@ -166,7 +203,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
         for (int q = 0; q < 4; ++q) { start[tid * 4 + q] = off; off += c[q]; }
         if (tid == 255) start[kSortBuckets] = off;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int s = 0; s < kExpCand / 256; ++s) {
         const int i = s * 256 + tid;
@@ -176,7 +213,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
             i2[p] = idx[i] | 0;          // (bucket order; order inside a bucket is arbitrary here)
         }
     }
-    __syncthreads();
+    lds_barrier();
     // final position = bucket start + number of smaller pairs inside the bucket
 #pragma unroll
     for (int s = 0; s < kExpCand / 256; ++s) {
@@ -197,7 +234,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
             idx[rank] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // Exclusive scan of per-thread counts over the 256-thread block; returns the total.
@@ -215,13 +252,34 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* 
         const int o = __shfl_up(inc, d);
         if (lane >= d) inc += o;
     }
-    __syncthreads();
+    lds_barrier();
     if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { if (w < wave) base += wave_tot[w]; tot += wave_tot[w]; }
     *my_offset = base + inc - v;
+    return tot;
+}
+
+// Exclusive ranks of up to two boolean flags per thread over the 256-thread block, and their
+// totals (a in the low half-word, b in the high one).  Ballots + population counts instead of a
+// shuffle scan, and ONE barrier: consecutive calls alternate between two LDS buffers, so the
+// barrier of call k also separates the reads of call k - 1 from the writes of call k + 1.
+__device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int* rank_b, int (*wave_cnt)[4], int& toggle)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long ma = __builtin_amdgcn_ballot_w64(a), mb = __builtin_amdgcn_ballot_w64(b);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int* buf = wave_cnt[toggle];
+    toggle ^= 1;
+    if (lane == 0) buf[wave] = __popcll(ma) | (__popcll(mb) << 16);
+    lds_barrier();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = buf[w]; if (w < wave) base += c; tot += c; }
+    *rank_a = (base & 0xffff) + __popcll(ma & below);
+    *rank_b = (base >> 16) + __popcll(mb & below);
     return tot;
 }
 
@@ -242,9 +300,53 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     __shared__ int sh_i[8];
     __shared__ long long sh_top;
     __shared__ int wave_tot[4];
+    __shared__ int wave_cnt[2][4];
+    int rank_toggle = 0;                              // (uniform)
     __shared__ int sh_rf[4];                          // per-wave candidate counts of the float32 round
+    // The entry a round pushes on TOP of the stack is, nine times out of ten, the next one popped.
+    // The pushing thread leaves a copy here together with its key and the empty slot that ended the
+    // key's seen-set probe, so the pop needs neither the stack read nor a probe of its own.
+    __shared__ long long sh_seed;
+    __shared__ unsigned long long sh_key;
+    __shared__ int sh_first[4];
+    __shared__ double nxt_e[4];
+    __shared__ unsigned long long nxt_key;
+    __shared__ long long nxt_slot;
+    __shared__ int nxt_valid;
+    if (threadIdx.x == 0) nxt_valid = 0;
 
-    const ExpandPair& P = pairs[blockIdx.x];
+    // The pair descriptor is read from memory, so its pointers reach the compiler as GENERIC ones and
+    // every access through them would be a FLAT instruction (see gptr in tile_ops.h).  P is a view of
+    // the descriptor whose pointers are typed as global memory.
+    const ExpandPair& M = pairs[blockIdx.x];
+    struct View {
+        gptr<const int8_t> q_rows8; gptr<const int32_t> q_norm; gptr<const double> q_selfdist, q_pos;
+        gptr<const int32_t> idx_order, idx_start;
+        double idx_bucket, idx_x0, idx_y0; int idx_nbx, idx_nby;
+        gptr<const int8_t> t_rows8; gptr<const int32_t> t_norm; gptr<const int64_t> cell_off; gptr<const double> t_pos;
+        int width, height, cell_w, cell_h, rows, cols, margin, radius, f32;
+        gptr<const double> seeds; int64_t n_seeds; double tau;
+        gptr<double> stack; int64_t stack_cap;
+        gptr<unsigned long long> seen; int64_t seen_cap;
+        gptr<unsigned long long> found; int64_t found_cap;
+        gptr<int32_t> m_index; gptr<double> m_pos, m_ratio; int64_t match_cap;
+        gptr<long long> result; int prof;
+    } P;
+    P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
+    P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos;
+    P.idx_order = (gptr<const int32_t>)M.idx_order; P.idx_start = (gptr<const int32_t>)M.idx_start;
+    P.idx_bucket = M.idx_bucket; P.idx_x0 = M.idx_x0; P.idx_y0 = M.idx_y0; P.idx_nbx = M.idx_nbx; P.idx_nby = M.idx_nby;
+    P.t_rows8 = (gptr<const int8_t>)M.t_rows8; P.t_norm = (gptr<const int32_t>)M.t_norm;
+    P.cell_off = (gptr<const int64_t>)M.cell_off; P.t_pos = (gptr<const double>)M.t_pos;
+    P.width = M.width; P.height = M.height; P.cell_w = M.cell_w; P.cell_h = M.cell_h;
+    P.rows = M.rows; P.cols = M.cols; P.margin = M.margin; P.radius = M.radius; P.f32 = M.f32;
+    P.seeds = (gptr<const double>)M.seeds; P.n_seeds = M.n_seeds; P.tau = M.tau;
+    P.stack = (gptr<double>)M.stack; P.stack_cap = M.stack_cap;
+    P.seen = (gptr<unsigned long long>)M.seen; P.seen_cap = M.seen_cap;
+    P.found = (gptr<unsigned long long>)M.found; P.found_cap = M.found_cap;
+    P.m_index = (gptr<int32_t>)M.m_index; P.m_pos = (gptr<double>)M.m_pos; P.m_ratio = (gptr<double>)M.m_ratio;
+    P.match_cap = M.match_cap; P.result = (gptr<long long>)M.result; P.prof = M.prof;
+    const RoundF32G RF(M.rf);
     const int tid = threadIdx.x;
 
     long long top = 0;            // stack height: owned by thread 0, published in sh_top each round
@@ -260,40 +362,79 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
         if (tid == 0) {
             int have = 0;
-            while (status == kExpOk) {
-                double e[4];
-                if (top > 0) {
-                    --top;
-                    for (int k = 0; k < 4; ++k) e[k] = P.stack[top * 4 + k];
-                } else if (seed_i < P.n_seeds) {
-                    for (int k = 0; k < 4; ++k) e[k] = P.seeds[seed_i * 4 + k];
-                    ++seed_i;
-                } else {
-                    break;
-                }
-                const int col = blk(e[3], P.cell_h), row = blk(e[2], P.cell_w);
-                const int qcol = blk(e[1], P.cell_h), qrow = blk(e[0], P.cell_w);
-                const unsigned long long key = pack4x16(col, row, qcol, qrow);
-                if (2 * (seen_n + 1) > P.seen_cap) {                 // (only a NEW key needs room)
-                    if (set_contains(P.seen, P.seen_cap, key)) continue;
-                    status = kExpTableFull;
-                    break;
-                }
-                const int ins = set_insert_new(P.seen, P.seen_cap, key);
-                if (ins == 0) continue;
-                if (ins < 0) { status = kExpTableFull; break; }
+            if (nxt_valid && top > 0 && 2 * (seen_n + 1) <= P.seen_cap) {
+                // the entry on top is the one the previous round pushed last: it is cached, its key is
+                // known to be new (checked when it was pushed; nothing was inserted since) and the slot
+                // that ended that probe is still empty
+                --top;
+                P.seen[nxt_slot] = nxt_key;
                 ++seen_n;
-                for (int k = 0; k < 4; ++k) cur[k] = e[k];
-                sh_i[1] = col; sh_i[2] = row;
+                for (int k = 0; k < 4; ++k) cur[k] = nxt_e[k];
+                sh_i[1] = blk(nxt_e[3], P.cell_h); sh_i[2] = blk(nxt_e[2], P.cell_w);
                 have = 1;
-                break;
             }
+            nxt_valid = 0;
             sh_i[0] = have;
             sh_i[3] = status;
             sh_i[7] = 0;
             sh_top = top;
+            sh_seed = seed_i;
+            EXP_STAMP(7);
         }
-        __syncthreads();
+        lds_barrier();
+        // Not the cached entry: entries whose key was matched since they were pushed are skipped
+        // (fastmatch.pyx:71-72) -- on average four stale entries per round, each a dependent
+        // stack read + hash probe if one thread pops them one by one.  Instead 256 threads look at
+        // the next 256 entries of the source (stack from the top, then the seed list in order) at
+        // once; the first one with an unseen key is the round's entry, everything before it is
+        // stale and dropped, everything after it stays where it is.
+        while (!sh_i[0] && sh_i[3] == kExpOk) {
+            const long long t = sh_top, si = sh_seed;
+            const bool from_stack = t > 0;
+            const long long avail = from_stack ? t : (P.n_seeds - si);
+            if (avail <= 0) break;
+            const int w = (int)(avail < 256 ? avail : 256);
+            bool unseen = false;
+            double e[4] = {0, 0, 0, 0};
+            unsigned long long key = 0;
+            int ecol = 0, erow = 0;
+            if (tid < w) {
+                const long long src = from_stack ? (t - 1 - tid) : (si + tid);
+                gptr<const double> ep = from_stack ? (gptr<const double>)(P.stack + src * 4) : (P.seeds + src * 4);
+                for (int k = 0; k < 4; ++k) e[k] = ep[k];
+                ecol = blk(e[3], P.cell_h); erow = blk(e[2], P.cell_w);
+                key = pack4x16(ecol, erow, blk(e[1], P.cell_h), blk(e[0], P.cell_w));
+                unseen = !set_contains((gptr<const unsigned long long>)P.seen, P.seen_cap, key);
+            }
+            const unsigned long long um = __builtin_amdgcn_ballot_w64(unseen);
+            if ((tid & 63) == 0) sh_first[tid >> 6] = um ? (tid + (int)__builtin_ctzll(um)) : 1 << 20;
+            lds_barrier();
+            const int first = min(min(sh_first[0], sh_first[1]), min(sh_first[2], sh_first[3]));
+            if (first < w && tid == first) {
+                for (int k = 0; k < 4; ++k) cur[k] = e[k];
+                sh_i[1] = ecol; sh_i[2] = erow;
+                sh_key = key;
+            }
+            lds_barrier();
+            if (tid == 0) {
+                if (first < w) {
+                    if (from_stack) top = t - first - 1; else seed_i = si + first + 1;
+                    if (2 * (seen_n + 1) > P.seen_cap) status = kExpTableFull;            // a NEW key needs room
+                    else {
+                        const int ins = set_insert_new(P.seen, P.seen_cap, sh_key);
+                        if (ins < 0) status = kExpTableFull;
+                        else { ++seen_n; sh_i[0] = 1; }
+                    }
+                } else {
+                    if (from_stack) top = t - w; else seed_i = si + w;
+                }
+                sh_i[3] = status;
+                sh_top = top;
+                sh_seed = seed_i;
+            }
+            lds_barrier();
+        }
+        lds_barrier();
         status = sh_i[3];
         if (!sh_i[0] || status != kExpOk) break;
         const int col = sh_i[1], row = sh_i[2];
@@ -308,7 +449,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
         if (tid == 0) sh_i[4] = 0;
-        __syncthreads();
+        lds_barrier();
         {
             const double r = (double)P.radius, b = P.idx_bucket;
             int bx0 = (int)floor(((double)qx - r - P.idx_x0) / b), bx1 = (int)floor(((double)qx + r - P.idx_x0) / b);
@@ -317,10 +458,28 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             bx1 = min(bx1, P.idx_nbx - 1); by1 = min(by1, P.idx_nby - 1);
             const double r2 = r * r;
             if (P.idx_nbx > 0 && bx1 >= bx0) {
-                for (int by = by0; by <= by1; ++by) {
-                    const int s = P.idx_start[by * P.idx_nbx + bx0], e = P.idx_start[by * P.idx_nbx + bx1 + 1];
-                    for (int i = s + tid; i < e; i += 256) {
-                        const int qi = P.idx_order[i];
+                // The bucket rows' index ranges are fetched first (independent loads), then ONE flat
+                // loop walks their concatenation: three dependent memory round trips in all (ranges,
+                // keypoint index, position) instead of three per bucket row.  8 rows at a time.
+                for (int byb = by0; byb <= by1; byb += 8) {
+                    int rs[8], pre[9];
+                    pre[0] = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int by = byb + j;
+                        int s0 = 0, e0 = 0;
+                        if (by <= by1) { s0 = P.idx_start[by * P.idx_nbx + bx0]; e0 = P.idx_start[by * P.idx_nbx + bx1 + 1]; }
+                        rs[j] = s0;
+                        pre[j + 1] = pre[j] + (e0 - s0);
+                    }
+                    for (int f = tid; f < pre[8]; f += 256) {
+                        int j = 0;
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) j += (f >= pre[q]) ? 1 : 0;
+                        int base = rs[0], off = pre[0];
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) { base = (j == q) ? rs[q] : base; off = (j == q) ? pre[q] : off; }
+                        const int qi = P.idx_order[base + f - off];
                         const double dx = P.q_pos[2 * qi] - (double)qx, dy = P.q_pos[2 * qi + 1] - (double)qy;
                         const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));   // no fma: NumPy order
                         if (d2 <= r2) {
@@ -331,7 +490,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         const int nq = sh_i[4];
         if (nq > kExpCand) { status = kExpCandFull; break; }
         EXP_STAMP(1);
@@ -348,8 +507,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         for (int i = tid; i < nq; i += 256) keys[i] = ~0ull;     // keys[] becomes the qbest table
         if (P.f32) {
             // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
-            __syncthreads();
-            const bool ok = x1_round_f32(P.rf, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
+            lds_barrier();
+            const bool ok = x1_round_f32(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
                                          (unsigned long long*)(hist + 2 * kSortBuckets + 16), sh_rf,
                                          P.prof ? pt : nullptr, &tstamp);
             if (!ok) { status = kExpListFull; break; }
@@ -357,7 +516,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             x1_round_wsplit<kExpSR>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
                                     (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
         }
-        __syncthreads();
+        lds_barrier();
 
         EXP_STAMP(3);
         // ---- 4./5. accepted matches: neighbours and new results, in slot order ------------------
@@ -380,14 +539,14 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     t_local = (int)(unsigned)qb;
                 }
             }
-            int o;
-            const int cnt = block_exclusive_scan(acc ? 1 : 0, &o, wave_tot);
-            // keys[] (qbest) of slots < s0 + 256 are consumed: entries na+o <= i never clobber unread ones
-            __syncthreads();
+            int o, o_unused;
+            const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
+            // keys[] (qbest) of slots < s0 + 256 are consumed (the barrier inside the ranking separates
+            // those reads from these writes): entries na+o <= i never clobber unread ones
             if (acc) { tix[na + o] = i | (t_local << 11); nkey[na + o] = (unsigned long long)__double_as_longlong(ratio); }
             na += cnt;
         }
-        __syncthreads();
+        lds_barrier();
         EXP_STAMP(4);
         // (b) per accepted match: neighbour key + seen probe, result key + found probe.
         //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
@@ -400,6 +559,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
             int qrow_idx = 0;
             bool known = false;
+            long long nslot = 0;
             if (live) {
                 const int slot = tix[k] & 2047, t_local = tix[k] >> 11;
                 qrow_idx = cand[slot];
@@ -420,12 +580,13 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 k1 = pack4x16((int)mqx, (int)mqy, (int)px, (int)py);
                 // two independent probes: would the neighbour be skipped when popped? is the
                 // result already in the list?
-                if (nk != ~0ull && set_contains(P.seen, P.seen_cap, nk)) nk = ~0ull;
-                known = found_contains(P.found, P.found_cap, rbits, k1);
+                bool in_seen;
+                probe_both(P.seen, P.seen_cap, nk, P.found, P.found_cap, rbits, k1, &in_seen, &nslot, &known);
+                if (in_seen) nk = ~0ull;
                 keys[k] = nk;
                 rk[k] = k1;
             }
-            __syncthreads();
+            lds_barrier();
             // earlier entries of this round with the same key win (lists are in slot order)
             bool push = live && nk != ~0ull, emit = live && !known;
             if (live) {
@@ -436,15 +597,15 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
             // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
             // chunks of 256 accepted matches are pushed in reverse chunk order below
-            int po;
-            const int ptot = block_exclusive_scan(push ? 1 : 0, &po, wave_tot);
-            int eo;
-            const int etot = block_exclusive_scan(emit ? 1 : 0, &eo, wave_tot);
+            // one scan for both ranks: pushes in the low half-word, emits in the high one (<= 256 each)
+            int po, eo;
+            const int petot = block_rank_flags(push, emit, &po, &eo, wave_cnt, rank_toggle);
+            const int ptot = petot & 0xffff, etot = petot >> 16;
             if (tid == 0) {
                 sh_i[5] = (sh_top + ptot > P.stack_cap) ? 1 : 0;
                 sh_i[6] = (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) ? 1 : 0;
             }
-            __syncthreads();
+            lds_barrier();
             if (sh_i[5]) { status = kExpStackFull; break; }
             if (sh_i[6]) { status = kExpMatchFull; break; }
             if (push) {
@@ -454,6 +615,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const long long dst = (na <= 256) ? sh_top + (ptot - 1 - po) : sh_top + po;
                 P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
                 P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
+                if (na <= 256 && po == 0) {            // this entry ends up on top: cache it for the next pop
+                    nxt_e[0] = mqx; nxt_e[1] = mqy; nxt_e[2] = nx; nxt_e[3] = ny;
+                    nxt_key = nk; nxt_slot = nslot; nxt_valid = 1;
+                }
             }
             if (emit) {
                 const long long dst = n_matches + n_emit + eo;
@@ -464,14 +629,15 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
             }
             n_emit += etot;
-            __syncthreads();
+            lds_barrier();
             if (tid == 0) { sh_top += ptot; top += ptot; }
-            __syncthreads();
+            lds_barrier();
         }
         if (status != kExpOk) break;
         // More than one chunk: the pushed region [top_before, top) is in ascending slot order;
         // reverse it in place.
         if (na > 256) {
+            __syncthreads();       // entries pushed by other threads are read from global memory below
             const long long lo = sh_i_top_before, hi = sh_top;
             const long long cntp = hi - lo;
             for (long long x = tid; x < cntp / 2; x += 256) {

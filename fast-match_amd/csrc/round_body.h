@@ -9,7 +9,8 @@ namespace fm {
 // x1_round_wsplit: on return (after the caller's next __syncthreads) qbest[slot], slot in
 // [0, nq), holds (d2 << 32 | local train index) of the cross-checked match of query slot `slot`,
 // or ~0.  q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
-// qbest must be pre-filled with ~0 for slots [0, nq) (visible to all threads).
+// qbest must be pre-filled with ~0 for slots [0, nq) (visible to all threads).  The bank pointers are
+// global-memory pointers (gptr, tile_ops.h): callers convert theirs once.
 // SR = query rows gathered per staging step (128 in round_kernel, 512 in expand_kernel so that a
 // typical round needs ONE global round trip); smem must hold SR * 128 + SR / 32 * 256 bytes.
 //
@@ -20,9 +21,9 @@ namespace fm {
 // atomicMin on (d2 << 32 | slot) -- min d2, then lowest slot, exactly the order
 // cv::batchDistance keeps -- before the scatter-min into qbest.
 template <int SR>
-__device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_rows8, const int32_t* __restrict__ q_norm,
+__device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr<const int32_t> q_norm,
                                                 const int* q_rows, int nq,
-                                                const int8_t* __restrict__ t_rows8, const int32_t* __restrict__ t_norm,
+                                                gptr<const int8_t> t_rows8, gptr<const int32_t> t_norm,
                                                 int64_t t0, int nt, char* smem, unsigned long long* qbest,
                                                 unsigned long long* tbest /* LDS [128] */,
                                                 long long* pt = nullptr, long long* ts = nullptr)
@@ -49,7 +50,7 @@ __device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_row
             const int n = cb0 + 32 * j + (lane & 31);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (n < nt) bf[j][c] = *(const v4i*)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
+                if (n < nt) bf[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
                 else        bf[j][c] = v4i{0, 0, 0, 0};
             }
         }
@@ -59,7 +60,7 @@ __device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_row
         for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; top[j].init(); }
 
         for (int st = 0; st < nstages; ++st) {
-            __syncthreads();                       // previous stage fully consumed
+            lds_barrier();                       // previous stage fully consumed
             X1_STAMP(8);
             // issue every global load of the step first (row norms, then the 16-byte row
             // pieces; unconditional, clamped past the subset), then do the LDS writes
@@ -69,19 +70,19 @@ __device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_row
                 const int slot = st * SR + k * 256 + tid;
                 nmv[k] = q_norm[q_rows[slot < nq ? slot : nq - 1]];
             }
-            v4i rv[SR / 32];
-#pragma unroll
-            for (int i = 0; i < SR / 32; ++i) {
-                const int row = (wave * (SR / 32) + i) * 8 + (lane >> 3);
-                const int slot = st * SR + row;
-                const int qi = q_rows[slot < nq ? slot : nq - 1];
-                rv[i] = *(const v4i*)(q_rows8 + (size_t)qi * kDim + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
-            }
+            // the rows themselves go global -> LDS by DMA (no registers, all SR/32 pieces of a wave in
+            // flight together): a piece is 8 rows x 128 B, lane (row = lane >> 3, p = lane & 7) fetches
+            // source chunk p ^ ((row >> 1) & 7), which lands at chunk position p.  Slots past the subset
+            // fetch the last real row; their accumulator init (kPadCinit) keeps them below every real one.
 #pragma unroll
             for (int i = 0; i < SR / 32; ++i) {
                 const int g = wave * (SR / 32) + i;
-                const int slot = st * SR + g * 8 + (lane >> 3);
-                *(v4i*)(smem + g * 1024 + lane * 16) = slot < nq ? rv[i] : v4i{0, 0, 0, 0};
+                const int row = g * 8 + (lane >> 3);
+                const int slot = st * SR + row;
+                const int qi = q_rows[slot < nq ? slot : nq - 1];
+                gptr<const int8_t> src = q_rows8 + (size_t)qi * kDim + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+                __builtin_amdgcn_global_load_lds((gptr<const void>)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + g * 1024), 16, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < (SR + 255) / 256; ++k) {
@@ -97,7 +98,8 @@ __device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_row
                     aux[32 + 16 * hh + reg] = low;
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
             X1_STAMP(9);
             const int ntiles = min(SR / kTileRows, (nq - st * SR + kTileRows - 1) / kTileRows);
             for (int tt = wave; tt < ntiles; tt += 4) {           // this wave's tiles, ascending
@@ -142,13 +144,13 @@ __device__ __forceinline__ void x1_round_wsplit(const int8_t* __restrict__ q_row
                 atomicMin(&tbest[32 * j + (lane & 31)], ((unsigned long long)d2 << 32) | (unsigned)ri);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 128 && cb0 + tid < nt) {
             const unsigned long long tb = tbest[tid];
             if (tb != ~0ull)
                 atomicMin(&qbest[(unsigned)tb], (tb & 0xffffffff00000000ull) | (unsigned)(cb0 + tid));
         }
-        __syncthreads();
+        lds_barrier();
         X1_STAMP(11);
     }
 #undef X1_STAMP

@@ -33,7 +33,7 @@ constexpr int kRF_RowBytes  = 256;                       // fp16 row
 constexpr int kRF_StageBytes = kRF_SR * kRF_RowBytes + kRF_SR * 4;   // rows + accumulator inits
 constexpr int kRF_NC        = 2;                         // 16-column blocks per wave
 
-struct RoundF32 {
+struct RoundF32 {             // as the host fills it (generic pointers)
     const char*  q_rowsh;     // query bank: fp16 plane (scaled by 2^kq), 256 B per row
     const float* q_auxf;      //             -|row|^2/2 of the scaled row
     const float* q_rowsf;     //             float32 rows [n_pad][128] (exact chain)
@@ -41,6 +41,18 @@ struct RoundF32 {
     const float* t_normf;     //             |row|^2 of the scaled row
     const float* t_rowsf;
     float eps_c, eps_nm, aux_mul;   // K8's margin terms and accumulator-init factor (launch_filter)
+};
+
+struct RoundF32G {            // the same with global-memory pointers (gptr, tile_ops.h), for the kernels
+    gptr<const char>  q_rowsh;
+    gptr<const float> q_auxf, q_rowsf;
+    gptr<const char>  t_rowsh;
+    gptr<const float> t_normf, t_rowsf;
+    float eps_c, eps_nm, aux_mul;
+    __device__ __forceinline__ explicit RoundF32G(const RoundF32& r)
+        : q_rowsh((gptr<const char>)r.q_rowsh), q_auxf((gptr<const float>)r.q_auxf), q_rowsf((gptr<const float>)r.q_rowsf),
+          t_rowsh((gptr<const char>)r.t_rowsh), t_normf((gptr<const float>)r.t_normf), t_rowsf((gptr<const float>)r.t_rowsf),
+          eps_c(r.eps_c), eps_nm(r.eps_nm), aux_mul(r.aux_mul) {}
 };
 
 __device__ __forceinline__ float rf_max3(float a, float b, float c)
@@ -53,7 +65,7 @@ __device__ __forceinline__ float rf_max3(float a, float b, float c)
 // clist: LDS scratch for clist_cap candidates (u32 each: slot | column << 12); tbest: LDS u64[128];
 // sh: LDS int[4].
 // Returns false (uniformly) if the candidate list overflowed: the round's result is then invalid.
-__device__ __forceinline__ bool x1_round_f32(const RoundF32& R, const int* q_rows, int nq, int64_t t0, int nt,
+__device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_rows, int nq, int64_t t0, int nt,
                                              char* smem, unsigned long long* qbest, unsigned* clist, int clist_cap,
                                              unsigned long long* tbest, int* sh,
                                              long long* pt = nullptr, long long* ts = nullptr)
@@ -77,22 +89,22 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32& R, const int* q_row
     // position p.  Slots past the subset fetch the last real row; their accumulator init
     // (-3.4e38) keeps them below every bound.
     auto gather = [&](int st) {
-        __syncthreads();                                  // previous image fully consumed
+        lds_barrier();                                  // previous image fully consumed
 #pragma unroll
         for (int i = 0; i < kRF_SR / 16; ++i) {
             const int piece = wave * (kRF_SR / 16) + i;   // 64 pieces of 4 rows per stage, 16 per wave
             const int row = piece * 4 + (lane >> 4);
             const int slot = st * kRF_SR + row;
             const int qi = q_rows[slot < nq ? slot : nq - 1];
-            const char* src = R.q_rowsh + (size_t)qi * kRF_RowBytes + 16 * ((lane & 15) ^ (row & 15));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            gptr<const char> src = R.q_rowsh + (size_t)qi * kRF_RowBytes + 16 * ((lane & 15) ^ (row & 15));
+            __builtin_amdgcn_global_load_lds((gptr<const void>)src,
                                              (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
         }
         const int aslot = st * kRF_SR + tid;
         const float aux = aslot < nq ? R.q_auxf[q_rows[aslot]] * R.aux_mul : -3.4e38f;
         ((float*)(smem + kRF_SR * kRF_RowBytes))[tid] = aux;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
     };
 
     int loaded = -1;                                      // stage whose image is in LDS (uniform)
@@ -112,7 +124,7 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32& R, const int* q_row
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 v4i h = v4i{0, 0, 0, 0};
-                if (in) h = *(const v4i*)(R.t_rowsh + (size_t)(t0 + n) * kRF_RowBytes + (4 * s + g) * 16);
+                if (in) h = *(gptr<const v4i>)(R.t_rowsh + (size_t)(t0 + n) * kRF_RowBytes + (4 * s + g) * 16);
                 bh[j][s] = __builtin_bit_cast(r_v8h, h);
             }
         }
@@ -242,7 +254,7 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32& R, const int* q_row
         }
         RF_STAMP(10);
         if (lane == 0) sh[wave] = wcount;
-        __syncthreads();
+        lds_barrier();
         int c0 = sh[0], c1 = sh[1], c2 = sh[2], c3 = sh[3];
         if (c0 > wcap || c1 > wcap || c2 > wcap || c3 > wcap) ok = false;
         c0 = min(c0, wcap); c1 = min(c1, wcap); c2 = min(c2, wcap); c3 = min(c3, wcap);
@@ -253,29 +265,29 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32& R, const int* q_row
             const int o = i - (w > 0 ? c0 : 0) - (w > 1 ? c1 : 0) - (w > 2 ? c2 : 0);
             const unsigned e = clist[w * wcap + o];
             const int slot = (int)(e & 4095u), tl = (int)(e >> 12);
-            const float4* cp = (const float4*)(R.t_rowsf + (size_t)(t0 + cb0 + tl) * kDim);
-            const float4* rp = (const float4*)(R.q_rowsf + (size_t)q_rows[slot] * kDim);
+            gptr<const r_v4f> cp = (gptr<const r_v4f>)(R.t_rowsf + (size_t)(t0 + cb0 + tl) * kDim);
+            gptr<const r_v4f> rp = (gptr<const r_v4f>)(R.q_rowsf + (size_t)q_rows[slot] * kDim);
             float sum = 0.f;
 #pragma unroll 16
             for (int k4 = 0; k4 < kDim / 4; ++k4) {
-                const float4 a = cp[k4];
-                const float4 b = rp[k4];
+                const r_v4f a = cp[k4];
+                const r_v4f b = rp[k4];
                 float v;
-                v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
-                v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
-                v = a.z - b.z; sum = __builtin_fmaf(v, v, sum);
-                v = a.w - b.w; sum = __builtin_fmaf(v, v, sum);
+                v = a[0] - b[0]; sum = __builtin_fmaf(v, v, sum);
+                v = a[1] - b[1]; sum = __builtin_fmaf(v, v, sum);
+                v = a[2] - b[2]; sum = __builtin_fmaf(v, v, sum);
+                v = a[3] - b[3]; sum = __builtin_fmaf(v, v, sum);
             }
             atomicMin(&tbest[tl], ((unsigned long long)__float_as_uint(sqrtf(sum)) << 32) | (unsigned)slot);
         }
-        __syncthreads();
+        lds_barrier();
         RF_STAMP(11);
         if (tid < 128 && cb0 + tid < nt) {
             const unsigned long long tb = tbest[tid];
             if (tb != ~0ull)
                 atomicMin(&qbest[(unsigned)tb], (tb & 0xffffffff00000000ull) | (unsigned)(cb0 + tid));
         }
-        __syncthreads();
+        lds_barrier();
     }
 #undef RF_STAMP
     return ok;

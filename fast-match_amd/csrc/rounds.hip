@@ -55,7 +55,8 @@ void round_kernel(RoundParams p)
 
     __syncthreads();
     if (nq > 0 && nt > 0)
-        x1_round_wsplit<kStageRows>(p.q_rows8, p.q_norm, p.q_rows + q0, nq, p.t_rows8, p.t_norm, t0, nt, smem, qbest, tbest);
+        x1_round_wsplit<kStageRows>((gptr<const int8_t>)p.q_rows8, (gptr<const int32_t>)p.q_norm, p.q_rows + q0, nq,
+                                    (gptr<const int8_t>)p.t_rows8, (gptr<const int32_t>)p.t_norm, t0, nt, smem, qbest, tbest);
     __syncthreads();
     for (int i = tid; i < nq; i += 256) {
         const unsigned long long key = qbest[i];
@@ -110,7 +111,7 @@ void round_f32_kernel(RoundF32Params p)
     for (int i = tid; i < nq; i += 256) qbest[i] = ~0ull;
     __syncthreads();
     bool ok = true;
-    if (nq > 0 && nt > 0) ok = x1_round_f32(p.rf, p.q_rows + q0, nq, t0, nt, smem, qbest, clist, kRoundF32Clist, tbest, sh);
+    if (nq > 0 && nt > 0) ok = x1_round_f32(RoundF32G(p.rf), p.q_rows + q0, nq, t0, nt, smem, qbest, clist, kRoundF32Clist, tbest, sh);
     __syncthreads();
     for (int i = tid; i < nq; i += 256) {
         const unsigned long long key = qbest[i];

@@ -7,7 +7,26 @@
 namespace fm {
 
 typedef int v4i  __attribute__((ext_vector_type(4)));
+
+// Pointer into GLOBAL memory (address space 1).  A pointer that a kernel reads from memory (not
+// from its argument list) is a generic one to the compiler, and every access through it becomes a
+// FLAT instruction, which counts on the LDS counter as well as on the vector-memory counter: each
+// LDS wait then also waits for all outstanding global traffic.  The one-workgroup kernels
+// (expand.hip) convert such pointers once; the device functions they share with kernels whose
+// pointers come from the argument list are templates over the pointer type.
+template <class T> using gptr = __attribute__((address_space(1))) T*;
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding GLOBAL load and store of the wave (s_waitcnt vmcnt(0)); in the latency-bound
+// one-workgroup kernel (K7) that drain would sit on the critical path of each of the ~30 steps of
+// a round.  Use where the threads exchange data through LDS only: global data written by one
+// thread and read by another needs a real __syncthreads() in between.  (Only meaningful when the
+// global accesses are global_* instructions, see gptr above: FLAT ones count on lgkmcnt too.)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 constexpr int kStageRowBytes = kStageRows * kDim;                           // 16384
 constexpr int kStageAuxBytes = (kStageRows / kTileRows) * kAuxPerTile * 4;  // 1024

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k(RoundF32 R, const int* q_rows_g, int nq
     for (int r = 0; r < reps; ++r) {
         for (int i = threadIdx.x; i < nq; i += 256) qbest[i] = ~0ull;
         __syncthreads();
-        x1_round_f32(R, q_rows, nq, 0, nt, smem, qbest, clist, 8192, tbest, sh, pt, &ts);
+        x1_round_f32(RoundF32G(R), q_rows, nq, 0, nt, smem, qbest, clist, 8192, tbest, sh, pt, &ts);
         __syncthreads();
     }
     if (threadIdx.x == 0) { for (int i = 0; i < 12; ++i) out[i] = pt[i]; out[12] = wall_clock64() - t0; out[13] = sh[0]; }
