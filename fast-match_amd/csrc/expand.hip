@@ -27,6 +27,9 @@
 
 namespace fm {
 
+constexpr int kExpThreads = 512;          // one workgroup of 8 waves per image pair (two waves per SIMD: the round is
+                                          // a chain of short latency-bound steps, a second wave hides part of each)
+constexpr int kExpWaves = kExpThreads / 64;
 constexpr int kExpCand = 2048;            // radius-subset capacity per round
 constexpr int kExpSR = 512;               // query rows gathered per staging step
 constexpr int kExpStageBytes = kExpSR * kDim + kExpSR / 32 * 256;
@@ -175,13 +178,13 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     const int tid = threadIdx.x;
     int* start = hist;                       // [kSortBuckets + 1] after the scan
     int* cursor = hist + kSortBuckets + 4;   // [kSortBuckets]
-    for (int b = tid; b < kSortBuckets; b += 256) { start[b] = 0; cursor[b] = 0; }
+    for (int b = tid; b < kSortBuckets; b += kExpThreads) { start[b] = 0; cursor[b] = 0; }
     lds_barrier();
     const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
-    int myb[kExpCand / 256];
+    int myb[kExpCand / kExpThreads];
 #pragma unroll
-    for (int s = 0; s < kExpCand / 256; ++s) {
-        const int i = s * 256 + tid;
+    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+        const int i = s * kExpThreads + tid;
         myb[s] = 0;
         if (i < n) {
             const double d2 = __longlong_as_double((long long)keys[i]);
@@ -192,21 +195,22 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
         }
     }
     lds_barrier();
-    // exclusive scan of the bucket counts: 4 buckets per thread
+    // exclusive scan of the bucket counts: kSortBuckets / kExpThreads buckets per thread
     {
-        int c[4], s = 0;
+        constexpr int kPer = kSortBuckets / kExpThreads;
+        int c[kPer], s = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { c[q] = start[tid * 4 + q]; s += c[q]; }
+        for (int q = 0; q < kPer; ++q) { c[q] = start[tid * kPer + q]; s += c[q]; }
         int off;
         block_exclusive_scan_nosync(s, &off, hist + 2 * kSortBuckets + 8 /* tail: wave totals */);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { start[tid * 4 + q] = off; off += c[q]; }
-        if (tid == 255) start[kSortBuckets] = off;
+        for (int q = 0; q < kPer; ++q) { start[tid * kPer + q] = off; off += c[q]; }
+        if (tid == kExpThreads - 1) start[kSortBuckets] = off;
     }
     lds_barrier();
 #pragma unroll
-    for (int s = 0; s < kExpCand / 256; ++s) {
-        const int i = s * 256 + tid;
+    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+        const int i = s * kExpThreads + tid;
         if (i < n) {
             const int p = start[myb[s]] + atomicAdd(&cursor[myb[s]], 1);
             k2[p] = keys[i];
@@ -216,8 +220,8 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     lds_barrier();
     // final position = bucket start + number of smaller pairs inside the bucket
 #pragma unroll
-    for (int s = 0; s < kExpCand / 256; ++s) {
-        const int p = s * 256 + tid;
+    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+        const int p = s * kExpThreads + tid;
         if (p < n) {
             const unsigned long long k = k2[p];
             const int v = i2[p];
@@ -257,7 +261,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* 
     lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { if (w < wave) base += wave_tot[w]; tot += wave_tot[w]; }
+    for (int w = 0; w < kExpWaves; ++w) { if (w < wave) base += wave_tot[w]; tot += wave_tot[w]; }
     *my_offset = base + inc - v;
     return tot;
 }
@@ -266,7 +270,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* 
 // totals (a in the low half-word, b in the high one).  Ballots + population counts instead of a
 // shuffle scan, and ONE barrier: consecutive calls alternate between two LDS buffers, so the
 // barrier of call k also separates the reads of call k - 1 from the writes of call k + 1.
-__device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int* rank_b, int (*wave_cnt)[4], int& toggle)
+__device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int* rank_b, int (*wave_cnt)[kExpWaves], int& toggle)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long ma = __builtin_amdgcn_ballot_w64(a), mb = __builtin_amdgcn_ballot_w64(b);
@@ -277,13 +281,13 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
     lds_barrier();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = buf[w]; if (w < wave) base += c; tot += c; }
+    for (int w = 0; w < kExpWaves; ++w) { const int c = buf[w]; if (w < wave) base += c; tot += c; }
     *rank_a = (base & 0xffff) + __popcll(ma & below);
     *rank_b = (base >> 16) + __popcll(mb & below);
     return tot;
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
     // dynamic LDS (kExpLdsBytes): a 512-row gather stage, the sort keys / qbest table, the
@@ -299,16 +303,16 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     __shared__ double cur[4];                         // query_pos, target_pos of the round
     __shared__ int sh_i[8];
     __shared__ long long sh_top;
-    __shared__ int wave_tot[4];
-    __shared__ int wave_cnt[2][4];
+    __shared__ int wave_tot[kExpWaves];
+    __shared__ int wave_cnt[2][kExpWaves];
     int rank_toggle = 0;                              // (uniform)
-    __shared__ int sh_rf[4];                          // per-wave candidate counts of the float32 round
+    __shared__ int sh_rf[kExpWaves];                          // per-wave candidate counts of the float32 round
     // The entry a round pushes on TOP of the stack is, nine times out of ten, the next one popped.
     // The pushing thread leaves a copy here together with its key and the empty slot that ended the
     // key's seen-set probe, so the pop needs neither the stack read nor a probe of its own.
     __shared__ long long sh_seed;
     __shared__ unsigned long long sh_key;
-    __shared__ int sh_first[4];
+    __shared__ int sh_first[kExpWaves];
     __shared__ double nxt_e[4];
     __shared__ unsigned long long nxt_key;
     __shared__ long long nxt_slot;
@@ -393,7 +397,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             const bool from_stack = t > 0;
             const long long avail = from_stack ? t : (P.n_seeds - si);
             if (avail <= 0) break;
-            const int w = (int)(avail < 256 ? avail : 256);
+            const int w = (int)(avail < kExpThreads ? avail : kExpThreads);
             bool unseen = false;
             double e[4] = {0, 0, 0, 0};
             unsigned long long key = 0;
@@ -409,7 +413,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             const unsigned long long um = __builtin_amdgcn_ballot_w64(unseen);
             if ((tid & 63) == 0) sh_first[tid >> 6] = um ? (tid + (int)__builtin_ctzll(um)) : 1 << 20;
             lds_barrier();
-            const int first = min(min(sh_first[0], sh_first[1]), min(sh_first[2], sh_first[3]));
+            int first = sh_first[0];
+#pragma unroll
+            for (int q = 1; q < kExpWaves; ++q) first = min(first, sh_first[q]);
             if (first < w && tid == first) {
                 for (int k = 0; k < 4; ++k) cur[k] = e[k];
                 sh_i[1] = ecol; sh_i[2] = erow;
@@ -446,6 +452,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         // the cell actually fetched is the one of the TRUNCATED target position (target.get)
         const int gcol = blk((double)ty, P.cell_h), grow = blk((double)tx, P.cell_w);
         ++n_rounds;
+        // the cell's row range is needed only after the radius query and the sort: fetch it now, so the
+        // load's latency is not on the critical path in front of the cross-check
+        const int cell = gcol * P.rows + grow;
+        const int64_t t0 = P.cell_off[cell];
+        const int64_t t1 = P.cell_off[cell + 1];
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
         if (tid == 0) sh_i[4] = 0;
@@ -472,7 +483,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         rs[j] = s0;
                         pre[j + 1] = pre[j] + (e0 - s0);
                     }
-                    for (int f = tid; f < pre[8]; f += 256) {
+                    for (int f = tid; f < pre[8]; f += kExpThreads) {
                         int j = 0;
 #pragma unroll
                         for (int q = 1; q < 8; ++q) j += (f >= pre[q]) ? 1 : 0;
@@ -499,21 +510,19 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
-        const int cell = gcol * P.rows + grow;
-        const int64_t t0 = P.cell_off[cell];
-        const int nt = (int)(P.cell_off[cell + 1] - t0);
+        const int nt = (int)(t1 - t0);
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
-        for (int i = tid; i < nq; i += 256) keys[i] = ~0ull;     // keys[] becomes the qbest table
+        for (int i = tid; i < nq; i += kExpThreads) keys[i] = ~0ull;     // keys[] becomes the qbest table
         if (P.f32) {
             // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
             lds_barrier();
-            const bool ok = x1_round_f32(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
+            const bool ok = x1_round_f32<kExpThreads>(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
                                          (unsigned long long*)(hist + 2 * kSortBuckets + 16), sh_rf,
                                          P.prof ? pt : nullptr, &tstamp);
             if (!ok) { status = kExpListFull; break; }
         } else {
-            x1_round_wsplit<kExpSR>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
+            x1_round_wsplit<kExpSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
                                     (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
         }
         lds_barrier();
@@ -524,7 +533,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         //     nkey[k] = ratio bits  (k < na)
         const int ccx = center_coord(row, P.cell_w, P.width), ccy = center_coord(col, P.cell_h, P.height);
         int na = 0;
-        for (int s0 = 0; s0 < nq; s0 += 256) {
+        for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
             const int i = s0 + tid;
             bool acc = false;
             double ratio = 0.0;
@@ -552,7 +561,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
         unsigned long long* rk = (unsigned long long*)smem;        // stage buffer is free now
         int n_emit = 0;
-        for (int k0 = 0; k0 < na; k0 += 256) {
+        for (int k0 = 0; k0 < na; k0 += kExpThreads) {
             const int k = k0 + tid;
             const bool live = k < na;
             double mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
@@ -612,10 +621,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 // The first accepted match must be popped first, i.e. sit on top.  One chunk
                 // (na <= 256, the usual case): write in reverse rank order.  More: chunks are
                 // written in ascending order and the whole region is reversed afterwards.
-                const long long dst = (na <= 256) ? sh_top + (ptot - 1 - po) : sh_top + po;
+                const long long dst = (na <= kExpThreads) ? sh_top + (ptot - 1 - po) : sh_top + po;
                 P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
                 P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
-                if (na <= 256 && po == 0) {            // this entry ends up on top: cache it for the next pop
+                if (na <= kExpThreads && po == 0) {            // this entry ends up on top: cache it for the next pop
                     nxt_e[0] = mqx; nxt_e[1] = mqy; nxt_e[2] = nx; nxt_e[3] = ny;
                     nxt_key = nk; nxt_slot = nslot; nxt_valid = 1;
                 }
@@ -636,11 +645,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (status != kExpOk) break;
         // More than one chunk: the pushed region [top_before, top) is in ascending slot order;
         // reverse it in place.
-        if (na > 256) {
+        if (na > kExpThreads) {
             __syncthreads();       // entries pushed by other threads are read from global memory below
             const long long lo = sh_i_top_before, hi = sh_top;
             const long long cntp = hi - lo;
-            for (long long x = tid; x < cntp / 2; x += 256) {
+            for (long long x = tid; x < cntp / 2; x += kExpThreads) {
                 const long long a = lo + x, b = hi - 1 - x;
                 for (int c = 0; c < 4; ++c) { const double t = P.stack[a * 4 + c]; P.stack[a * 4 + c] = P.stack[b * 4 + c]; P.stack[b * 4 + c] = t; }
             }
@@ -669,7 +678,7 @@ hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(expand_kernel, dim3(n_pairs), dim3(256), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
+    hipLaunchKernelGGL(expand_kernel, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
     return hipGetLastError();
 }
 

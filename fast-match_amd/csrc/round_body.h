@@ -13,6 +13,7 @@ namespace fm {
 // global-memory pointers (gptr, tile_ops.h): callers convert theirs once.
 // SR = query rows gathered per staging step (128 in round_kernel, 512 in expand_kernel so that a
 // typical round needs ONE global round trip); smem must hold SR * 128 + SR / 32 * 256 bytes.
+// NT = threads of the workgroup (256 in round_kernel, 512 in expand_kernel).
 //
 // Every wave owns ALL four 32-column
 // blocks of a 128-column chunk (four independent MFMA chains per tile, so the dependent
@@ -20,7 +21,7 @@ namespace fm {
 // four waves' reverse-NN candidates meet in an LDS table tbest[128] through 64-bit
 // atomicMin on (d2 << 32 | slot) -- min d2, then lowest slot, exactly the order
 // cv::batchDistance keeps -- before the scatter-min into qbest.
-template <int SR>
+template <int SR, int NT = 256>
 __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr<const int32_t> q_norm,
                                                 const int* q_rows, int nq,
                                                 gptr<const int8_t> t_rows8, gptr<const int32_t> t_norm,
@@ -29,7 +30,12 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                                                 long long* pt = nullptr, long long* ts = nullptr)
 {
 #define X1_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
-    constexpr int NB = 4;
+    constexpr int NW = NT / 64;                   // waves
+    constexpr int kGroups = NW / 4;               // 4 waves: every wave owns all four 32-column blocks;
+    constexpr int NB = 4 / kGroups;               // 8 waves: two groups of waves own two blocks each
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    constexpr int kPieces = (SR / 8) / NW;        // 1-KiB gather pieces (8 rows) per wave
+    static_assert(kPieces >= 1 && (SR / 8) % NW == 0, "stage rows must spread evenly over the waves");
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -41,13 +47,15 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
     constexpr int kRowBytes = SR * kDim;
     const int xoff = kRowBytes + h * 64;
     const int nstages = (nq + SR - 1) / SR;
+    const int blk0 = (wave % kGroups) * NB;       // this wave's first column block of the 128-column chunk
+    const int tphase = wave / kGroups;            // ... and which tiles it takes (every fourth)
 
     for (int cb0 = 0; cb0 < nt; cb0 += 128) {
         if (tid < 128) tbest[tid] = ~0ull;
         v4i bf[NB][4];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int n = cb0 + 32 * j + (lane & 31);
+            const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (n < nt) bf[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
@@ -64,10 +72,10 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             X1_STAMP(8);
             // issue every global load of the step first (row norms, then the 16-byte row
             // pieces; unconditional, clamped past the subset), then do the LDS writes
-            int nmv[(SR + 255) / 256];
+            int nmv[(SR + NT - 1) / NT];
 #pragma unroll
-            for (int k = 0; k < (SR + 255) / 256; ++k) {
-                const int slot = st * SR + k * 256 + tid;
+            for (int k = 0; k < (SR + NT - 1) / NT; ++k) {
+                const int slot = st * SR + k * NT + tid;
                 nmv[k] = q_norm[q_rows[slot < nq ? slot : nq - 1]];
             }
             // the rows themselves go global -> LDS by DMA (no registers, all SR/32 pieces of a wave in
@@ -75,8 +83,8 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             // source chunk p ^ ((row >> 1) & 7), which lands at chunk position p.  Slots past the subset
             // fetch the last real row; their accumulator init (kPadCinit) keeps them below every real one.
 #pragma unroll
-            for (int i = 0; i < SR / 32; ++i) {
-                const int g = wave * (SR / 32) + i;
+            for (int i = 0; i < kPieces; ++i) {
+                const int g = wave * kPieces + i;
                 const int row = g * 8 + (lane >> 3);
                 const int slot = st * SR + row;
                 const int qi = q_rows[slot < nq ? slot : nq - 1];
@@ -85,8 +93,8 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                                                  (__attribute__((address_space(3))) void*)(smem + g * 1024), 16, 0, 0);
             }
 #pragma unroll
-            for (int k = 0; k < (SR + 255) / 256; ++k) {
-                const int rr = k * 256 + tid;
+            for (int k = 0; k < (SR + NT - 1) / NT; ++k) {
+                const int rr = k * NT + tid;
                 if (rr < SR) {
                     const int slot = st * SR + rr;
                     const int tile = rr >> 5, mm = rr & 31;
@@ -102,7 +110,7 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             lds_barrier();
             X1_STAMP(9);
             const int ntiles = min(SR / kTileRows, (nq - st * SR + kTileRows - 1) / kTileRows);
-            for (int tt = wave; tt < ntiles; tt += 4) {           // this wave's tiles, ascending
+            for (int tt = tphase; tt < ntiles; tt += 4) {         // this wave's tiles, ascending
                 v4i af[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(smem + tt * (kTileRows * kDim) + aoff[c]);
@@ -138,10 +146,10 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             const bool mine = !better(oh, oi, mh, mi);
             const int rh = mine ? mh : oh;
             const int ri = mine ? mi : oi;
-            const int n = cb0 + 32 * j + (lane & 31);
+            const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
             if (h == 0 && n < nt && ri >= 0) {
                 const unsigned d2 = (unsigned)(t_norm[t0 + n] + 1 - rh);
-                atomicMin(&tbest[32 * j + (lane & 31)], ((unsigned long long)d2 << 32) | (unsigned)ri);
+                atomicMin(&tbest[32 * (blk0 + j) + (lane & 31)], ((unsigned long long)d2 << 32) | (unsigned)ri);
             }
         }
         lds_barrier();

@@ -31,7 +31,6 @@ typedef float    r_v4f __attribute__((ext_vector_type(4)));
 constexpr int kRF_SR        = 256;                       // query slots per gather stage
 constexpr int kRF_RowBytes  = 256;                       // fp16 row
 constexpr int kRF_StageBytes = kRF_SR * kRF_RowBytes + kRF_SR * 4;   // rows + accumulator inits
-constexpr int kRF_NC        = 2;                         // 16-column blocks per wave
 
 struct RoundF32 {             // as the host fills it (generic pointers)
     const char*  q_rowsh;     // query bank: fp16 plane (scaled by 2^kq), 256 B per row
@@ -63,8 +62,9 @@ __device__ __forceinline__ float rf_max3(float a, float b, float c)
 // qbest[slot], slot in [0, nq): pre-filled with ~0 by the caller; on return (after the caller's
 // next barrier) (float32 distance bits << 32 | local train index) of the cross-checked match.
 // clist: LDS scratch for clist_cap candidates (u32 each: slot | column << 12); tbest: LDS u64[128];
-// sh: LDS int[4].
+// sh: LDS int[NT / 64].  NT = threads of the workgroup (256 in round_f32_kernel, 512 in expand_kernel).
 // Returns false (uniformly) if the candidate list overflowed: the round's result is then invalid.
+template <int NT = 256>
 __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_rows, int nq, int64_t t0, int nt,
                                              char* smem, unsigned long long* qbest, unsigned* clist, int clist_cap,
                                              unsigned long long* tbest, int* sh,
@@ -80,6 +80,10 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
 #pragma unroll
     for (int s = 0; s < 4; ++s) aoff[s] = c16 * kRF_RowBytes + 16 * ((4 * s + g) ^ c16);
     const int xoff = kRF_SR * kRF_RowBytes + 16 * g;
+    constexpr int NW = NT / 64;                          // waves of the workgroup
+    constexpr int kRF_NC = 128 / (16 * NW);              // 16-column blocks per wave: the waves share a 128-column chunk
+    constexpr int kPieces = (kRF_SR / 4) / NW;           // 1-KiB gather pieces (4 rows) per wave
+    static_assert(kRF_NC >= 1 && kPieces >= 1, "4 or 8 waves");
     const int nstages = (nq + kRF_SR - 1) / kRF_SR;
     bool ok = true;
 
@@ -91,8 +95,8 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
     auto gather = [&](int st) {
         lds_barrier();                                  // previous image fully consumed
 #pragma unroll
-        for (int i = 0; i < kRF_SR / 16; ++i) {
-            const int piece = wave * (kRF_SR / 16) + i;   // 64 pieces of 4 rows per stage, 16 per wave
+        for (int i = 0; i < kPieces; ++i) {
+            const int piece = wave * kPieces + i;         // 64 pieces of 4 rows per stage
             const int row = piece * 4 + (lane >> 4);
             const int slot = st * kRF_SR + row;
             const int qi = q_rows[slot < nq ? slot : nq - 1];
@@ -100,9 +104,11 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
             __builtin_amdgcn_global_load_lds((gptr<const void>)src,
                                              (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
         }
-        const int aslot = st * kRF_SR + tid;
-        const float aux = aslot < nq ? R.q_auxf[q_rows[aslot]] * R.aux_mul : -3.4e38f;
-        ((float*)(smem + kRF_SR * kRF_RowBytes))[tid] = aux;
+        if (tid < kRF_SR) {
+            const int aslot = st * kRF_SR + tid;
+            const float aux = aslot < nq ? R.q_auxf[q_rows[aslot]] * R.aux_mul : -3.4e38f;
+            ((float*)(smem + kRF_SR * kRF_RowBytes))[tid] = aux;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
     };
@@ -110,7 +116,7 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
     int loaded = -1;                                      // stage whose image is in LDS (uniform)
     for (int cb0 = 0; cb0 < nt; cb0 += 128) {
         if (tid < 128) tbest[tid] = ~0ull;
-        const int wcap = clist_cap / 4;                    // every wave appends to its own quarter of the list
+        const int wcap = clist_cap / NW;                   // every wave appends to its own part of the list
         unsigned* const wlist = clist + wave * wcap;
         int wcount = 0;                                    // wave uniform
         // this wave's 32 train rows (two 16-column blocks), stationary for the whole chunk
@@ -118,7 +124,7 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
         float marg[kRF_NC];
 #pragma unroll
         for (int j = 0; j < kRF_NC; ++j) {
-            const int n = cb0 + wave * 32 + 16 * j + c16;
+            const int n = cb0 + wave * (16 * kRF_NC) + 16 * j + c16;
             const bool in = n < nt;
             marg[j] = in ? fmaf(R.eps_c, R.t_normf[t0 + n], R.eps_nm) : 0.f;
 #pragma unroll
@@ -205,7 +211,7 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
                 const int nv = 4 * ntiles;
 #pragma unroll
                 for (int j = 0; j < kRF_NC; ++j) {
-                    const int tl = wave * 32 + 16 * j + c16;                  // column within the 128-chunk
+                    const int tl = wave * (16 * kRF_NC) + 16 * j + c16;       // column within the 128-chunk
                     unsigned long long b = (cb0 + tl < nt) ? bits[j] : 0ull;
                     for (;;) {
                         const bool has = b != 0ull;
@@ -255,14 +261,19 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
         RF_STAMP(10);
         if (lane == 0) sh[wave] = wcount;
         lds_barrier();
-        int c0 = sh[0], c1 = sh[1], c2 = sh[2], c3 = sh[3];
-        if (c0 > wcap || c1 > wcap || c2 > wcap || c3 > wcap) ok = false;
-        c0 = min(c0, wcap); c1 = min(c1, wcap); c2 = min(c2, wcap); c3 = min(c3, wcap);
-        const int ncand = c0 + c1 + c2 + c3;
+        int cnt[NW], ncand = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int c = sh[w];
+            if (c > wcap) ok = false;
+            cnt[w] = min(c, wcap);
+            ncand += cnt[w];
+        }
         // exact float32 chain per candidate (K5's order: k ascending, v = a - b, s = fma(v, v, s))
-        for (int i = tid; i < ncand; i += 256) {
-            const int w = (i >= c0) + (i >= c0 + c1) + (i >= c0 + c1 + c2);
-            const int o = i - (w > 0 ? c0 : 0) - (w > 1 ? c1 : 0) - (w > 2 ? c2 : 0);
+        for (int i = tid; i < ncand; i += NT) {
+            int w = 0, o = i;
+#pragma unroll
+            for (int q = 0; q < NW - 1; ++q) { const bool past = w == q && o >= cnt[q]; o -= past ? cnt[q] : 0; w += past ? 1 : 0; }
             const unsigned e = clist[w * wcap + o];
             const int slot = (int)(e & 4095u), tl = (int)(e >> 12);
             gptr<const r_v4f> cp = (gptr<const r_v4f>)(R.t_rowsf + (size_t)(t0 + cb0 + tl) * kDim);
