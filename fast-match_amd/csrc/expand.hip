@@ -31,12 +31,14 @@ constexpr int kExpThreads = 512;          // one workgroup of 8 waves per image 
                                           // a chain of short latency-bound steps, a second wave hides part of each)
 constexpr int kExpWaves = kExpThreads / 64;
 constexpr int kExpCand = 2048;            // radius-subset capacity per round
+constexpr int kExpPosCap = 1024;          // accepted matches of a round whose positions are kept in LDS
 constexpr int kExpSR = 512;               // query rows gathered per staging step
 constexpr int kExpStageBytes = kExpSR * kDim + kExpSR / 32 * 256;
 constexpr int kExpLdsBytes = kExpStageBytes + kExpCand * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
        kExpListFull = 6 };
+static_assert(kExpCand * 8 + kExpPosCap * 32 <= kExpSR * kDim + kExpSR / 32 * 256, "rk[] + pos4[] must fit the stage buffer");
 static_assert(kRF_StageBytes <= kExpStageBytes, "the float32 round's gather image must fit the stage buffer");
 // float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
 constexpr int kExpClistCap = (kExpCand * (8 + 4) + 2 * 1024 * 4) / 4;
@@ -532,27 +534,40 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         // (a) compact the accepted slots in order:  tix[k] = slot | t_local << 11,
         //     nkey[k] = ratio bits  (k < na)
         const int ccx = center_coord(row, P.cell_w, P.width), ccy = center_coord(col, P.cell_h, P.height);
+        double* const pos4 = (double*)(smem + kExpCand * 8);          // [kExpPosCap][4] behind rk[] (stage buffer)
         int na = 0;
         for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
             const int i = s0 + tid;
             bool acc = false;
-            double ratio = 0.0;
+            double ratio = 0.0, pq0 = 0, pq1 = 0, pt0 = 0, pt1 = 0;
             int t_local = 0;
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
                     // high word: exact integer d^2 (int8 route) or the float32 distance bits (float32 route)
                     const float d = P.f32 ? __uint_as_float((unsigned)(qb >> 32)) : sqrtf((float)(unsigned)(qb >> 32));
-                    ratio = (double)d / P.q_selfdist[cand[i]];
-                    acc = ratio < P.tau;
+                    // the positions step (b) needs ride on the same memory round trip as the self distance
+                    const int qrow = cand[i];
                     t_local = (int)(unsigned)qb;
+                    const double sd = P.q_selfdist[qrow];
+                    pq0 = P.q_pos[2 * qrow]; pq1 = P.q_pos[2 * qrow + 1];
+                    pt0 = P.t_pos[2 * (t0 + t_local)]; pt1 = P.t_pos[2 * (t0 + t_local) + 1];
+                    ratio = (double)d / sd;
+                    acc = ratio < P.tau;
                 }
             }
             int o, o_unused;
             const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
             // keys[] (qbest) of slots < s0 + 256 are consumed (the barrier inside the ranking separates
             // those reads from these writes): entries na+o <= i never clobber unread ones
-            if (acc) { tix[na + o] = i | (t_local << 11); nkey[na + o] = (unsigned long long)__double_as_longlong(ratio); }
+            if (acc) {
+                tix[na + o] = i | (t_local << 11);
+                nkey[na + o] = (unsigned long long)__double_as_longlong(ratio);
+                if (na + o < kExpPosCap) {               // (the stage buffer is free after the cross-check)
+                    double* pp = pos4 + 4 * (na + o);
+                    pp[0] = pq0; pp[1] = pq1; pp[2] = pt0; pp[3] = pt1;
+                }
+            }
             na += cnt;
         }
         lds_barrier();
@@ -573,8 +588,13 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int slot = tix[k] & 2047, t_local = tix[k] >> 11;
                 qrow_idx = cand[slot];
                 rbits = nkey[k];
-                mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
-                px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
+                if (k < kExpPosCap) {                    // fetched together with the self distances in (a)
+                    const double* pp = pos4 + 4 * k;
+                    mqx = pp[0]; mqy = pp[1]; px = pp[2]; py = pp[3];
+                } else {
+                    mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
+                    px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
+                }
                 const int xd = (int)px - ccx, yd = (int)py - ccy;          // Grid_Cache.get_neighbor
                 int ncol = col, nrow = row;
                 if (yd < xd && yd < -xd) ncol = col - 1;
@@ -596,13 +616,31 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 rk[k] = k1;
             }
             lds_barrier();
-            // earlier entries of this round with the same key win (lists are in slot order)
+            // Earlier entries of this round with the same key win (lists are in slot order).  A round
+            // accepts some tens of matches; one thread per entry walking all earlier entries is a chain
+            // of dependent LDS reads as long as the list.  Instead every WAVE takes entries k and its
+            // lanes the earlier entries j: one pass of <= 64 comparisons per entry, flags in dupf[].
+            int* const dupf = hist;                                  // [kExpCand]: bit 0 push, bit 1 emit duplicate
+            {
+                const int kend = min(na, k0 + kExpThreads);
+                const int lane = tid & 63, wave = tid >> 6;
+                for (int kk = k0 + wave; kk < kend; kk += kExpWaves) {
+                    const unsigned long long a_nk = keys[kk], a_rk = rk[kk], a_rb = nkey[kk];
+                    bool dp = false, de = false;
+                    for (int j = lane; j < kk; j += 64) {
+                        dp |= a_nk != ~0ull && keys[j] == a_nk;
+                        de |= rk[j] == a_rk && nkey[j] == a_rb;
+                    }
+                    const int f = (__builtin_amdgcn_ballot_w64(dp) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(de) != 0ull ? 2 : 0);
+                    if (lane == 0) dupf[kk] = f;
+                }
+            }
+            lds_barrier();
             bool push = live && nk != ~0ull, emit = live && !known;
             if (live) {
-                for (int j = 0; j < k && (push || emit); ++j) {
-                    if (push && keys[j] == nk) push = false;
-                    if (emit && rk[j] == k1 && nkey[j] == rbits) emit = false;
-                }
+                const int f = dupf[k];
+                if (f & 1) push = false;
+                if (f & 2) emit = false;
             }
             // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
             // chunks of 256 accepted matches are pushed in reverse chunk order below
