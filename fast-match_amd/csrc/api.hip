@@ -1591,9 +1591,16 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         host[i].n_seeds = n_seeds[i];
         host[i].tau = tau[i];
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, host.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+    // the int8 and the float32 pairs are two kernels: descriptors grouped by kind, one launch each
+    std::vector<ExpandPair> grouped;
+    grouped.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) if (!host[i].f32) grouped.push_back(host[i]);
+    const int n_i8 = (int)grouped.size();
+    for (int i = 0; i < n; ++i) if (host[i].f32) grouped.push_back(host[i]);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_expand(ctx->ws_in, n, ctx->stream));
+    if (n_i8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n_i8, false, ctx->stream));
+    if (n - n_i8 > 0) HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n_i8 * sizeof(ExpandPair), n - n_i8, true, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     std::vector<long long> res((size_t)n * 4);

@@ -289,6 +289,9 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
     return tot;
 }
 
+// F32: the pairs of the launch hold float32 banks (float32 round) -- a kernel of its own, so that
+// the int8 kernel does not carry the float32 round's registers (inlined together they spill).
+template <bool F32>
 __global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
@@ -516,7 +519,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
         for (int i = tid; i < nq; i += kExpThreads) keys[i] = ~0ull;     // keys[] becomes the qbest table
-        if (P.f32) {
+        if constexpr (F32) {
             // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
             lds_barrier();
             const bool ok = x1_round_f32<kExpThreads>(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
@@ -545,7 +548,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
                     // high word: exact integer d^2 (int8 route) or the float32 distance bits (float32 route)
-                    const float d = P.f32 ? __uint_as_float((unsigned)(qb >> 32)) : sqrtf((float)(unsigned)(qb >> 32));
+                    const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : sqrtf((float)(unsigned)(qb >> 32));
                     // the positions step (b) needs ride on the same memory round trip as the self distance
                     const int qrow = cand[i];
                     t_local = (int)(unsigned)qb;
@@ -708,15 +711,17 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 }
 
-hipError_t launch_expand(const void* d_pairs, int n_pairs, hipStream_t stream)
+hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
+        hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(expand_kernel, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
+    if (f32) hipLaunchKernelGGL(expand_kernel<true>, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
+    else     hipLaunchKernelGGL(expand_kernel<false>, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
     return hipGetLastError();
 }
 

@@ -257,3 +257,31 @@ def test_device_loop_float32_banks_with_an_integer_valued_side(ctx, monkeypatch)
         _same_matches(got, exp)
         _same_matches(host, exp)
         assert len(got) > 20 and stats["rounds"] == oget.rounds
+
+
+def test_match_many_with_integer_and_float32_pairs_in_one_call(ctx, monkeypatch):
+    """One fm_expand_run over pairs of both descriptor kinds (two kernels behind one call): every
+    pair equals its own single-pair run and the oracle."""
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    rng = np.random.default_rng(9)
+    pairs, oracles = [], []
+    for k in range(4):
+        q, t = synth.image_pair((640, 480), 2200 + 200 * k, seed=1300 + k)
+        conv = (lambda d: d) if k % 2 == 0 else (lambda d: d.astype(np.float32) + rng.uniform(-0.4, 0.4, d.shape).astype(np.float32))
+        qd, td, qtd, ttd = conv(q["descriptors"]), conv(t["descriptors"]), conv(q["thumb_descriptors"]), conv(t["thumb_descriptors"])
+        mc = cache.Metric_Cache.from_arrays(qd, q["positions"], q["size"], qtd, q["thumb_positions"], q["thumb_size"],
+                                            options={"context": ctx})
+        fi = cache.Feature_Image(t["size"], t["positions"], td, t["thumb_positions"], ttd, t["thumb_size"])
+        pairs.append((mc, fi))
+        oq = fo.OQuery(qd, q["positions"], q["size"],
+                       thumb={"descriptors": qtd, "positions": q["thumb_positions"], "size": q["thumb_size"]})
+        ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
+              "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+        oracles.append(fo.o_match(oq, ot, {}))
+    prepared = []
+    res = fastmatch.match_many(pairs, 0.8, {"context": ctx, "prepared_out": prepared})
+    assert all(p["expander"] not in (None, False) for p in prepared)
+    for (mc, fi), r, og in zip(pairs, res, oracles):
+        _same_matches(r, og(0.8))
+        _same_matches(r, fastmatch.match(mc, fi, {"context": ctx})(0.8))
+        assert len(r) > 20
