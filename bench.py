@@ -199,6 +199,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: libraries that print banners to fd 1 (RCCL's
+    # version block) are sent to stderr, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     # FM_BENCH_BACKEND=gloo + FM_BENCH_SINGLE_DEVICE=1: dry-run of the N > 1 code path on a
@@ -249,6 +254,7 @@ def main():
     counts = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
     outbuf = outbufs[0]
     use_async = world == 1 and os.environ.get("FM_BENCH_SYNC") != "1"
+    dev_async = world > 1 and os.environ.get("FM_BENCH_SYNC") != "1"
 
     # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
@@ -275,6 +281,22 @@ def main():
             for j, (qb, tb) in enumerate(banks):
                 ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
             ctx.sync()                                      # results of the whole batch are on the host now
+            return int(sum(int(c[0]) for c in counts))
+        if dev_async and (abi_gather is not None or device_gather):
+            # no host synchronisation between pairs: K1 launches back to back on the library's stream,
+            # each pair's small kernels + its all-gather beside the next pair's K1
+            for j, (qb, tb) in enumerate(banks):
+                if abi_gather is not None:
+                    g = abi_gather
+                    ctx.match_accepted_dev_async(qb, tb, TAU, g["rows"].data_ptr(), g["count"].data_ptr(), NQ, h_count=counts[j])
+                    ctx.gather_matches(g["rows"].data_ptr(), g["count"].data_ptr(), NQ, g["all_rows"].data_ptr(),
+                                       g["all_counts"].data_ptr(), wait=False)
+                else:
+                    rows, count = gatherer.send_buffers()
+                    ctx.match_accepted_dev_async(qb, tb, TAU, rows.data_ptr(), count.data_ptr(), NQ, h_count=counts[j],
+                                                 consumer_stream=gatherer.consumer_stream())
+                    gatherer.submit_device()
+            ctx.sync()
             return int(sum(int(c[0]) for c in counts))
         for qb, tb in banks:
             if abi_gather is not None:
@@ -436,8 +458,10 @@ def main():
                          "hbm_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "hbm_frac_of_8tbps": (traffic / (k_ms * 1e-3) / 8e12) if traffic else None,
                          "mfma_pipe_busy_frac": busy,
+                         "kernel_launches_in_region": args.steps * PAIRS_PER_STEP,
                          "note": "int8 ops: 256 per descriptor pair x 1e10 pairs per launch; kernel_ms = mean HIP-event time of the "
-                                 "K1 launches of the timed region, events on the library's own stream; hbm_gbps = PMC HBM bytes "
+                                 "K1 launches of the timed region that carry an event pair (every 4th async call: each event "
+                                 "record is a packet the next K1 queues behind), events on the library's own stream; hbm_gbps = PMC HBM bytes "
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
                                  "cycles of the launch (profiles/)"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
@@ -451,7 +475,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Q, T)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,6 +77,7 @@ SYMBOLS = {
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
+    "fm_match_accepted_dev_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "fm_expand_create": (_INT, [_P, ctypes.POINTER(fm_expand_desc), ctypes.POINTER(_P)]),
     "fm_expand_destroy": (_INT, [_P, _P]),
@@ -396,6 +397,18 @@ class Context(object):
         self._check(self.lib.fm_match_accepted_dev(self.handle, q.handle, t.handle, float(tau), int(cap),
                                                    _P(int(rows_ptr)), _P(int(count_ptr)), ctypes.byref(n)))
         return n.value
+
+    def match_accepted_dev_async(self, q, t, tau, rows_ptr, count_ptr, cap, h_count=None, consumer_stream=0):
+        """``match_accepted_dev`` enqueued without a synchronisation (``sync()`` later).  ``h_count``:
+        a ``pinned_empty(1, np.int64)`` array that also receives the count, or None;
+        ``consumer_stream``: the raw handle of the stream that will read the buffers
+        (``torch.cuda.current_stream().cuda_stream``), ordered against the fill in both directions."""
+        if h_count is not None and (not isinstance(h_count, np.ndarray) or h_count.dtype != np.int64 or h_count.size < 1):
+            raise ValueError("h_count must be an int64 array (pinned_empty(1, np.int64))")
+        self._check(self.lib.fm_match_accepted_dev_async(self.handle, q.handle, t.handle, float(tau), int(cap),
+                                                         _P(int(rows_ptr)), _P(int(count_ptr)),
+                                                         _ptr(h_count) if h_count is not None else None,
+                                                         _P(int(consumer_stream)) if consumer_stream else None))
 
     def knn2_ratio(self, q, t, tau, out=None):
         """Classic Ratio-Match: 2-NN + d1/d2 < tau, accepted matches in ascending query index:

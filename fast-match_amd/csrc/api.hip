@@ -46,9 +46,24 @@ struct fm_ctx {
     struct StagedCopy { void* dst; size_t off, bytes; };
     std::vector<StagedCopy> staged;
     // calls enqueued without a synchronisation (fm_match_accepted_async): their events, read at fm_sync
-    struct PendingTimer { hipEvent_t c0, c1, k0, k1; bool timed; int64_t pairs; };
+    struct PendingTimer { hipEvent_t c0, c1, k0, k1; bool timed; int64_t pairs; bool call_timed = true; };
+    int64_t async_calls = 0;
     std::vector<PendingTimer> pending;       // in flight
     std::vector<PendingTimer> timer_pool;    // idle event sets
+    // fm_match_accepted_async: K1 launches follow each other on `stream`; the small kernels behind a
+    // K1 (election, decode + ratio, compaction) run on `stream_tail` and overlap the NEXT call's K1.
+    // Two workspace slots alternate; a slot's tail kernels leave its bound[] and qbest[] arrays in
+    // the state the next K1 / election expects, so no fill operations sit between two K1 launches.
+    hipStream_t stream_tail = nullptr;
+    hipStream_t rows_stream = nullptr;      // stream that produced the last device-resident rows (fm_gather_matches follows it)
+    hipEvent_t ev_consumer = nullptr;
+    struct AsyncSlot {
+        void* ws = nullptr; size_t bytes = 0;
+        int64_t nq = -1, ncols_alloc = -1, partial_bytes = -1;   // layout the arrays were initialised for
+        hipEvent_t tail_done = nullptr, k_done = nullptr;
+        bool in_use = false;
+    } aslot[2];
+    int aslot_next = 0;
     void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
     int   comm_ranks = 0;
     fm_stats stats{};
@@ -269,12 +284,16 @@ __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial
 // (lowest q on ties) = min over the split partials; then scatter-min of (d2<<32 | t)
 // into qbest[rq]: q keeps the closest electing train row, lowest t on ties.  64-bit
 // atomicMin is order independent, so the result is deterministic.
+// bound_reset (async calls): the K1 that produced `partial` is complete, so its bound[] array is
+// put back to "no bound" here for the next K1 that uses this workspace slot.
 __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ partial, int nsplit,
                                       int ncols_alloc, int64_t nt,
-                                      unsigned long long* __restrict__ qbest, unsigned t_offset = 0)
+                                      unsigned long long* __restrict__ qbest, unsigned t_offset = 0,
+                                      int* __restrict__ bound_reset = nullptr)
 {
     // four lanes per train row, each takes every 4th split: short independent load chains
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (bound_reset && gid < ncols_alloc) bound_reset[gid] = INT32_MIN;
     const int64_t t = gid >> 2;
     const int part = (int)(gid & 3);
     unsigned long long b = ~0ull;
@@ -298,18 +317,20 @@ __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ par
 // Cross-check step 3 + optional R1: decode qbest, distance = sqrtf(d2) (float32, exact
 // for integer d2 < 2^24), ratio = (double)dist / selfdist[q] in float64, pass = ratio < tau
 // (fastmatch.pyx:124,165; :50,75,82).
-__global__ void xcheck_finalize_kernel(const unsigned long long* __restrict__ qbest, int64_t nq,
+__global__ void xcheck_finalize_kernel(const unsigned long long* qbest, int64_t nq,
                                        const double* __restrict__ selfdist, double tau,
                                        int32_t* __restrict__ tidx, float* __restrict__ dist,
                                        double* __restrict__ ratio, uint8_t* __restrict__ pass,
                                        unsigned long long* __restrict__ npass, int f32,
-                                       int* __restrict__ block_counts)
+                                       int* __restrict__ block_counts,
+                                       unsigned long long* qbest_reset = nullptr)
 {
     __shared__ int wave_cnt[4];
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool p = false;
     if (q < nq) {
         const unsigned long long key = qbest[q];
+        if (qbest_reset) qbest_reset[q] = ~0ull;     // (async calls: the slot's table is left empty for its next election)
         int32_t ti = -1;
         float d = INFINITY;
         double r = NAN;
@@ -477,6 +498,19 @@ extern "C" const char* fm_last_error(const fm_ctx* ctx)
     return copy.c_str();
 }
 
+// FM_TUNE_LIVE=1: the launch-shape overrides are re-read before every plan (A/B runs inside one
+// process, scripts/gpu_k12_ab.py); otherwise they are read once when the context is created.
+static void refresh_tuning(fm_ctx* ctx)
+{
+    if (!getenv("FM_TUNE_LIVE")) return;
+    const char* s;
+    ctx->force_nb = (s = getenv("FM_NB")) ? atoi(s) : 0;
+    ctx->force_nsplit = (s = getenv("FM_NSPLIT")) ? atoi(s) : 0;
+    ctx->force_nw = (s = getenv("FM_NW")) ? atoi(s) : 0;
+}
+
+extern "C" int fm_ctx_destroy(fm_ctx* ctx);
+
 extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
 {
     if (!out) return fail(nullptr, FM_EINVAL, "fm_ctx_create: out is NULL");
@@ -511,6 +545,21 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
         delete ctx;
         return fail(nullptr, FM_EDEVICE, std::string("fm_ctx_create: ") + hipGetErrorString(e));
     }
+    {
+        // the tail stream gets the highest priority: its workgroups are few and short and should not
+        // queue behind the thousands of workgroups of the K1 they overlap
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        if ((e = hipStreamCreateWithPriority(&ctx->stream_tail, hipStreamNonBlocking, greatest)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->aslot[0].tail_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->aslot[1].tail_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->ev_consumer, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->aslot[0].k_done, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->aslot[1].k_done, hipEventDisableTiming)) != hipSuccess) {
+            fm_ctx_destroy(ctx);
+            return fail(nullptr, FM_EDEVICE, std::string("fm_ctx_create: ") + hipGetErrorString(e));
+        }
+    }
     if (hipHostMalloc((void**)&ctx->h_scratch, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_scratch = nullptr; }
     if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
     if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
@@ -532,6 +581,14 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (!ctx) return FM_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_tail) (void)hipStreamSynchronize(ctx->stream_tail);
+    for (auto& sl : ctx->aslot) {
+        if (sl.ws) (void)hipFree(sl.ws);
+        if (sl.tail_done) (void)hipEventDestroy(sl.tail_done);
+        if (sl.k_done) (void)hipEventDestroy(sl.k_done);
+    }
+    if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
+    if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
     if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
     for (auto* v : {&ctx->pending, &ctx->timer_pool})
         for (auto& t : *v) { (void)hipEventDestroy(t.c0); (void)hipEventDestroy(t.c1); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
@@ -555,8 +612,10 @@ static int drain_pending(fm_ctx* ctx)
 {
     for (auto& t : ctx->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.c0, t.c1) == hipSuccess) { ctx->stats.total_ms += ms; ctx->stats.calls += 1; }
-        else (void)hipGetLastError();
+        if (t.call_timed) {      // enqueue-to-results latency of the call (overlapped calls: not additive)
+            if (hipEventElapsedTime(&ms, t.k0, t.c1) == hipSuccess) { ctx->stats.total_ms += ms; ctx->stats.calls += 1; }
+            else (void)hipGetLastError();
+        }
         if (t.timed) {
             if (hipEventElapsedTime(&ms, t.k0, t.k1) == hipSuccess) {
                 ctx->stats.kernel_ms += ms;
@@ -575,6 +634,7 @@ extern "C" int fm_sync(fm_ctx* ctx)
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_sync: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
     return drain_pending(ctx);
 }
 
@@ -584,6 +644,7 @@ extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)
     if (!ctx->pending.empty()) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
         drain_pending(ctx);
     }
     *out = ctx->stats;
@@ -958,12 +1019,13 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     if (f32) {
         if ((rc = rowreduce_f32_route(ctx, q, t, 2, &pl)) != FM_OK) return rc;
     } else {
+        refresh_tuning(ctx);
         pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
         if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes())) != FM_OK) return rc;
         int* d_bound = nullptr;
         if (ctx->use_coop && pl.nsplit > 1) {
             d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
-            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
         HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
@@ -1069,7 +1131,8 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
                          const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr,
-                         int32_t* dev_rows = nullptr, long long* dev_count = nullptr, bool async_mode = false)
+                         int32_t* dev_rows = nullptr, long long* dev_count = nullptr, bool async_mode = false,
+                         hipStream_t consumer = nullptr)
 {
     const bool compact = compact_cap >= 0;
     const bool to_device = dev_rows != nullptr;
@@ -1104,6 +1167,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     RowReducePlan pl;
     int* d_bound = nullptr;
     if (!f32) {
+        refresh_tuning(ctx);
         pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
         if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
         if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
@@ -1114,14 +1178,16 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         // kernel writes directly; the events of this call are read at fm_sync.
         void* a_q = pinned_device_alias(c_qidx); void* a_t = pinned_device_alias(tidx);
         void* a_d = pinned_device_alias(dist);   void* a_r = pinned_device_alias(ratio);
-        void* a_c = pinned_device_alias(n_pass);
-        if (!a_q || !a_t || !a_d || !a_r || !a_c || f32)
-            return fail(ctx, FM_EINVAL, std::string(who) + ": needs integer-valued banks and page-locked outputs (fm_host_alloc)");
+        void* a_c = n_pass ? pinned_device_alias(n_pass) : nullptr;
+        if (f32) return fail(ctx, FM_EINVAL, std::string(who) + ": needs integer-valued banks");
+        if (to_device ? (n_pass && !a_c) : (!a_q || !a_t || !a_d || !a_r || !a_c))
+            return fail(ctx, FM_EINVAL, std::string(who) + ": host outputs must be page-locked (fm_host_alloc)");
         fm_ctx::PendingTimer tm;
         if (!ctx->timer_pool.empty()) { tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back(); }
         else {
             if (ctx->pending.size() >= 1024) {                 // bound the number of live events
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
                 drain_pending(ctx);
                 tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back();
             } else {
@@ -1131,26 +1197,82 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         }
         tm.timed = nt > 0;
         tm.pairs = nq * nt;
-        HIP_TRY(ctx, hipEventRecord(tm.c0, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
-        if (nt > 0) {
-            if (d_bound)
-                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
-            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(tm.k1, ctx->stream));
-            hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest);
+        // workspace slot: partial | bound | qbest | tidx | dist | ratio | pass | block counts
+        fm_ctx::AsyncSlot& sl = ctx->aslot[ctx->aslot_next];
+        ctx->aslot_next ^= 1;
+        const size_t pbytes = (pl.partial_bytes(1) + 15) & ~(size_t)15;
+        const size_t bbytes = ((size_t)pl.ncols_alloc * 4 + 15) & ~(size_t)15;
+        const size_t a_qbest = pbytes + bbytes, a_tidx = a_qbest + (size_t)nq * 8, a_dist = a_tidx + (size_t)nq * 4;
+        const size_t a_ratio = (a_dist + (size_t)nq * 4 + 7) & ~(size_t)7, a_pass = a_ratio + (size_t)nq * 8;
+        const size_t a_bc = (a_pass + (size_t)nq + 15) & ~(size_t)15, a_end = a_bc + (size_t)nblk * 4 + 16;
+        if (sl.in_use)       // the slot's previous tail reads partial / qbest and re-arms bound: K1 must not start before
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, sl.tail_done, 0));
+        if (a_end > sl.bytes || sl.nq != nq || sl.ncols_alloc != pl.ncols_alloc || sl.partial_bytes != (int64_t)pbytes) {
+            if (sl.in_use) HIP_TRY(ctx, hipEventSynchronize(sl.tail_done));
+            if (a_end > sl.bytes) {
+                if (sl.ws) { HIP_TRY(ctx, hipFree(sl.ws)); sl.ws = nullptr; sl.bytes = 0; }
+                HIP_TRY(ctx, hipMalloc(&sl.ws, a_end + a_end / 4));
+                sl.bytes = a_end + a_end / 4;
+            }
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)((char*)sl.ws + pbytes), (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync((char*)sl.ws + a_qbest, 0xff, (size_t)nq * 8, ctx->stream));
+            sl.nq = nq; sl.ncols_alloc = pl.ncols_alloc; sl.partial_bytes = (int64_t)pbytes;
         }
-        hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const unsigned long long*)d_qbest, nq, (const double*)q->selfdist, tau, d_tidx, d_dist, d_ratio,
-                           d_pass, d_cnt, f32, (int*)(base + o_bc));
-        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                           (const int32_t*)d_tidx, (const float*)d_dist, (const double*)d_ratio, (const uint8_t*)d_pass,
-                           (const int*)(base + o_bc), nq, compact_cap < nq ? compact_cap : nq, (int32_t*)a_q, (int32_t*)a_t,
-                           (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
+        char* sb = (char*)sl.ws;
+        unsigned long long* s_partial = (unsigned long long*)sb;
+        int* s_bound = (int*)(sb + pbytes);
+        unsigned long long* s_qbest = (unsigned long long*)(sb + a_qbest);
+        int32_t* s_tidx = (int32_t*)(sb + a_tidx);
+        float* s_dist = (float*)(sb + a_dist);
+        double* s_ratio = (double*)(sb + a_ratio);
+        uint8_t* s_pass = (uint8_t*)(sb + a_pass);
+        int* s_bc = (int*)(sb + a_bc);
+        const bool coop = ctx->use_coop && pl.nsplit > 1;
+        // Every event record is a packet the K1 launches of consecutive calls queue behind; the
+        // start-of-kernel event is therefore taken for every async_time_every-th call only (those
+        // calls are the ones fm_get_stats accounts as timed K1 launches; FM_ASYNC_TIME_EVERY, default 1).
+        static const int time_every = [] { const char* e = getenv("FM_ASYNC_TIME_EVERY"); return e ? atoi(e) : 4; }();
+        const bool timed_call = time_every > 0 && (ctx->async_calls++ % time_every) == 0;
+        tm.timed = tm.timed && timed_call;
+        tm.call_timed = timed_call;
+        if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
+        if (nt > 0)
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, s_partial, coop ? s_bound : nullptr, ctx->use_glds, ctx->stream));
+        // (untimed calls hand over through the slot's own event, created without timing)
+        hipEvent_t handover = timed_call ? tm.k1 : sl.k_done;
+        HIP_TRY(ctx, hipEventRecord(handover, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, handover, 0));
+        if (nt > 0) {
+            const int64_t sthreads = nt * 4 > (int64_t)pl.ncols_alloc ? nt * 4 : (int64_t)pl.ncols_alloc;
+            hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ctx->stream_tail,
+                               (const unsigned long long*)s_partial, pl.nsplit, pl.ncols_alloc, nt, s_qbest, 0u, s_bound);
+        }
+        hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream_tail,
+                           (const unsigned long long*)s_qbest, nq, (const double*)q->selfdist, tau, s_tidx, s_dist, s_ratio,
+                           s_pass, (unsigned long long*)nullptr, f32, s_bc, s_qbest);
+        if (to_device) {
+            // the rows go to the caller's device buffers, which a consumer stream (the result gather)
+            // reads: the compaction waits for what that stream has been given so far (the gather that
+            // last read these buffers), and the stream waits for the compaction
+            if (consumer) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, ctx->ev_consumer, 0));
+            }
+            hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream_tail,
+                               (const int32_t*)s_tidx, (const float*)s_dist, (const uint8_t*)s_pass,
+                               (const int*)s_bc, nq, compact_cap, dev_rows, dev_count, (unsigned long long*)a_c);
+        } else {
+            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream_tail,
+                               (const int32_t*)s_tidx, (const float*)s_dist, (const double*)s_ratio, (const uint8_t*)s_pass,
+                               (const int*)s_bc, nq, compact_cap < nq ? compact_cap : nq, (int32_t*)a_q, (int32_t*)a_t,
+                               (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
+        }
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream));
+        if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream_tail));
+        HIP_TRY(ctx, hipEventRecord(sl.tail_done, ctx->stream_tail));
+        if (to_device && consumer) HIP_TRY(ctx, hipStreamWaitEvent(consumer, sl.tail_done, 0));
+        ctx->rows_stream = to_device ? ctx->stream_tail : ctx->stream;
+        sl.in_use = true;
         ctx->pending.push_back(tm);
         return FM_OK;
     }
@@ -1159,7 +1281,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     if (!compact) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nt > 0) {
         if (d_bound)
-            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         if (f32) {
             if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
         } else {
@@ -1181,6 +1303,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long cnt = 0;
     if (to_device) {
+        ctx->rows_stream = ctx->stream;
         // accepted matches stay on the device as packed rows (multi-GPU gather input)
         void* a_c = ctx->h_scratch ? pinned_device_alias(ctx->h_scratch) : nullptr;
         hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
@@ -1262,6 +1385,7 @@ extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
     RowReducePlan pl;
     int* d_bound = nullptr;
     if (!f32) {
+        refresh_tuning(ctx);
         pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
         if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
         if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
@@ -1270,7 +1394,7 @@ extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
     if (nt > 0) {
         if (d_bound)
-            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         if (f32) {
             if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
         } else {
@@ -1331,6 +1455,31 @@ extern "C" int fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_ban
     if (q && q->n == 0) HIP_TRY(ctx, hipMemset(d_count, 0, 8));
     return xcheck_common(ctx, q, t, true, tau, nullptr, nullptr, nullptr, nullptr, n_accepted, "fm_match_accepted_dev",
                          cap, nullptr, d_rows, (long long*)d_count);
+}
+
+extern "C" int fm_match_accepted_dev_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                                           int32_t* d_rows, int64_t* d_count, int64_t* h_count, void* consumer_stream)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_dev_async: ctx is NULL");
+    if (cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_async: cap < 0");
+    if (!d_rows || !d_count) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_async: device output pointer is NULL");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, d_rows) != hipSuccess || at.type != hipMemoryTypeDevice ||
+        hipPointerGetAttributes(&at, d_count) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_async: d_rows / d_count must be device memory");
+    }
+    if (q && q->n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream_tail));
+        if (h_count) *h_count = 0;
+        if (consumer_stream) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, ctx->stream_tail));
+            HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)consumer_stream, ctx->ev_consumer, 0));
+        }
+        ctx->rows_stream = ctx->stream_tail;
+    }
+    return xcheck_common(ctx, q, t, true, tau, nullptr, nullptr, nullptr, nullptr, h_count, "fm_match_accepted_dev_async",
+                         cap, nullptr, d_rows, (long long*)d_count, true, (hipStream_t)consumer_stream);
 }
 
 extern "C" int fm_ratio_filter(fm_ctx* ctx, const float* dist, const double* selfdist, const int32_t* qrows,
@@ -1695,8 +1844,11 @@ extern "C" int fm_gather_matches(fm_ctx* ctx, const int32_t* d_rows, const int64
         return fail(ctx, FM_EINVAL, "fm_gather_matches: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::string err;
-    const int rc = comm_gather(ctx->comm, d_rows, d_count, cap, d_all_rows, d_all_counts, ctx->stream, &err);
+    // on the stream that filled d_rows: behind fm_match_accepted_dev_async that is the tail stream, so
+    // the collective does not sit in front of the next pair's K1
+    hipStream_t gs = ctx->rows_stream ? ctx->rows_stream : ctx->stream;
+    const int rc = comm_gather(ctx->comm, d_rows, d_count, cap, d_all_rows, d_all_counts, gs, &err);
     if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches: " + err);
-    if (wait) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (wait) HIP_TRY(ctx, hipStreamSynchronize(gs));
     return FM_OK;
 }

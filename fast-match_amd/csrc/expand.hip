@@ -243,13 +243,13 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     lds_barrier();
 }
 
-// Exclusive scan of per-thread counts over the 256-thread block; returns the total.
-__device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[4]*/);
+// Exclusive scan of per-thread counts over the workgroup; returns the total.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[kExpWaves]*/);
 __device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot)
 {
     return block_exclusive_scan(v, my_offset, wave_tot);
 }
-__device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[4]*/)
+__device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[kExpWaves]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
@@ -268,7 +268,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* 
     return tot;
 }
 
-// Exclusive ranks of up to two boolean flags per thread over the 256-thread block, and their
+// Exclusive ranks of up to two boolean flags per thread over the workgroup, and their
 // totals (a in the low half-word, b in the high one).  Ballots + population counts instead of a
 // shuffle scan, and ONE barrier: consecutive calls alternate between two LDS buffers, so the
 // barrier of call k also separates the reads of call k - 1 from the writes of call k + 1.
@@ -308,7 +308,6 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     __shared__ double cur[4];                         // query_pos, target_pos of the round
     __shared__ int sh_i[8];
     __shared__ long long sh_top;
-    __shared__ int wave_tot[kExpWaves];
     __shared__ int wave_cnt[2][kExpWaves];
     int rank_toggle = 0;                              // (uniform)
     __shared__ int sh_rf[kExpWaves];                          // per-wave candidate counts of the float32 round
@@ -393,8 +392,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         lds_barrier();
         // Not the cached entry: entries whose key was matched since they were pushed are skipped
         // (fastmatch.pyx:71-72) -- on average four stale entries per round, each a dependent
-        // stack read + hash probe if one thread pops them one by one.  Instead 256 threads look at
-        // the next 256 entries of the source (stack from the top, then the seed list in order) at
+        // stack read + hash probe if one thread pops them one by one.  Instead the workgroup looks at
+        // the next kExpThreads entries of the source (stack from the top, then the seed list in order) at
         // once; the first one with an unseen key is the round's entry, everything before it is
         // stale and dropped, everything after it stays where it is.
         while (!sh_i[0] && sh_i[3] == kExpOk) {
@@ -561,7 +560,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
             int o, o_unused;
             const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
-            // keys[] (qbest) of slots < s0 + 256 are consumed (the barrier inside the ranking separates
+            // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
             // those reads from these writes): entries na+o <= i never clobber unread ones
             if (acc) {
                 tix[na + o] = i | (t_local << 11);
@@ -646,8 +645,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 if (f & 2) emit = false;
             }
             // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
-            // chunks of 256 accepted matches are pushed in reverse chunk order below
-            // one scan for both ranks: pushes in the low half-word, emits in the high one (<= 256 each)
+            // chunks of kExpThreads accepted matches are pushed in reverse chunk order below
+            // one scan for both ranks: pushes in the low half-word, emits in the high one (<= kExpThreads each)
             int po, eo;
             const int petot = block_rank_flags(push, emit, &po, &eo, wave_cnt, rank_toggle);
             const int ptot = petot & 0xffff, etot = petot >> 16;
@@ -660,7 +659,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (sh_i[6]) { status = kExpMatchFull; break; }
             if (push) {
                 // The first accepted match must be popped first, i.e. sit on top.  One chunk
-                // (na <= 256, the usual case): write in reverse rank order.  More: chunks are
+                // (na <= kExpThreads, the usual case): write in reverse rank order.  More: chunks are
                 // written in ascending order and the whole region is reversed afterwards.
                 const long long dst = (na <= kExpThreads) ? sh_top + (ptot - 1 - po) : sh_top + po;
                 P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;

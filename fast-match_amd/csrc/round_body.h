@@ -1,6 +1,6 @@
 // The arithmetic of one expansion round on integer-valued banks (cross-checked 1-NN, SURVEY.md
 // Appendix A.3) as ONE workgroup-wide device function shared by round_kernel (rounds.hip) and
-// expand_kernel (expand.hip).  256 threads; contains barriers: every thread of the block must call it.
+// expand_kernel (expand.hip).  NT threads; contains barriers: every thread of the block must call it.
 #pragma once
 #include "tile_ops.h"
 

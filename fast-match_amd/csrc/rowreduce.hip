@@ -28,6 +28,16 @@
 #include <type_traits>
 #include <stdlib.h>
 
+#ifdef FM_COUNT_VISITS
+__device__ unsigned long long g_visits[256];     // [split]: exact-path visits (wave, block), [128 + split]: units x blocks
+extern "C" int fm_debug_visits(unsigned long long* out, int reset)
+{
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_visits), sizeof(g_visits));
+    if (reset) { static unsigned long long z[256]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_visits), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 namespace fm {
 
 struct RRParams {
@@ -172,13 +182,16 @@ void rowreduce_kernel(RRParams p)
             // stage st's DMA was issued two hand-overs ago; only the DMA of stage st + 1 (the newest
             // VMEM operations of this wave, unless an exact path published a bound since) may still
             // be in flight.  The bound loads (gnext) are older than that DMA, so they have landed too.
-            static_assert(NC == 4, "the wait below names four bound registers");
             if (st + 1 < st1) {
-                if (wave == NW - 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) : "n"(kDmaPerWave + 1) : "memory");
-                else                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) : "n"(kDmaPerWave) : "memory");
+                if (wave == NW - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave + 1) : "memory");
+                else                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(gnext[0]), "+v"(gnext[1]), "+v"(gnext[2]), "+v"(gnext[3]) :: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            // (volatile asm statements keep their order: the bound registers count as written here,
+            // behind the wait, so no use of them can be scheduled in front of it)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(gnext[j]));
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -241,6 +254,9 @@ void rowreduce_kernel(RRParams p)
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
+#ifdef FM_COUNT_VISITS
+                        if (lane == 0) atomicAdd(&g_visits[split & 127], 1ull);
+#endif
                         const bool improved = top[j].update(acc[0][j], acc[1][j], low0, low1,
                                                             st * (kStageRows / kTileRows) + u);
                         thr[j] = max(top[j].own_threshold(), gthr[j]);
@@ -268,6 +284,9 @@ void rowreduce_kernel(RRParams p)
         }
     }
 
+#ifdef FM_COUNT_VISITS
+    if (lane == 0) atomicAdd(&g_visits[128 + (split & 127)], (unsigned long long)(st1 - st0) * 4 * NC);
+#endif
     // Merge the four lane groups (same output row, interleaved reduced rows), then emit.
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -365,7 +384,7 @@ static int nbuf_choice(int ktop)
 template <int NC, int KTOP, int NW>
 static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
 {
-    if constexpr (NC == 4 && NW == 8) {
+    if constexpr (NW == 8) {
         // PRIO: s_setprio 2 while a wave issues a unit's 16 MFMAs as one burst, back to 0 for the
         // epilogue (A/B on one box: 0.897 -> 0.887 ms); FM_PRIO=0 selects the variant without it
         const char* pe = getenv("FM_PRIO");

@@ -231,9 +231,17 @@ class MatchGatherer(object):
             return self.fill_buf[self.slot], self.fill_mine[self.slot]
         return self.buf[self.slot], self.mine[self.slot]
 
+    def consumer_stream(self):
+        """Raw handle of the stream the collectives of this gatherer are ordered on (torch's current
+        stream): what ``Context.match_accepted_dev_async`` takes as ``consumer_stream``.  0 on CPU."""
+        if self.on_cpu and self.fill_buf is None:
+            return 0
+        return int(self.torch.cuda.current_stream().cuda_stream)
+
     def submit_device(self):
-        """Start the all-gather of the slot handed out by the last ``send_buffers()``.  The
-        fill must be complete (fm_match_accepted_dev is synchronous)."""
+        """Start the all-gather of the slot handed out by the last ``send_buffers()``.  The fill
+        must be complete (fm_match_accepted_dev) or ordered in front of torch's current stream
+        (fm_match_accepted_dev_async with ``consumer_stream()``)."""
         self._wait()
         k = self.slot
         self.slot ^= 1

@@ -158,7 +158,9 @@ int  fm_match_accepted(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double t
  * Every output -- qidx, tidx, dist, ratio and *n_accepted -- must be page-locked host memory
  * (fm_host_alloc), which the compaction kernel writes directly; banks must be integer valued.
  * A stream of image pairs then runs back to back on the GPU with no host round
- * trip between pairs (the reference maps its matcher over pairs sequentially, turntable.py:59).  */
+ * trip between pairs (the reference maps its matcher over pairs sequentially, turntable.py:59):
+ * the K1 launches follow each other on the context's stream while each pair's small kernels
+ * (election, ratio test, compaction) run on a second stream beside the next pair's K1.          */
 int  fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
                              int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
                              int64_t* n_accepted /*page-locked*/);
@@ -173,6 +175,19 @@ int  fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
 int  fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
                            int32_t* d_rows /*device [cap][3]*/, int64_t* d_count /*device*/,
                            int64_t* n_accepted /*host, or NULL*/);
+
+/* fm_match_accepted_dev without the synchronisation: the call enqueues and returns.  The match
+ * kernel (K1) goes to the context's stream, the small kernels behind it (election, ratio test,
+ * compaction into d_rows / d_count) to a second stream, where they overlap the NEXT pair's K1.
+ * consumer_stream (a hipStream_t, or NULL) is the stream that will read d_rows / d_count -- the
+ * stream the caller's all-gather is enqueued on: the compaction first waits for the work that
+ * stream has been given so far (the collective that last read these buffers), and the stream is
+ * made to wait for the compaction, so the caller needs no host synchronisation between pairs.
+ * h_count: page-locked host word (fm_host_alloc) that also receives the count, or NULL.
+ * Integer-valued banks only.  fm_gather_matches called next follows the same ordering.         */
+int  fm_match_accepted_dev_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
+                                 int32_t* d_rows /*device [cap][3]*/, int64_t* d_count /*device*/,
+                                 int64_t* h_count /*page-locked or NULL*/, void* consumer_stream /*hipStream_t or NULL*/);
 
 /* ---- K4: many match_position rounds in one launch ------------------------------------
  * Round b matches the query rows  q_rows[q_off[b] .. q_off[b+1])  of bank q (the radius

@@ -6,6 +6,7 @@ import numpy as np
 import fastmatch_amd as fm
 from fastmatch_amd import synth
 
+os.environ["FM_TUNE_LIVE"] = "1"
 ctx = fm.Context(0)
 Q, T, _ = synth.planted_pair(100000, 100000, 20250002)
 qb, tb = ctx.bank(Q), ctx.bank(T)

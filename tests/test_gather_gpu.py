@@ -88,8 +88,25 @@ def test_async_stream_of_pairs_equals_the_synchronous_calls(ctx):
             assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta)
             assert np.array_equal(out[2][:m], da) and np.array_equal(out[3][:m], ra)
     st = ctx.stats()
-    assert st["kernel_launches"] == 20 and st["calls"] == 20           # 10 async + 10 sync
-    assert st["pairs"] == 4 * sum(len(p[0]) * len(p[1]) for p in pairs)
+    # 10 synchronous calls, all timed, + 10 async ones of which every FM_ASYNC_TIME_EVERY-th (default:
+    # 4th) carries the start-of-kernel event; pairs are accounted for the timed launches only
+    assert 10 < st["kernel_launches"] <= 20 and st["calls"] == st["kernel_launches"]
+    # pairs of equal shape reuse a workspace slot without re-initialising it: the slot's tail kernels
+    # must leave bound[] / qbest[] clean (three passes over three same-shape pairs + an odd one out)
+    same = [_banks(ctx, 3000, 2400, seed=60 + k) for k in range(3)] + [pairs[1]]
+    want = [ctx.match_accepted(qb, tb, 0.7) for (_, _, qb, tb) in same]
+    souts = [(ctx.pinned_empty(4000, np.int32), ctx.pinned_empty(4000, np.int32),
+              ctx.pinned_empty(4000, np.float32), ctx.pinned_empty(4000, np.float64)) for _ in range(12)]
+    scnt = [ctx.pinned_empty(1, np.int64) for _ in range(12)]
+    for j in range(12):
+        ctx.match_accepted_async(same[j % 4][2], same[j % 4][3], 0.7, souts[j], scnt[j])
+    ctx.sync()
+    for j in range(12):
+        qa, ta, da, ra = want[j % 4]
+        m = int(scnt[j][0])
+        assert m == len(qa) > 50
+        assert np.array_equal(souts[j][0][:m], qa) and np.array_equal(souts[j][1][:m], ta)
+        assert np.array_equal(souts[j][2][:m], da) and np.array_equal(souts[j][3][:m], ra)
     with pytest.raises(_ffi.FastMatchHipError):                        # pageable outputs are refused
         ctx.match_accepted_async(pairs[0][2], pairs[0][3], 0.7,
                                  (np.empty(4000, np.int32), np.empty(4000, np.int32), np.empty(4000, np.float32), np.empty(4000, np.float64)),
@@ -148,6 +165,7 @@ else:
 ctx = fastmatch_amd.Context(0)
 g = sharding.MatchGatherer(tdev, capacity=4000, fill_device=torch.device("cuda", 0))
 expect = []
+keep = []
 for step in range(3):                                   # a stream of pairs, gathers overlapped
     allq = []
     for r in range(world):
@@ -156,11 +174,17 @@ for step in range(3):                                   # a stream of pairs, gat
     Q, T = allq[rank]
     qb, tb = ctx.bank(Q), ctx.bank(T)
     qb.set_selfdist(ctx.self_dist(qb))
+    keep.append((qb, tb))                               # banks outlive the kernels enqueued on them
     rows, count = g.send_buffers()
-    n = ctx.match_accepted_dev(qb, tb, 0.7, rows.data_ptr(), count.data_ptr(), 4000)
+    if os.environ.get("FM_TEST_ASYNC") == "1":          # no host synchronisation between the pairs
+        ctx.match_accepted_dev_async(qb, tb, 0.7, rows.data_ptr(), count.data_ptr(), 4000,
+                                     consumer_stream=g.consumer_stream())
+    else:
+        n = ctx.match_accepted_dev(qb, tb, 0.7, rows.data_ptr(), count.data_ptr(), 4000)
     g.submit_device()
     counts, allrows = g.finish() if step == 2 else (None, None)
     if step == 2:
+        ctx.sync()
         for r in range(world):                          # every rank's rows == its host-path result
             Qr, Tr = allq[r]
             qr, tr = ctx.bank(Qr), ctx.bank(Tr)
@@ -175,10 +199,10 @@ print("RANK_OK", rank)
 '''
 
 
-def _run_ranks(world, backend, tmp_path):
+def _run_ranks(world, backend, tmp_path, async_fill=False):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT % {"root": ROOT})
-    env = dict(os.environ, FM_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, FM_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", FM_TEST_ASYNC="1" if async_fill else "0")
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
@@ -196,3 +220,81 @@ def test_gatherer_device_path_two_ranks_sharing_the_gpu(tmp_path):
     """Two ranks on the one GPU of the box: device-side fill, gloo transport (RCCL refuses two
     ranks on one device); every rank sees both ranks' rows."""
     _run_ranks(2, "gloo", tmp_path)
+
+
+def test_gatherer_async_fill_one_rank_rccl(tmp_path):
+    """fm_match_accepted_dev_async feeding the RCCL all-gather through stream ordering only."""
+    _run_ranks(1, "nccl", tmp_path, async_fill=True)
+
+
+def test_gatherer_async_fill_two_ranks_sharing_the_gpu(tmp_path):
+    _run_ranks(2, "gloo", tmp_path, async_fill=True)
+
+
+def test_device_rows_async_are_ordered_against_the_consumer_stream(ctx):
+    """fm_match_accepted_dev_async: a stream of pairs into two alternating device buffers that a
+    torch stream snapshots right behind every call -- no host synchronisation until the end.  Every
+    snapshot equals the synchronous call's rows (fill -> consumer ordering), although each buffer
+    is refilled two pairs later (consumer -> fill ordering)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cap = 4000
+    pairs = [_banks(ctx, 3600, 3000, seed=80 + k) for k in range(3)] + [_banks(ctx, 2100, 2500, seed=90)]
+    want = []
+    for (_, _, qb, tb) in pairs:
+        qa, ta, da, _ = ctx.match_accepted(qb, tb, 0.8)
+        want.append(sharding.pack_matches(qa, ta, da))
+    bufs = [torch.full((cap, 3), -7, dtype=torch.int32, device=dev) for _ in range(2)]
+    cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+    hcnt = [ctx.pinned_empty(1, np.int64) for _ in range(10)]
+    side = torch.cuda.Stream(device=dev)
+    snaps = []
+    with torch.cuda.stream(side):
+        for j in range(10):
+            k = j % 2
+            ctx.match_accepted_dev_async(pairs[j % 4][2], pairs[j % 4][3], 0.8, bufs[k].data_ptr(), cnts[k].data_ptr(), cap,
+                                         h_count=hcnt[j], consumer_stream=side.cuda_stream)
+            snaps.append((bufs[k].clone(), cnts[k].clone()))        # on `side`, behind the fill
+            bufs[k].fill_(-5)                                        # the next fill of this buffer must come after this
+    ctx.sync()
+    side.synchronize()
+    for j, (rows, cnt) in enumerate(snaps):
+        w = want[j % 4]
+        assert int(cnt.item()) == len(w) == int(hcnt[j][0]) > 100
+        assert np.array_equal(rows[:len(w)].cpu().numpy(), w)
+        assert (rows[len(w):] == -5).all() or j < 2                  # (first use of a buffer: still the -7 fill)
+    with pytest.raises(fastmatch_amd_error()):                       # host memory is refused
+        ctx.match_accepted_dev_async(pairs[0][2], pairs[0][3], 0.8, np.zeros((cap, 3), np.int32).ctypes.data, cnts[0].data_ptr(), cap)
+
+
+def fastmatch_amd_error():
+    from fastmatch_amd import _ffi
+    return _ffi.FastMatchHipError
+
+
+def test_rccl_gather_follows_the_async_fill_one_rank():
+    """fm_gather_matches behind fm_match_accepted_dev_async runs on the stream that fills the rows."""
+    import torch
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    dev = torch.device("cuda", 0)
+    cap = 3000
+    pairs = [_banks(c, 3000, 2600, seed=15 + k) for k in range(3)]
+    rows = torch.full((cap, 3), -7, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    all_rows = [torch.full((1, cap, 3), -9, dtype=torch.int32, device=dev) for _ in pairs]
+    all_counts = [torch.full((1,), -1, dtype=torch.int64, device=dev) for _ in pairs]
+    c.comm_init(1, 0, c.comm_unique_id())
+    try:
+        for k, (_, _, qb, tb) in enumerate(pairs):      # one send buffer, three pairs, no host synchronisation
+            c.match_accepted_dev_async(qb, tb, 0.8, rows.data_ptr(), count.data_ptr(), cap)
+            c.gather_matches(rows.data_ptr(), count.data_ptr(), cap, all_rows[k].data_ptr(), all_counts[k].data_ptr(), wait=False)
+        c.sync()
+        for k, (_, _, qb, tb) in enumerate(pairs):
+            qa, ta, da, _ = c.match_accepted(qb, tb, 0.8)
+            n = int(all_counts[k][0].item())
+            assert n == len(qa) > 100
+            assert np.array_equal(all_rows[k][0, :n].cpu().numpy(), sharding.pack_matches(qa, ta, da))
+    finally:
+        c.comm_destroy()
+    c.close()
