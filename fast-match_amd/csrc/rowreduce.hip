@@ -355,13 +355,13 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
-    // ~6 rounds of the workgroups the chip holds (16 waves per CU): enough to balance the
-    // tail, few enough that every workgroup sweeps a long slice.
-    int64_t want = 6 * 256 * (16 / nw);
-    int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
+    // Just UNDER five rounds of the workgroups the chip holds (16 waves per CU): a grid slightly over
+    // a whole number of rounds leaves most CUs idle for the run time of a workgroup at the end
+    // (100k x 100k: 16 splits = 6.1 rounds 0.867 ms, 13 splits = 4.98 rounds 0.842 ms; K2 1.095 -> 1.041).
+    const int64_t resident = 256 * (16 / nw);
+    int64_t nsplit = (5 * resident) / pl.nchunks;
     if (nsplit > nstages / 8) nsplit = nstages / 8;   // keep >= 8 stages (1024 rows) per split
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > 4) nsplit = (nsplit + 3) / 4 * 4;
     if (force_nsplit > 0) nsplit = force_nsplit;
     if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
     int64_t per = (nstages + nsplit - 1) / nsplit;
