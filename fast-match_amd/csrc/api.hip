@@ -1024,8 +1024,8 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
         if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes())) != FM_OK) return rc;
         int* d_bound = nullptr;
         if (ctx->use_coop && pl.nsplit > 1) {
-            d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));
-            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));      // bound1 | bound2 (rowreduce.hip)
+            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc * 2, ctx->stream));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
         HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));

@@ -58,7 +58,7 @@ struct RowReducePlan {
     int nsplit;
     int stages_per_split;
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
-    size_t bound_bytes() const { return (size_t)ncols_alloc * 4; }
+    size_t bound_bytes() const { return (size_t)ncols_alloc * 4 * 2; }   // (top-2 launches keep two arrays)
 };
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw);
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,

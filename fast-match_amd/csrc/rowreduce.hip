@@ -135,10 +135,18 @@ void rowreduce_kernel(RRParams p)
     }
 
     TopK8<KTOP> top[NC];
-    int thr[NC];          // a unit is examined exactly only if some acc >= thr
-    int gthr[NC];         // part of thr that comes from the other blocks' published bounds
+    int thr[NC];          // a unit is examined exactly only if some acc >= thr.  Both sources of thr -- the
+                          // lane's own K-th best and the published bounds -- only ever rise, so thr = max(thr, new)
+    int ret1[NC];         // KTOP == 2: what bound1[] held when this lane last published a new best (see below)
 #pragma unroll
-    for (int j = 0; j < NC; ++j) { top[j].init(); thr[j] = INT32_MIN; gthr[j] = INT32_MIN; }
+    for (int j = 0; j < NC; ++j) { top[j].init(); thr[j] = INT32_MIN; ret1[j] = INT32_MIN; }
+    // KTOP == 2: bound[0 .. ncols_alloc) = bound1 (best hi any lane has reached), bound[ncols_alloc ..) =
+    // bound2, a lower bound of the GLOBAL second best, which is what the thresholds come from.  A lane
+    // feeds bound2 with its own second best and, when its best changes, with min(new best, previous
+    // content of bound1): that content is the hi of a different candidate (another lane's best, or this
+    // lane's displaced one), so two candidates reach the minimum.  The fetch-max that returns it is
+    // consumed at the next stage hand-over, behind the wait the hand-over needs anyway.
+    int* const bound_thr = (KTOP == 2 && p.bound) ? p.bound + p.ncols_alloc : p.bound;
 
     const int st0 = split * p.stages_per_split;
     const int st1 = min(st0 + p.stages_per_split, p.nstages);
@@ -164,7 +172,7 @@ void rowreduce_kernel(RRParams p)
     for (int j = 0; j < NC; ++j) {
         const int n = cb + 16 * j + c16;
         gnext[j] = (p.bound && n < p.ncols_alloc)
-            ? __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
+            ? __hip_atomic_load(bound_thr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
     }
     // prologue prefetch (issued AFTER the bound loads: vmcnt retires in order, so "at most the newest
     // stage's DMA outstanding" implies that the bound loads and every older DMA have landed)
@@ -198,9 +206,20 @@ void rowreduce_kernel(RRParams p)
             __syncthreads();   // stage st landed; every wave is done with the other buffer
         }
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            gthr[j] = gnext[j] >> 1;                    // hi >= g possible iff acc >= floor(g / 2)
-            thr[j] = max(thr[j], gthr[j]);
+        for (int j = 0; j < NC; ++j) thr[j] = max(thr[j], gnext[j] >> 1);      // hi >= g possible iff acc >= floor(g / 2)
+        if constexpr (KTOP == 2) {
+            if (p.bound) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    if (__builtin_amdgcn_ballot_w64(ret1[j] != INT32_MIN) != 0ull) {       // (rare after the first stages)
+                        const int c = min(ret1[j], top[j].hi(0));
+                        const int n = cb + 16 * j + c16;
+                        if (ret1[j] != INT32_MIN && c > gnext[j] && n < p.ncols_alloc)
+                            __hip_atomic_fetch_max(bound_thr + n, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ret1[j] = INT32_MIN;
+                    }
+                }
+            }
         }
         if constexpr (NBUF == 2) {
             if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
@@ -211,10 +230,10 @@ void rowreduce_kernel(RRParams p)
                 const int n = cb + 16 * j + c16;
                 if constexpr (NBUF == 3) {
                     // (ncols_alloc is a multiple of the chunk, so n is always inside the array)
-                    load_bound_untracked(gnext[j], p.bound + n);
+                    load_bound_untracked(gnext[j], bound_thr + n);
                 } else {
                     if (n < p.ncols_alloc)
-                        gnext[j] = __hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gnext[j] = __hip_atomic_load(bound_thr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -257,13 +276,19 @@ void rowreduce_kernel(RRParams p)
 #ifdef FM_COUNT_VISITS
                         if (lane == 0) atomicAdd(&g_visits[split & 127], 1ull);
 #endif
+                        const int best_before = top[j].key[0];
                         const bool improved = top[j].update(acc[0][j], acc[1][j], low0, low1,
                                                             st * (kStageRows / kTileRows) + u);
-                        thr[j] = max(top[j].own_threshold(), gthr[j]);
+                        thr[j] = max(thr[j], top[j].own_threshold());
                         if (p.bound && improved && top[j].full()) {
                             const int n = cb + 16 * j + c16;
-                            if (n < p.ncols_alloc)
-                                __hip_atomic_fetch_max(p.bound + n, top[j].kth_hi(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (n < p.ncols_alloc) {
+                                __hip_atomic_fetch_max(bound_thr + n, top[j].kth_hi(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if constexpr (KTOP == 2) {
+                                    if (top[j].key[0] != best_before)
+                                        ret1[j] = __hip_atomic_fetch_max(p.bound + n, top[j].hi(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
                         }
                     }
                 }
