@@ -42,7 +42,7 @@ class fm_expand_desc(ctypes.Structure):
                 ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64)]
 
 
-EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 2048 rows",
+EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 4096 rows (2048 for float32 banks)",
                  3: "target position outside the image", 4: "result list full", 5: "hash table full",
                  6: "float32 round: candidate list full"}
 

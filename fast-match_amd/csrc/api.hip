@@ -1748,14 +1748,34 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     for (int i = 0; i < n; ++i) if (host[i].f32) grouped.push_back(host[i]);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (n_i8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n_i8, false, ctx->stream));
-    if (n - n_i8 > 0) HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n_i8 * sizeof(ExpandPair), n - n_i8, true, ctx->stream));
+    if (n_i8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n_i8, false, false, ctx->stream));
+    if (n - n_i8 > 0) HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n_i8 * sizeof(ExpandPair), n - n_i8, true, false, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     std::vector<long long> res((size_t)n * 4);
     for (int i = 0; i < n; ++i)
         HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], pairs[i]->dev.result, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // Pairs in which a round's radius subset exceeded the kernel's capacity (status 2) run again, from
+    // the start, in the larger-capacity variant of the kernel (int8 banks); the rest keep their results.
+    {
+        std::vector<int> redo;
+        for (int i = 0; i < n; ++i) if (res[(size_t)i * 4 + 3] == 2 && !host[i].f32 && !getenv("FM_EXPAND_NO_BIG")) redo.push_back(i);
+        if (!redo.empty()) {
+            grouped.clear();
+            for (int i : redo) {
+                HIP_TRY(ctx, hipMemsetAsync(pairs[i]->dev.seen, 0xff, (size_t)pairs[i]->dev.seen_cap * 8, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(pairs[i]->dev.found, 0xff, (size_t)pairs[i]->dev.found_cap * 16, ctx->stream));
+                grouped.push_back(host[i]);
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), redo.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, launch_expand(ctx->ws_in, (int)redo.size(), false, true, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+            for (int i : redo)
+                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], pairs[i]->dev.result, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
     if (getenv("FM_EXPAND_PROF")) {
         long long pr[16];

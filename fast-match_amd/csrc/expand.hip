@@ -30,18 +30,30 @@ namespace fm {
 constexpr int kExpThreads = 512;          // one workgroup of 8 waves per image pair (two waves per SIMD: the round is
                                           // a chain of short latency-bound steps, a second wave hides part of each)
 constexpr int kExpWaves = kExpThreads / 64;
-constexpr int kExpCand = 2048;            // radius-subset capacity per round
-constexpr int kExpPosCap = 1024;          // accepted matches of a round whose positions are kept in LDS
-constexpr int kExpSR = 512;               // query rows gathered per staging step
-constexpr int kExpStageBytes = kExpSR * kDim + kExpSR / 32 * 256;
-constexpr int kExpLdsBytes = kExpStageBytes + kExpCand * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
+constexpr int kExpCand = 2048;            // radius-subset capacity per round (the kernel every pair starts with)
+constexpr int kExpCandBig = 4096;         // ... of the kernel a pair is re-run with when a round exceeds it (int8 banks)
+
+// Capacities of one kernel variant.  LDS: gather stage | keys/qbest u64[CAND] | cand i32[CAND] |
+// nkey u64[CAND] | tix i32[CAND] | hist | tbest.  The big variant pays for its 4096-row arrays with a
+// 256-row gather stage (two gather steps for a typical round) and keeps almost no match positions in LDS.
+template <int CAND>
+struct ExpCfg {
+    static constexpr int kCand = CAND;
+    static constexpr int kSlotBits = CAND <= 2048 ? 11 : 12;                 // tix[] = slot | t_local << kSlotBits
+    static constexpr int kSR = CAND <= 2048 ? 512 : 256;                     // query rows gathered per staging step
+    static constexpr int kStageBytes = kSR * kDim + kSR / 32 * 256;
+    static constexpr int kPosCap = (kStageBytes - CAND * 8) / 32;            // accepted matches whose positions are kept in LDS
+    static constexpr int kLdsBytes = kStageBytes + CAND * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
+    // float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
+    static constexpr int kClistCap = (CAND * (8 + 4) + 2 * 1024 * 4) / 4;
+    static_assert((1 << kSlotBits) >= CAND, "slot bits");
+    static_assert(kPosCap >= 0 && CAND * 8 <= kStageBytes, "rk[] must fit the stage buffer");
+    static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
+};
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
        kExpListFull = 6 };
-static_assert(kExpCand * 8 + kExpPosCap * 32 <= kExpSR * kDim + kExpSR / 32 * 256, "rk[] + pos4[] must fit the stage buffer");
-static_assert(kRF_StageBytes <= kExpStageBytes, "the float32 round's gather image must fit the stage buffer");
-// float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
-constexpr int kExpClistCap = (kExpCand * (8 + 4) + 2 * 1024 * 4) / 4;
+static_assert(kRF_StageBytes <= ExpCfg<kExpCand>::kStageBytes, "the float32 round's gather image must fit the stage buffer");
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 {
@@ -165,15 +177,16 @@ __device__ __forceinline__ int center_coord(int i, int cell, int limit)
     return c < limit - 1 ? c : limit - 1;
 }
 
-// Sort n <= kExpCand (key, idx) pairs held in LDS ascending by (key, idx); pairs are unique.
+// Sort n <= CAND (key, idx) pairs held in LDS ascending by (key, idx); pairs are unique.
 // keys are the bit patterns of squared distances in [0, r2]: inside a disc they are spread
 // uniformly, so a counting sort over kSortBuckets linear buckets leaves ~n / kSortBuckets
 // elements per bucket and the exact order inside a bucket is fixed by a handful of
 // comparisons.  bucket(d2) is monotone in d2, so bucket order + in-bucket order = total order.
-// Scratch: k2 (u64[kExpCand]), i2 (int[kExpCand]), hist (int[2 * kSortBuckets + 8]).
+// Scratch: k2 (u64[CAND]), i2 (int[CAND]), hist (int[2 * kSortBuckets + 8]).
 constexpr int kSortBuckets = 1024;
 __device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot);
 
+template <int CAND>
 __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, unsigned long long* k2,
                                                  int* i2, int* hist, int n, double r2)
 {
@@ -183,9 +196,9 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     for (int b = tid; b < kSortBuckets; b += kExpThreads) { start[b] = 0; cursor[b] = 0; }
     lds_barrier();
     const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
-    int myb[kExpCand / kExpThreads];
+    int myb[CAND / kExpThreads];
 #pragma unroll
-    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+    for (int s = 0; s < CAND / kExpThreads; ++s) {
         const int i = s * kExpThreads + tid;
         myb[s] = 0;
         if (i < n) {
@@ -211,7 +224,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     }
     lds_barrier();
 #pragma unroll
-    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+    for (int s = 0; s < CAND / kExpThreads; ++s) {
         const int i = s * kExpThreads + tid;
         if (i < n) {
             const int p = start[myb[s]] + atomicAdd(&cursor[myb[s]], 1);
@@ -222,7 +235,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     lds_barrier();
     // final position = bucket start + number of smaller pairs inside the bucket
 #pragma unroll
-    for (int s = 0; s < kExpCand / kExpThreads; ++s) {
+    for (int s = 0; s < CAND / kExpThreads; ++s) {
         const int p = s * kExpThreads + tid;
         if (p < n) {
             const unsigned long long k = k2[p];
@@ -291,19 +304,22 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 
 // F32: the pairs of the launch hold float32 banks (float32 round) -- a kernel of its own, so that
 // the int8 kernel does not carry the float32 round's registers (inlined together they spill).
-template <bool F32>
+// CAND: capacity variant (ExpCfg); the big one exists for int8 banks only.
+template <bool F32, int CAND = kExpCand>
 __global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
-    // dynamic LDS (kExpLdsBytes): a 512-row gather stage, the sort keys / qbest table, the
+    using C = ExpCfg<CAND>;
+    static_assert(!F32 || CAND == kExpCand, "the float32 round needs the 512-row stage buffer");
+    // dynamic LDS (C::kLdsBytes): the gather stage, the sort keys / qbest table, the
     // candidate rows, and two scratch arrays
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-    char* smem = dyn_lds;                                                         // kExpStageBytes
-    unsigned long long* keys = (unsigned long long*)(dyn_lds + kExpStageBytes);   // sort keys, then qbest
-    int* cand = (int*)(keys + kExpCand);                                          // candidate / sorted query rows
-    unsigned long long* nkey = (unsigned long long*)(cand + kExpCand);            // ratio bits of accepted matches
-    int* tix  = (int*)(nkey + kExpCand);                                          // sort scratch, then accepted list
-    int* hist = tix + kExpCand;                                                   // counting-sort buckets
+    char* smem = dyn_lds;                                                         // C::kStageBytes
+    unsigned long long* keys = (unsigned long long*)(dyn_lds + C::kStageBytes);   // sort keys, then qbest
+    int* cand = (int*)(keys + CAND);                                              // candidate / sorted query rows
+    unsigned long long* nkey = (unsigned long long*)(cand + CAND);                // ratio bits of accepted matches
+    int* tix  = (int*)(nkey + CAND);                                              // sort scratch, then accepted list
+    int* hist = tix + CAND;                                                       // counting-sort buckets
     // (nkey, tix, hist are contiguous: the float32 round's candidate list aliases them during step 3)
     __shared__ double cur[4];                         // query_pos, target_pos of the round
     __shared__ int sh_i[8];
@@ -499,7 +515,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));   // no fma: NumPy order
                         if (d2 <= r2) {
                             const int slot = atomicAdd(&sh_i[4], 1);
-                            if (slot < kExpCand) { keys[slot] = (unsigned long long)__double_as_longlong(d2); cand[slot] = qi; }
+                            if (slot < CAND) { keys[slot] = (unsigned long long)__double_as_longlong(d2); cand[slot] = qi; }
                         }
                     }
                 }
@@ -507,10 +523,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         }
         lds_barrier();
         const int nq = sh_i[4];
-        if (nq > kExpCand) { status = kExpCandFull; break; }
+        if (nq > CAND) { status = kExpCandFull; break; }
         EXP_STAMP(1);
         // sort by (d2 bits, index): non-negative doubles order like their bit patterns
-        block_sort_pairs(keys, cand, nkey, tix, hist, nq, (double)P.radius * (double)P.radius);
+        block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq, (double)P.radius * (double)P.radius);
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
@@ -521,22 +537,22 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if constexpr (F32) {
             // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
             lds_barrier();
-            const bool ok = x1_round_f32<kExpThreads>(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, kExpClistCap,
+            const bool ok = x1_round_f32<kExpThreads>(RF, cand, nq, t0, nt, smem, keys, (unsigned*)nkey, C::kClistCap,
                                          (unsigned long long*)(hist + 2 * kSortBuckets + 16), sh_rf,
                                          P.prof ? pt : nullptr, &tstamp);
             if (!ok) { status = kExpListFull; break; }
         } else {
-            x1_round_wsplit<kExpSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
+            x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
                                     (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
         }
         lds_barrier();
 
         EXP_STAMP(3);
         // ---- 4./5. accepted matches: neighbours and new results, in slot order ------------------
-        // (a) compact the accepted slots in order:  tix[k] = slot | t_local << 11,
+        // (a) compact the accepted slots in order:  tix[k] = slot | t_local << C::kSlotBits,
         //     nkey[k] = ratio bits  (k < na)
         const int ccx = center_coord(row, P.cell_w, P.width), ccy = center_coord(col, P.cell_h, P.height);
-        double* const pos4 = (double*)(smem + kExpCand * 8);          // [kExpPosCap][4] behind rk[] (stage buffer)
+        double* const pos4 = (double*)(smem + CAND * 8);              // [C::kPosCap][4] behind rk[] (stage buffer)
         int na = 0;
         for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
             const int i = s0 + tid;
@@ -563,9 +579,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
             // those reads from these writes): entries na+o <= i never clobber unread ones
             if (acc) {
-                tix[na + o] = i | (t_local << 11);
+                tix[na + o] = i | (t_local << C::kSlotBits);
                 nkey[na + o] = (unsigned long long)__double_as_longlong(ratio);
-                if (na + o < kExpPosCap) {               // (the stage buffer is free after the cross-check)
+                if (na + o < C::kPosCap) {               // (the stage buffer is free after the cross-check)
                     double* pp = pos4 + 4 * (na + o);
                     pp[0] = pq0; pp[1] = pq1; pp[2] = pt0; pp[3] = pt1;
                 }
@@ -587,10 +603,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             bool known = false;
             long long nslot = 0;
             if (live) {
-                const int slot = tix[k] & 2047, t_local = tix[k] >> 11;
+                const int slot = tix[k] & ((1 << C::kSlotBits) - 1), t_local = tix[k] >> C::kSlotBits;
                 qrow_idx = cand[slot];
                 rbits = nkey[k];
-                if (k < kExpPosCap) {                    // fetched together with the self distances in (a)
+                if (k < C::kPosCap) {                    // fetched together with the self distances in (a)
                     const double* pp = pos4 + 4 * k;
                     mqx = pp[0]; mqy = pp[1]; px = pp[2]; py = pp[3];
                 } else {
@@ -622,7 +638,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             // accepts some tens of matches; one thread per entry walking all earlier entries is a chain
             // of dependent LDS reads as long as the list.  Instead every WAVE takes entries k and its
             // lanes the earlier entries j: one pass of <= 64 comparisons per entry, flags in dupf[].
-            int* const dupf = hist;                                  // [kExpCand]: bit 0 push, bit 1 emit duplicate
+            int* const dupf = hist;                                  // bit 0 push, bit 1 emit duplicate
             {
                 const int kend = min(na, k0 + kExpThreads);
                 const int lane = tid & 63, wave = tid >> 6;
@@ -634,13 +650,13 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         de |= rk[j] == a_rk && nkey[j] == a_rb;
                     }
                     const int f = (__builtin_amdgcn_ballot_w64(dp) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(de) != 0ull ? 2 : 0);
-                    if (lane == 0) dupf[kk] = f;
+                    if (lane == 0) dupf[kk - k0] = f;
                 }
             }
             lds_barrier();
             bool push = live && nk != ~0ull, emit = live && !known;
             if (live) {
-                const int f = dupf[k];
+                const int f = dupf[k - k0];
                 if (f & 1) push = false;
                 if (f & 2) emit = false;
             }
@@ -710,20 +726,24 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 }
 
-hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, hipStream_t stream)
+hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kExpLdsBytes);
+        hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCandBig>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCandBig>::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (f32) hipLaunchKernelGGL(expand_kernel<true>, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
-    else     hipLaunchKernelGGL(expand_kernel<false>, dim3(n_pairs), dim3(kExpThreads), kExpLdsBytes, stream, (const ExpandPair*)d_pairs);
+    if (f32 && big) return hipErrorInvalidValue;
+    if (f32)      hipLaunchKernelGGL((expand_kernel<true, kExpCand>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+    else if (big) hipLaunchKernelGGL((expand_kernel<false, kExpCandBig>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCandBig>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+    else          hipLaunchKernelGGL((expand_kernel<false, kExpCand>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
     return hipGetLastError();
 }
 
 int expand_cand_cap() { return kExpCand; }
+int expand_cand_cap_big() { return kExpCandBig; }
 
 }  // namespace fm

@@ -105,8 +105,9 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
                              double* d_ratio, hipStream_t stream);
 
 // ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
-hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, hipStream_t stream);   // all pairs of one kind
+hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream);   // all pairs of one kind / capacity
 int expand_cand_cap();
+int expand_cand_cap_big();
 
 // ---- result gather over RCCL (comm.hip; RCCL is dlopen'ed on first use) -----------------------
 int comm_unique_id(void* id128, std::string* err);

@@ -110,9 +110,12 @@ def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=Fals
     results = context.expand_run(expanders, seeds, taus)
     for ex, (n_matches, n_rounds, n_pairs, status) in zip(expanders, results):
         if status != 0:
+            if stats is not None:
+                stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
             out.append(None)
             continue
         if stats is not None:
+            stats["device_loops"] = stats.get("device_loops", 0) + 1
             stats["rounds"] = stats.get("rounds", 0) + n_rounds
             stats["pairs"] = stats.get("pairs", 0) + n_pairs
         index, pos, ratio = ex.fetch(n_matches)

@@ -236,7 +236,8 @@ typedef struct fm_expand_desc {
 
 #define FM_EXPAND_OK            0
 #define FM_EXPAND_STACK_FULL    1
-#define FM_EXPAND_SUBSET_FULL   2  /* a radius subset exceeded 2048 query rows              */
+#define FM_EXPAND_SUBSET_FULL   2  /* a radius subset exceeded 4096 query rows (2048 for float32 banks):
+                                      * pairs that exceed 2048 are re-run by fm_expand_run in a larger-capacity kernel */
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
 #define FM_EXPAND_MATCH_FULL    4
 #define FM_EXPAND_TABLE_FULL    5

@@ -134,13 +134,32 @@ def test_device_loop_return_arrays_and_many_pairs(ctx):
 
 
 def test_device_loop_falls_back_when_it_cannot_run(ctx):
-    # a radius that makes the query subset exceed the device capacity (2048 rows): the device
+    # a radius that makes the query subset exceed every device capacity (4096 rows): the device
     # reports it and match() silently replays the loop on the host with identical results
     mc, fi, oq, ot = _build((400, 300), 6000, seed=77, ctx=ctx)
     stats = {}
     got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.7)
     exp = fo.o_match(oq, ot, {"radius": 200})(0.7)
     _same_matches(got, exp)
+    assert stats.get("device_fallbacks") == 1 and "device_loops" not in stats
+
+
+def test_device_loop_reruns_in_the_large_capacity_kernel(ctx):
+    """Radius subsets between 2049 and 4096 rows: the 2048-row kernel gives up, fm_expand_run runs
+    the pair again in the 4096-row variant (256-row gather steps) -- still on the device, same
+    matches as the oracle and as the host-driven loop."""
+    mc, fi, oq, ot = _build((700, 500), 9000, seed=78, ctx=ctx)
+    pos = mc.original["positions"]
+    inside = ((pos[:, 0] - 350.0) ** 2 + (pos[:, 1] - 250.0) ** 2 <= 180.0 ** 2).sum()
+    assert 2048 < inside <= 4096                     # (the interior rounds are in the big kernel's range)
+    stats, hs = {}, {}
+    got = fastmatch.match(mc, fi, {"context": ctx, "radius": 180, "stats": stats})(0.7)
+    assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats
+    host = fastmatch.match(mc, fi, {"context": ctx, "radius": 180, "stats": hs, "device_loop": False})(0.7)
+    _same_matches(got, host)
+    assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"]
+    _same_matches(got, fo.o_match(oq, ot, {"radius": 180})(0.7))
+    assert len(got) > 200
 
 
 def test_device_loop_equals_host_loop_at_config3_scale(ctx):
