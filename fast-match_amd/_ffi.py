@@ -69,6 +69,7 @@ SYMBOLS = {
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
     "fm_xcheck1_keys": (_INT, [_P, _P, _P, _I64, _P]),
+    "fm_xcheck1_keys_dev": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_knn2_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_self_dist": (_INT, [_P, _P, _P]),
     "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
@@ -327,6 +328,11 @@ class Context(object):
         keys = np.empty(q.n, dtype=np.uint64)
         self._check(self.lib.fm_xcheck1_keys(self.handle, q.handle, t.handle, int(t_offset), _ptr(keys)))
         return keys
+
+    def xcheck1_keys_dev(self, q, t, t_offset, keys_ptr):
+        """``xcheck1_keys`` into device memory: ``keys_ptr`` = device address of a uint64/int64 [nq]
+        buffer (``tensor.data_ptr()``)."""
+        self._check(self.lib.fm_xcheck1_keys_dev(self.handle, q.handle, t.handle, int(t_offset), _P(int(keys_ptr))))
 
     def match_ratio(self, q, t, tau, out=None):
         """X1 + R1 fused.  ``out`` = optional (tidx i32[nq], dist f32[nq], ratio f64[nq],

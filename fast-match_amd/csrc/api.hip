@@ -1370,7 +1370,26 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
 // (distance key << 32) | (t_offset + local train row) of the closest train row OF THIS BANK that
 // elects q, ~0 if none.  The element-wise minimum of the ranks' key arrays is the key array of
 // the unsharded call (the key carries the global index, so ties break as on one GPU).
+static int xcheck1_keys_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys, bool keys_on_device);
+
 extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys)
+{
+    return xcheck1_keys_common(ctx, q, t, t_offset, keys, false);
+}
+
+extern "C" int fm_xcheck1_keys_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* d_keys)
+{
+    if (ctx && d_keys) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_keys) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(ctx, FM_EINVAL, "fm_xcheck1_keys_dev: d_keys must be device memory");
+        }
+    }
+    return xcheck1_keys_common(ctx, q, t, t_offset, d_keys, true);
+}
+
+static int xcheck1_keys_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys, bool keys_on_device)
 {
     int rc = check_pair(ctx, q, t, "fm_xcheck1_keys");
     if (rc != FM_OK) return rc;
@@ -1408,7 +1427,8 @@ extern "C" int fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
                            (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, (unsigned)t_offset);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, d2h(ctx, keys, d_qbest, (size_t)nq * 8));
+    if (keys_on_device) HIP_TRY(ctx, hipMemcpyAsync(keys, d_qbest, (size_t)nq * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIP_TRY(ctx, d2h(ctx, keys, d_qbest, (size_t)nq * 8));
     return cs.finish();
 }
 

@@ -103,6 +103,22 @@ def reduce_keys(keys, device=None, group=None):
     return out
 
 
+def reduce_keys_device(keys_t, group=None):
+    """``reduce_keys`` on a device tensor (int64 view of the uint64 keys, as ``fm_xcheck1_keys_dev``
+    leaves them): the "none" key ~0 (= -1 signed) is mapped to int64 max on the device, ONE
+    all-reduce(min) runs on the tensor in place (RCCL), and the keys come back as uint64 NumPy."""
+    import torch
+    import torch.distributed as dist
+    big = torch.iinfo(torch.int64).max
+    keys_t.masked_fill_(keys_t == -1, big)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(keys_t, op=dist.ReduceOp.MIN, group=group)
+    out = keys_t.cpu().numpy()
+    res = out.view(np.uint64).copy()
+    res[out == big] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return res
+
+
 def decode_keys(keys, float32_route=False):
     """(tidx int32[nq] (-1 = no match), dist float32[nq] (+inf = no match)) from election keys:
     what fm_xcheck1 returns.  Integer route: dist = sqrtf(float32(d^2)), exact for d^2 < 2^24."""
@@ -121,8 +137,15 @@ def xcheck1_sharded(ctx, qbank, tbank_shard, t_offset, device=None, group=None):
     split over the ranks (this rank holds rows [t_offset, t_offset + tbank_shard.n)).
     Every rank returns the full (tidx, dist) of the unsharded fm_xcheck1, bit for bit."""
     from . import _ffi
-    keys = ctx.xcheck1_keys(qbank, tbank_shard, t_offset)
-    keys = reduce_keys(keys, device=device, group=group)
+    on_gpu = device is not None and not (isinstance(device, str) and device == "cpu")
+    if on_gpu:                                  # keys stay in HBM from the election to the collective
+        import torch
+        keys_t = torch.empty(qbank.n, dtype=torch.int64, device=device)
+        ctx.xcheck1_keys_dev(qbank, tbank_shard, t_offset, keys_t.data_ptr())
+        keys = reduce_keys_device(keys_t, group=group)
+    else:
+        keys = ctx.xcheck1_keys(qbank, tbank_shard, t_offset)
+        keys = reduce_keys(keys, device=device, group=group)
     return decode_keys(keys, float32_route=(qbank.kind == _ffi.FM_BANK_F32))
 
 

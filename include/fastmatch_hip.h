@@ -126,6 +126,9 @@ int  fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
  * (one all-reduce(min) of nq words) equals the keys of the unsharded fm_xcheck1: same
  * matches, same tie-breaks (cv::BFMatcher cross-check, fastmatch.pyx:122-123, 161-162).   */
 int  fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys);
+/* The same with the keys left in caller-supplied DEVICE memory (uint64[nq]): the operand of the
+ * all-reduce(min) over the ranks, so the keys of a shard never visit the host.                 */
+int  fm_xcheck1_keys_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* d_keys);
 
 /* ---- R1: ratio + threshold -----------------------------------------------------------
  * Replaces  ratios = m.distance / query_dis[m.queryIdx]   (fastmatch.pyx:124, 165)

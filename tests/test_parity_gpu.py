@@ -614,6 +614,26 @@ def test_train_sharded_crosscheck_keys_reduce_to_the_unsharded_result(ctx, as_f3
     # single process: the helper is the plain call
     t, d = sharding.xcheck1_sharded(ctx, qb, ctx.bank(T), 0)
     assert _eq(t, full_t) and _eq(d, full_d)
+    # the device path: keys left in HBM (fm_xcheck1_keys_dev), reduced there (torch.minimum stands in
+    # for the all-reduce of several ranks), none-keys mapped on the device
+    import torch
+    dev = torch.device("cuda", 0)
+    for world in (1, 2):
+        acc = None
+        for r in range(world):
+            lo, hi = sharding.shard_rows(T.shape[0], r, world)
+            kt = torch.empty(qb.n, dtype=torch.int64, device=dev)
+            ctx.xcheck1_keys_dev(qb, ctx.bank(T[lo:hi]), lo, kt.data_ptr())
+            assert np.array_equal(kt.cpu().numpy().view(np.uint64), ctx.xcheck1_keys(qb, ctx.bank(T[lo:hi]), lo))
+            kt.masked_fill_(kt == -1, torch.iinfo(torch.int64).max)
+            acc = kt if acc is None else torch.minimum(acc, kt)
+        acc.masked_fill_(acc == torch.iinfo(torch.int64).max, -1)
+        t, d = sharding.decode_keys(sharding.reduce_keys_device(acc), float32_route=as_f32)
+        assert _eq(t, full_t) and _eq(d, full_d)
+    t, d = sharding.xcheck1_sharded(ctx, qb, ctx.bank(T), 0, device=dev)
+    assert _eq(t, full_t) and _eq(d, full_d)
+    with pytest.raises(Exception):
+        ctx.xcheck1_keys_dev(qb, ctx.bank(T), 0, np.zeros(qb.n, np.uint64).ctypes.data)      # host memory
     lo, hi = sharding.shard_rows(700, 0, 1)
     i2, d2 = sharding.knn2_sharded(ctx, qb, ctx.bank(T), 700)
     oi, od = ctx.knn2(qb, ctx.bank(T))
