@@ -781,6 +781,9 @@ struct CallScope {
     {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_call1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // (async calls still in flight finish on the tail stream: a synchronous call completes them too,
+        // as the header promises; they are accounted at the next fm_sync / fm_get_stats)
+        if (!ctx->pending.empty()) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
         for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
         ctx->staged.clear();
         ctx->h_stage_used = 0;

@@ -298,3 +298,20 @@ def test_rccl_gather_follows_the_async_fill_one_rank():
     finally:
         c.comm_destroy()
     c.close()
+
+
+def test_a_synchronous_call_completes_the_async_calls_before_it(ctx):
+    """include/fastmatch_hip.h: async results are valid after fm_sync OR any synchronous call."""
+    pairs = [_banks(ctx, 5000, 4200, seed=70 + k) for k in range(3)]
+    outs = [(ctx.pinned_empty(5000, np.int32), ctx.pinned_empty(5000, np.int32),
+             ctx.pinned_empty(5000, np.float32), ctx.pinned_empty(5000, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    for (Q, T, qb, tb), out, cnt in zip(pairs, outs, counts):
+        cnt[0] = -1
+        ctx.match_accepted_async(qb, tb, 0.7, out, cnt)
+    ref0 = ctx.match_accepted(pairs[0][2], pairs[0][3], 0.7)          # synchronous: no fm_sync in between
+    got = [(int(c[0]), o[0][:int(c[0])].copy(), o[1][:int(c[0])].copy()) for o, c in zip(outs, counts)]
+    for (Q, T, qb, tb), (m, qa, ta) in zip(pairs, got):
+        rq, rt, _, _ = ctx.match_accepted(qb, tb, 0.7)
+        assert m == len(rq) > 50 and np.array_equal(qa, rq) and np.array_equal(ta, rt)
+    ctx.sync()
