@@ -255,6 +255,8 @@ def main():
     outbuf = outbufs[0]
     use_async = world == 1 and os.environ.get("FM_BENCH_SYNC") != "1"
     dev_async = world > 1 and os.environ.get("FM_BENCH_SYNC") != "1"
+    use_batch = use_async and os.environ.get("FM_BENCH_BATCH", "1") != "0"
+    batch_args = ctx.prepare_batch(banks, outbufs, counts) if use_batch else None
 
     # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
@@ -278,8 +280,11 @@ def main():
     def step():
         n_acc = 0
         if use_async:
-            for j, (qb, tb) in enumerate(banks):
-                ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
+            if use_batch:                                   # pairs of one shape share distance-kernel launches
+                ctx.match_accepted_batch(batch_args, TAU)
+            else:
+                for j, (qb, tb) in enumerate(banks):
+                    ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
             ctx.sync()                                      # results of the whole batch are on the host now
             return int(sum(int(c[0]) for c in counts))
         if dev_async and (abi_gather is not None or device_gather):
@@ -408,7 +413,10 @@ def main():
     if rank == 0:
         pairs_per_step = float(NQ) * NT * PAIRS_PER_STEP
         value = world * pairs_per_step * args.steps / elapsed
-        k_ms = st["kernel_ms"] / max(st["kernel_launches"], 1)
+        # time of the distance kernel per image pair: a launch may hold several pairs (fm_match_accepted_batch)
+        timed_image_pairs = st["pairs"] / (float(NQ) * NT)
+        k_ms = st["kernel_ms"] / max(timed_image_pairs, 1e-9)
+        pairs_per_launch = timed_image_pairs / max(st["kernel_launches"], 1)
         call_ms = st["total_ms"] / max(st["calls"], 1)
         achieved = float(NQ) * NT * OPS_PER_PAIR / (k_ms * 1e-3) / 1e12
         # HBM bytes per K1 launch come from the committed rocprofv3 PMC passes (not live): they are
@@ -453,15 +461,17 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_tag": traffic_tag, "traffic_note": traffic_note,
-                         "kernel": "fm::rowreduce_kernel<4,1,true,8> (v_mfma_i32_16x16x64_i8)", "kernel_ms": k_ms,
+                         "kernel": ("fm::rowreduce_batch_kernel<4,1,8,3,1>" if use_batch else "fm::rowreduce_kernel<4,1,true,8,3,1>")
+                                   + " (v_mfma_i32_16x16x64_i8)",
+                         "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms * pairs_per_launch,
+                         "image_pairs_per_launch": pairs_per_launch,
                          "kernel_launches_timed": st["kernel_launches"],
-                         "hbm_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "hbm_frac_of_8tbps": (traffic / (k_ms * 1e-3) / 8e12) if traffic else None,
+                         "hbm_gbps": (traffic / (k_ms * pairs_per_launch * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac_of_8tbps": (traffic / (k_ms * pairs_per_launch * 1e-3) / 8e12) if traffic else None,
                          "mfma_pipe_busy_frac": busy,
-                         "kernel_launches_in_region": args.steps * PAIRS_PER_STEP,
-                         "note": "int8 ops: 256 per descriptor pair x 1e10 pairs per launch; kernel_ms = mean HIP-event time of the "
-                                 "K1 launches of the timed region that carry an event pair (every 4th async call: each event "
-                                 "record is a packet the next K1 queues behind), events on the library's own stream; hbm_gbps = PMC HBM bytes "
+                         "note": "int8 ops: 256 per descriptor pair x 1e10 descriptor pairs per image pair x image_pairs_per_launch; "
+                                 "kernel_ms = HIP-event time of the distance-kernel launches of the timed region (events on the "
+                                 "library's own stream) per image pair, kernel_ms_per_launch = per launch; traffic / hbm_gbps = PMC HBM bytes "
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
                                  "cycles of the launch (profiles/)"},
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,

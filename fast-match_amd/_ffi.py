@@ -77,6 +77,7 @@ SYMBOLS = {
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
+    "fm_match_accepted_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_dev_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
@@ -393,6 +394,34 @@ class Context(object):
         qidx, tidx, dist, ratio = out
         self._check(self.lib.fm_match_accepted_async(self.handle, q.handle, t.handle, float(tau), cap, _ptr(qidx),
                                                      _ptr(tidx), _ptr(dist), _ptr(ratio), _ptr(count)))
+
+    def prepare_batch(self, pairs, outs, counts):
+        """Argument block of ``match_accepted_batch`` for a fixed list of (query bank, train bank) pairs
+        and their output buffers, built once (the per-call cost of a batch sits in front of its first
+        launch): ``outs[i]`` = (qidx, tidx, dist, ratio), ``counts[i]`` = int64[1], all ``pinned_empty``."""
+        n = len(pairs)
+        if len(outs) != n or len(counts) != n:
+            raise ValueError("pairs, outs and counts must have the same length")
+        cap = None
+        for out, cnt in zip(outs, counts):
+            c = self._check_accepted_out(out)
+            cap = c if cap is None else min(cap, c)
+            if not isinstance(cnt, np.ndarray) or cnt.dtype != np.int64 or cnt.size < 1:
+                raise ValueError("count must be an int64 array (pinned_empty(1, np.int64))")
+        arr = lambda vals: (_P * n)(*[_P(int(v)) if v is not None else None for v in vals])
+        args = (n, arr([q.handle.value for q, _ in pairs]), arr([t.handle.value for _, t in pairs]), int(cap or 0),
+                arr([_ptr(o[0]) for o in outs]), arr([_ptr(o[1]) for o in outs]), arr([_ptr(o[2]) for o in outs]),
+                arr([_ptr(o[3]) for o in outs]), arr([_ptr(c) for c in counts]))
+        return {"args": args, "keep": (list(pairs), list(outs), list(counts))}     # (keeps banks and buffers alive)
+
+    def match_accepted_batch(self, pairs, tau, outs=None, counts=None):
+        """``match_accepted_async`` for a list of (query bank, train bank) pairs in ONE call: pairs of
+        one shape share distance-kernel launches (up to eight per launch).  Either the lists
+        (``outs[i]`` = (qidx, tidx, dist, ratio), ``counts[i]`` = int64[1], all from ``pinned_empty``) or
+        the block ``prepare_batch`` built from them; results are valid after ``sync()``."""
+        batch = pairs if isinstance(pairs, dict) else self.prepare_batch(pairs, outs, counts)
+        n, qh, th, cap, a0, a1, a2, a3, ac = batch["args"]
+        self._check(self.lib.fm_match_accepted_batch(self.handle, n, qh, th, float(tau), cap, a0, a1, a2, a3, ac))
 
     def match_accepted_dev(self, q, t, tau, rows_ptr, count_ptr, cap):
         """X1 + R1 with the accepted matches left on the device: ``rows_ptr`` = device address of

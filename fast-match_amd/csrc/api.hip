@@ -14,6 +14,7 @@
 #include <string.h>
 #include <mutex>
 #include <vector>
+#include <map>
 
 using namespace fm;
 
@@ -54,7 +55,9 @@ struct fm_ctx {
     // K1 (election, decode + ratio, compaction) run on `stream_tail` and overlap the NEXT call's K1.
     // Two workspace slots alternate; a slot's tail kernels leave its bound[] and qbest[] arrays in
     // the state the next K1 / election expects, so no fill operations sit between two K1 launches.
-    hipStream_t stream_tail = nullptr;
+    hipStream_t stream_tail = nullptr;      // = tails[0]
+    static constexpr int kTails = 3;
+    hipStream_t tails[kTails] = {nullptr, nullptr, nullptr};   // fm_match_accepted_batch spreads the pairs' tails over these
     hipStream_t rows_stream = nullptr;      // stream that produced the last device-resident rows (fm_gather_matches follows it)
     hipEvent_t ev_consumer = nullptr;
     struct AsyncSlot {
@@ -64,6 +67,7 @@ struct fm_ctx {
         bool in_use = false;
     } aslot[2];
     int aslot_next = 0;
+    std::vector<AsyncSlot> bslot;           // fm_match_accepted_batch: one per position in the call
     void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
     int   comm_ranks = 0;
     fm_stats stats{};
@@ -550,7 +554,10 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
         // queue behind the thousands of workgroups of the K1 they overlap
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
-        if ((e = hipStreamCreateWithPriority(&ctx->stream_tail, hipStreamNonBlocking, greatest)) != hipSuccess ||
+        if ((e = hipStreamCreateWithPriority(&ctx->tails[0], hipStreamNonBlocking, greatest)) != hipSuccess ||
+            (e = hipStreamCreateWithPriority(&ctx->tails[1], hipStreamNonBlocking, greatest)) != hipSuccess ||
+            (e = hipStreamCreateWithPriority(&ctx->tails[2], hipStreamNonBlocking, greatest)) != hipSuccess ||
+            ((ctx->stream_tail = ctx->tails[0]), false) ||
             (e = hipEventCreateWithFlags(&ctx->aslot[0].tail_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->aslot[1].tail_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->ev_consumer, hipEventDisableTiming)) != hipSuccess ||
@@ -581,14 +588,16 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     if (!ctx) return FM_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream_tail) (void)hipStreamSynchronize(ctx->stream_tail);
-    for (auto& sl : ctx->aslot) {
+    for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamSynchronize(ts);
+    auto free_slot = [](fm_ctx::AsyncSlot& sl) {
         if (sl.ws) (void)hipFree(sl.ws);
         if (sl.tail_done) (void)hipEventDestroy(sl.tail_done);
         if (sl.k_done) (void)hipEventDestroy(sl.k_done);
-    }
+    };
+    for (auto& sl : ctx->aslot) free_slot(sl);
+    for (auto& sl : ctx->bslot) free_slot(sl);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
-    if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
+    for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamDestroy(ts);
     if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
     for (auto* v : {&ctx->pending, &ctx->timer_pool})
         for (auto& t : *v) { (void)hipEventDestroy(t.c0); (void)hipEventDestroy(t.c1); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
@@ -634,7 +643,7 @@ extern "C" int fm_sync(fm_ctx* ctx)
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_sync: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
+    for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamSynchronize(ts));
     return drain_pending(ctx);
 }
 
@@ -644,7 +653,7 @@ extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)
     if (!ctx->pending.empty()) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
+        for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamSynchronize(ts));
         drain_pending(ctx);
     }
     *out = ctx->stats;
@@ -681,12 +690,25 @@ extern "C" int fm_device_name(fm_ctx* ctx, char* buf, int buflen)
     return FM_OK;
 }
 
+// Page-locked allocations made through fm_host_alloc, with their device-side aliases: the async entry
+// points look up to fifty output pointers per call, and a runtime query per pointer (microseconds each)
+// would sit in front of the first launch of a batch.
+struct PinnedRange { size_t bytes; char* dev; };
+static std::mutex g_pinned_mu;
+static std::map<uintptr_t, PinnedRange> g_pinned;
+
 extern "C" int fm_host_alloc(fm_ctx* ctx, int64_t bytes, void** out)
 {
     if (!ctx || !out || bytes < 0) return fail(ctx, FM_EINVAL, "fm_host_alloc: bad argument");
     *out = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipHostMalloc(out, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+    const size_t sz = (size_t)(bytes > 0 ? bytes : 1);
+    HIP_TRY(ctx, hipHostMalloc(out, sz, hipHostMallocDefault));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, *out, 0) == hipSuccess && dev) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        g_pinned[(uintptr_t)*out] = PinnedRange{sz, (char*)dev};
+    } else (void)hipGetLastError();
     return FM_OK;
 }
 
@@ -694,6 +716,7 @@ extern "C" int fm_host_free(fm_ctx* ctx, void* p)
 {
     if (!p) return FM_OK;
     if (ctx) (void)hipSetDevice(ctx->device);
+    { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned.erase((uintptr_t)p); }
     hipError_t e = hipHostFree(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, FM_EDEVICE, std::string("fm_host_free: ") + hipGetErrorString(e)); }
     return FM_OK;
@@ -704,6 +727,15 @@ extern "C" int fm_host_free(fm_ctx* ctx, void* p)
 static void* pinned_device_alias(const void* host)
 {
     if (!host) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        auto it = g_pinned.upper_bound((uintptr_t)host);
+        if (it != g_pinned.begin()) {
+            --it;
+            const size_t off = (uintptr_t)host - it->first;
+            if (off < it->second.bytes) return it->second.dev + off;
+        }
+    }
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (at.type != hipMemoryTypeHost) return nullptr;
@@ -783,7 +815,7 @@ struct CallScope {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         // (async calls still in flight finish on the tail stream: a synchronous call completes them too,
         // as the header promises; they are accounted at the next fm_sync / fm_get_stats)
-        if (!ctx->pending.empty()) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
+        if (!ctx->pending.empty()) for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamSynchronize(ts));
         for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
         ctx->staged.clear();
         ctx->h_stage_used = 0;
@@ -1131,6 +1163,104 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 // ---------------------------------------------------------------------------------------
 // X1 (+R1) entry points
 // ---------------------------------------------------------------------------------------
+// Workspace of one bank pair in flight (async calls): partial | bound | qbest | tidx | dist | ratio | pass | block counts
+struct SlotLayout {
+    size_t pbytes, a_qbest, a_tidx, a_dist, a_ratio, a_pass, a_bc, a_end;
+    int nblk;
+};
+
+static SlotLayout slot_layout(int64_t nq, const RowReducePlan& pl)
+{
+    SlotLayout L;
+    L.nblk = (int)((nq + 255) / 256);
+    L.pbytes = (pl.partial_bytes(1) + 15) & ~(size_t)15;
+    const size_t bbytes = ((size_t)pl.ncols_alloc * 4 + 15) & ~(size_t)15;
+    L.a_qbest = L.pbytes + bbytes; L.a_tidx = L.a_qbest + (size_t)nq * 8; L.a_dist = L.a_tidx + (size_t)nq * 4;
+    L.a_ratio = (L.a_dist + (size_t)nq * 4 + 7) & ~(size_t)7; L.a_pass = L.a_ratio + (size_t)nq * 8;
+    L.a_bc = (L.a_pass + (size_t)nq + 15) & ~(size_t)15; L.a_end = L.a_bc + (size_t)L.nblk * 4 + 16;
+    return L;
+}
+
+// Make the slot ready for a K1 on stream ks: wait for the slot's previous tail (it reads partial /
+// qbest and re-arms bound), (re)allocate and initialise the arrays when the shape changed.
+static int slot_prepare(fm_ctx* ctx, fm_ctx::AsyncSlot& sl, const SlotLayout& L, int64_t nq, const RowReducePlan& pl, hipStream_t ks)
+{
+    if (sl.in_use) HIP_TRY(ctx, hipStreamWaitEvent(ks, sl.tail_done, 0));
+    if (L.a_end > sl.bytes || sl.nq != nq || sl.ncols_alloc != pl.ncols_alloc || sl.partial_bytes != (int64_t)L.pbytes) {
+        if (sl.in_use) HIP_TRY(ctx, hipEventSynchronize(sl.tail_done));
+        if (L.a_end > sl.bytes) {
+            if (sl.ws) { HIP_TRY(ctx, hipFree(sl.ws)); sl.ws = nullptr; sl.bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&sl.ws, L.a_end + L.a_end / 4));
+            sl.bytes = L.a_end + L.a_end / 4;
+        }
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)((char*)sl.ws + L.pbytes), (int)0x80000000, (size_t)pl.ncols_alloc, ks));
+        HIP_TRY(ctx, hipMemsetAsync((char*)sl.ws + L.a_qbest, 0xff, (size_t)nq * 8, ks));
+        sl.nq = nq; sl.ncols_alloc = pl.ncols_alloc; sl.partial_bytes = (int64_t)L.pbytes;
+    }
+    return FM_OK;
+}
+
+static int take_timer(fm_ctx* ctx, fm_ctx::PendingTimer* tm)
+{
+    if (!ctx->timer_pool.empty()) { *tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back(); return FM_OK; }
+    if (ctx->pending.size() >= 1024) {                 // bound the number of live events
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (hipStream_t ts : ctx->tails) if (ts) HIP_TRY(ctx, hipStreamSynchronize(ts));
+        drain_pending(ctx);
+        *tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back();
+        return FM_OK;
+    }
+    HIP_TRY(ctx, hipEventCreate(&tm->c0)); HIP_TRY(ctx, hipEventCreate(&tm->c1));
+    HIP_TRY(ctx, hipEventCreate(&tm->k0)); HIP_TRY(ctx, hipEventCreate(&tm->k1));
+    return FM_OK;
+}
+
+// The small kernels behind a K1 (election, decode + ratio test, ordered compaction), on stream ts,
+// which must already wait for that K1.  Host outputs (a_* = device aliases of page-locked memory) or,
+// with dev_rows, the 12-byte rows of the result gather.  Leaves the slot's bound[] / qbest[] clean.
+static int enqueue_tail(fm_ctx* ctx, hipStream_t ts, fm_ctx::AsyncSlot& sl, const SlotLayout& L, const fm_bank* q,
+                        int64_t nq, int64_t nt, const RowReducePlan& pl, double tau, int64_t compact_cap,
+                        void* a_q, void* a_t, void* a_d, void* a_r, void* a_c,
+                        int32_t* dev_rows, long long* dev_count, hipStream_t consumer)
+{
+    char* sb = (char*)sl.ws;
+    unsigned long long* s_partial = (unsigned long long*)sb;
+    int* s_bound = (int*)(sb + L.pbytes);
+    unsigned long long* s_qbest = (unsigned long long*)(sb + L.a_qbest);
+    int32_t* s_tidx = (int32_t*)(sb + L.a_tidx);
+    float* s_dist = (float*)(sb + L.a_dist);
+    double* s_ratio = (double*)(sb + L.a_ratio);
+    uint8_t* s_pass = (uint8_t*)(sb + L.a_pass);
+    int* s_bc = (int*)(sb + L.a_bc);
+    if (nt > 0) {
+        const int64_t sthreads = nt * 4 > (int64_t)pl.ncols_alloc ? nt * 4 : (int64_t)pl.ncols_alloc;
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ts,
+                           (const unsigned long long*)s_partial, pl.nsplit, pl.ncols_alloc, nt, s_qbest, 0u, s_bound);
+    }
+    hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ts,
+                       (const unsigned long long*)s_qbest, nq, (const double*)q->selfdist, tau, s_tidx, s_dist, s_ratio,
+                       s_pass, (unsigned long long*)nullptr, 0, s_bc, s_qbest);
+    if (dev_rows) {
+        // the rows go to the caller's device buffers, which a consumer stream (the result gather)
+        // reads: the compaction waits for what that stream has been given so far (the gather that
+        // last read these buffers), and the stream waits for the compaction
+        if (consumer) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
+            HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_consumer, 0));
+        }
+        hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)L.nblk), dim3(256), 0, ts,
+                           (const int32_t*)s_tidx, (const float*)s_dist, (const uint8_t*)s_pass,
+                           (const int*)s_bc, nq, compact_cap, dev_rows, dev_count, (unsigned long long*)a_c);
+    } else {
+        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)L.nblk), dim3(256), 0, ts,
+                           (const int32_t*)s_tidx, (const float*)s_dist, (const double*)s_ratio, (const uint8_t*)s_pass,
+                           (const int*)s_bc, nq, compact_cap < nq ? compact_cap : nq, (int32_t*)a_q, (int32_t*)a_t,
+                           (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return FM_OK;
+}
+
 static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool with_ratio, double tau,
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
                          const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr,
@@ -1186,91 +1316,31 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         if (to_device ? (n_pass && !a_c) : (!a_q || !a_t || !a_d || !a_r || !a_c))
             return fail(ctx, FM_EINVAL, std::string(who) + ": host outputs must be page-locked (fm_host_alloc)");
         fm_ctx::PendingTimer tm;
-        if (!ctx->timer_pool.empty()) { tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back(); }
-        else {
-            if (ctx->pending.size() >= 1024) {                 // bound the number of live events
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_tail));
-                drain_pending(ctx);
-                tm = ctx->timer_pool.back(); ctx->timer_pool.pop_back();
-            } else {
-                HIP_TRY(ctx, hipEventCreate(&tm.c0)); HIP_TRY(ctx, hipEventCreate(&tm.c1));
-                HIP_TRY(ctx, hipEventCreate(&tm.k0)); HIP_TRY(ctx, hipEventCreate(&tm.k1));
-            }
-        }
+        if ((rc = take_timer(ctx, &tm)) != FM_OK) return rc;
         tm.timed = nt > 0;
         tm.pairs = nq * nt;
-        // workspace slot: partial | bound | qbest | tidx | dist | ratio | pass | block counts
         fm_ctx::AsyncSlot& sl = ctx->aslot[ctx->aslot_next];
         ctx->aslot_next ^= 1;
-        const size_t pbytes = (pl.partial_bytes(1) + 15) & ~(size_t)15;
-        const size_t bbytes = ((size_t)pl.ncols_alloc * 4 + 15) & ~(size_t)15;
-        const size_t a_qbest = pbytes + bbytes, a_tidx = a_qbest + (size_t)nq * 8, a_dist = a_tidx + (size_t)nq * 4;
-        const size_t a_ratio = (a_dist + (size_t)nq * 4 + 7) & ~(size_t)7, a_pass = a_ratio + (size_t)nq * 8;
-        const size_t a_bc = (a_pass + (size_t)nq + 15) & ~(size_t)15, a_end = a_bc + (size_t)nblk * 4 + 16;
-        if (sl.in_use)       // the slot's previous tail reads partial / qbest and re-arms bound: K1 must not start before
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, sl.tail_done, 0));
-        if (a_end > sl.bytes || sl.nq != nq || sl.ncols_alloc != pl.ncols_alloc || sl.partial_bytes != (int64_t)pbytes) {
-            if (sl.in_use) HIP_TRY(ctx, hipEventSynchronize(sl.tail_done));
-            if (a_end > sl.bytes) {
-                if (sl.ws) { HIP_TRY(ctx, hipFree(sl.ws)); sl.ws = nullptr; sl.bytes = 0; }
-                HIP_TRY(ctx, hipMalloc(&sl.ws, a_end + a_end / 4));
-                sl.bytes = a_end + a_end / 4;
-            }
-            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)((char*)sl.ws + pbytes), (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync((char*)sl.ws + a_qbest, 0xff, (size_t)nq * 8, ctx->stream));
-            sl.nq = nq; sl.ncols_alloc = pl.ncols_alloc; sl.partial_bytes = (int64_t)pbytes;
-        }
-        char* sb = (char*)sl.ws;
-        unsigned long long* s_partial = (unsigned long long*)sb;
-        int* s_bound = (int*)(sb + pbytes);
-        unsigned long long* s_qbest = (unsigned long long*)(sb + a_qbest);
-        int32_t* s_tidx = (int32_t*)(sb + a_tidx);
-        float* s_dist = (float*)(sb + a_dist);
-        double* s_ratio = (double*)(sb + a_ratio);
-        uint8_t* s_pass = (uint8_t*)(sb + a_pass);
-        int* s_bc = (int*)(sb + a_bc);
+        const SlotLayout L = slot_layout(nq, pl);
+        if ((rc = slot_prepare(ctx, sl, L, nq, pl, ctx->stream)) != FM_OK) return rc;
         const bool coop = ctx->use_coop && pl.nsplit > 1;
         // Every event record is a packet the K1 launches of consecutive calls queue behind; the
         // start-of-kernel event is therefore taken for every async_time_every-th call only (those
-        // calls are the ones fm_get_stats accounts as timed K1 launches; FM_ASYNC_TIME_EVERY, default 1).
+        // calls are the ones fm_get_stats accounts as timed K1 launches; FM_ASYNC_TIME_EVERY, default 4).
         static const int time_every = [] { const char* e = getenv("FM_ASYNC_TIME_EVERY"); return e ? atoi(e) : 4; }();
         const bool timed_call = time_every > 0 && (ctx->async_calls++ % time_every) == 0;
         tm.timed = tm.timed && timed_call;
         tm.call_timed = timed_call;
         if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
         if (nt > 0)
-            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, s_partial, coop ? s_bound : nullptr, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)sl.ws, coop ? (int*)((char*)sl.ws + L.pbytes) : nullptr,
+                                          ctx->use_glds, ctx->stream));
         // (untimed calls hand over through the slot's own event, created without timing)
         hipEvent_t handover = timed_call ? tm.k1 : sl.k_done;
         HIP_TRY(ctx, hipEventRecord(handover, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, handover, 0));
-        if (nt > 0) {
-            const int64_t sthreads = nt * 4 > (int64_t)pl.ncols_alloc ? nt * 4 : (int64_t)pl.ncols_alloc;
-            hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ctx->stream_tail,
-                               (const unsigned long long*)s_partial, pl.nsplit, pl.ncols_alloc, nt, s_qbest, 0u, s_bound);
-        }
-        hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream_tail,
-                           (const unsigned long long*)s_qbest, nq, (const double*)q->selfdist, tau, s_tidx, s_dist, s_ratio,
-                           s_pass, (unsigned long long*)nullptr, f32, s_bc, s_qbest);
-        if (to_device) {
-            // the rows go to the caller's device buffers, which a consumer stream (the result gather)
-            // reads: the compaction waits for what that stream has been given so far (the gather that
-            // last read these buffers), and the stream waits for the compaction
-            if (consumer) {
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, ctx->ev_consumer, 0));
-            }
-            hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream_tail,
-                               (const int32_t*)s_tidx, (const float*)s_dist, (const uint8_t*)s_pass,
-                               (const int*)s_bc, nq, compact_cap, dev_rows, dev_count, (unsigned long long*)a_c);
-        } else {
-            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream_tail,
-                               (const int32_t*)s_tidx, (const float*)s_dist, (const double*)s_ratio, (const uint8_t*)s_pass,
-                               (const int*)s_bc, nq, compact_cap < nq ? compact_cap : nq, (int32_t*)a_q, (int32_t*)a_t,
-                               (float*)a_d, (double*)a_r, (unsigned long long*)a_c);
-        }
-        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = enqueue_tail(ctx, ctx->stream_tail, sl, L, q, nq, nt, pl, tau, compact_cap, a_q, a_t, a_d, a_r, a_c,
+                               to_device ? dev_rows : nullptr, dev_count, consumer)) != FM_OK) return rc;
         if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream_tail));
         HIP_TRY(ctx, hipEventRecord(sl.tail_done, ctx->stream_tail));
         if (to_device && consumer) HIP_TRY(ctx, hipStreamWaitEvent(consumer, sl.tail_done, 0));
@@ -1461,6 +1531,101 @@ extern "C" int fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_b
     if (q && q->n == 0) { *n_accepted = 0; }
     return xcheck_common(ctx, q, t, true, tau, tidx, dist, ratio, nullptr, n_accepted, "fm_match_accepted_async", cap, qidx,
                          nullptr, nullptr, true);
+}
+
+// n image pairs in one call, enqueued like fm_match_accepted_async; runs of consecutive pairs of one
+// shape go through K1 TOGETHER (rowreduce_batch_kernel: up to FM_BATCH_GROUP = 8 pairs per launch), each
+// pair's small kernels follow on one of three tail streams beside the next group's K1.
+extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                                       int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
+                                       double* const* ratio, int64_t* const* n_accepted)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_batch: ctx is NULL");
+    if (n < 0 || cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n < 0 or cap < 0");
+    if (n == 0) return FM_OK;
+    if (!q || !t || !qidx || !tidx || !dist || !ratio || !n_accepted) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
+    int rc;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check_pair(ctx, q[i], t[i], "fm_match_accepted_batch")) != FM_OK) return rc;
+        if (!n_accepted[i]) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n_accepted is NULL");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    static const int group_max = [] { const char* e = getenv("FM_BATCH_GROUP"); int v = e ? atoi(e) : kRRBatchMax;
+                                      return v < 1 ? 1 : (v > kRRBatchMax ? kRRBatchMax : v); }();
+    auto batchable = [&](int i) {
+        return q[i]->kind != FM_BANK_F32 && q[i]->n > 0 && t[i]->n > 0 && q[i]->selfdist != nullptr;
+    };
+    if ((int)ctx->bslot.size() < n) ctx->bslot.resize((size_t)n);
+    refresh_tuning(ctx);
+    int i = 0;
+    while (i < n) {
+        // run of same-shape pairs from i on, then this launch's share of it: a launch's small kernels overlap
+        // the NEXT launch, so only the last launch's are exposed -- the run ends with a short launch (2 pairs)
+        int run = 1;
+        if (batchable(i))
+            while (i + run < n && batchable(i + run) && q[i + run]->n_pad == q[i]->n_pad && t[i + run]->n_pad == t[i]->n_pad) ++run;
+        int g = run;
+        if (run > group_max + 2) g = group_max;
+        else if (run > 4) g = run - 2 < group_max ? run - 2 : group_max;
+        if (g > group_max) g = group_max;
+        RowReducePlan pl;
+        if (g > 1) {
+            pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
+            const char* nb = getenv("FM_NBUF");
+            if (pl.nb != 4 || pl.nw != 8 || !ctx->use_glds || (nb && atoi(nb) == 2)) g = 1;     // shapes the batched kernel is not built for
+        }
+        if (g == 1) {                  // an odd pair: the single-pair async call (which also reports its errors)
+            if (q[i]->n == 0) *n_accepted[i] = 0;
+            rc = xcheck_common(ctx, q[i], t[i], true, tau, tidx[i], dist[i], ratio[i], nullptr, n_accepted[i],
+                               "fm_match_accepted_batch", cap, qidx[i], nullptr, nullptr, true);
+            if (rc != FM_OK) return rc;
+            ++i;
+            continue;
+        }
+        const bool coop = ctx->use_coop && pl.nsplit > 1;
+        void* al[kRRBatchMax][5];
+        SlotLayout L[kRRBatchMax];
+        const Bank* cols[kRRBatchMax]; const Bank* red[kRRBatchMax];
+        unsigned long long* part[kRRBatchMax]; int* bnd[kRRBatchMax];
+        fm_ctx::PendingTimer tm;
+        if ((rc = take_timer(ctx, &tm)) != FM_OK) return rc;
+        tm.timed = true; tm.call_timed = true; tm.pairs = 0;
+        for (int j = 0; j < g; ++j) {
+            const int k = i + j;
+            al[j][0] = pinned_device_alias(qidx[k]); al[j][1] = pinned_device_alias(tidx[k]);
+            al[j][2] = pinned_device_alias(dist[k]); al[j][3] = pinned_device_alias(ratio[k]);
+            al[j][4] = pinned_device_alias(n_accepted[k]);
+            for (int u = 0; u < 5; ++u)
+                if (!al[j][u]) { ctx->timer_pool.push_back(tm); return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: host outputs must be page-locked (fm_host_alloc)"); }
+            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
+            if (!sl.tail_done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming));
+            L[j] = slot_layout(q[k]->n, pl);
+            if ((rc = slot_prepare(ctx, sl, L[j], q[k]->n, pl, ctx->stream)) != FM_OK) { ctx->timer_pool.push_back(tm); return rc; }
+            cols[j] = t[k]; red[j] = q[k];            // reverse NN: output rows = train rows, reduced over the query rows
+            part[j] = (unsigned long long*)sl.ws;
+            bnd[j] = coop ? (int*)((char*)sl.ws + L[j].pbytes) : nullptr;
+            tm.pairs += q[k]->n * t[k]->n;
+            *n_accepted[k] = 0;
+        }
+        HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce_batch(g, cols, red, pl, part, bnd, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(tm.k1, ctx->stream));
+        for (int j = 0; j < g; ++j) {
+            const int k = i + j;
+            hipStream_t ts = ctx->tails[j % fm_ctx::kTails];
+            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
+            HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
+            if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
+                                   al[j][4], nullptr, nullptr, nullptr)) != FM_OK) return rc;
+            HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));
+            sl.in_use = true;
+            if (j == g - 1) HIP_TRY(ctx, hipEventRecord(tm.c1, ts));
+        }
+        ctx->rows_stream = ctx->stream;
+        ctx->pending.push_back(tm);
+        i += g;
+    }
+    return FM_OK;
 }
 
 extern "C" int fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,

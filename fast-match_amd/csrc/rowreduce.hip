@@ -100,12 +100,12 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 // NBUF = LDS stage buffers: 2 = the stage consumed next is the one prefetched last (its LDS-DMA is
 // waited for with vmcnt(0) at every stage hand-over); 3 = prefetch two stages ahead, so the
 // hand-over only waits for a DMA issued a whole stage earlier and the newest one stays in flight.
-template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2, int PRIO = 0>
-__global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
-void rowreduce_kernel(RRParams p)
+// bid = index of the workgroup inside ITS launch of one bank pair (rowreduce_kernel: blockIdx.x;
+// rowreduce_batch_kernel: blockIdx.x modulo the workgroups of a pair).
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF, int PRIO>
+__device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid, char* smem)
 {
     static_assert(NBUF == 2 || (NBUF == 3 && GLDS), "three stage buffers need the LDS-DMA path");
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -116,8 +116,8 @@ void rowreduce_kernel(RRParams p)
     // the first few slices, so the bounds it publishes serve all later workgroups (which
     // reduce other slices for the same output rows) from their first tile on.  Concurrent
     // workgroups then sweep the same slice, which every XCD serves from its own L2.
-    const int chunk = blockIdx.x % p.nchunks;
-    const int split = blockIdx.x / p.nchunks;
+    const int chunk = bid % p.nchunks;
+    const int split = bid / p.nchunks;
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
     // Stationary operand: this wave's NC x 16 output rows, two 64-byte K-halves each.
@@ -363,6 +363,34 @@ void rowreduce_kernel(RRParams p)
     }
 }
 
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2, int PRIO = 0>
+__global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
+void rowreduce_kernel(RRParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
+    rowreduce_body<NC, KTOP, GLDS, NW, NBUF, PRIO>(p, (int)blockIdx.x, smem);
+}
+
+// Several bank pairs of ONE shape in one launch, pair after pair in block order: when the workgroups of
+// pair i run out, the CUs they leave take workgroups of pair i + 1 at once -- between two separate
+// launches the chip drains (the last of five rounds of workgroups finish at different times) and a
+// launch gap follows, together ~4 % of a 100k x 100k launch.
+struct RRBatch {
+    RRParams p[kRRBatchMax];
+    int      n;
+    int      blocks_per_pair;
+};
+
+template <int NC, int KTOP, int NW, int NBUF, int PRIO>
+__global__ __launch_bounds__(64 * NW, 4)
+void rowreduce_batch_kernel(RRBatch b)
+{
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
+    const int pair = (int)blockIdx.x / b.blocks_per_pair;
+    const RRParams p = b.p[pair];
+    rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+}
+
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw)
 {
     RowReducePlan pl;
@@ -442,10 +470,9 @@ static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool gld
     return launch_t<4, KTOP, 4>(p, grid, glds, stream);
 }
 
-hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                            unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream)
+static void fill_params(RRParams& p, const Bank& cols, const Bank& red, const RowReducePlan& plan,
+                        unsigned long long* partial, int* bound)
 {
-    RRParams p;
     p.bound = (plan.nsplit > 1) ? bound : nullptr;
     p.col_rows = cols.rows8;
     p.col_norm = cols.norm;
@@ -459,6 +486,27 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
     p.stages_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
+}
+
+// Top-1 row-reduce of n <= kRRBatchMax bank pairs that share `plan` (same padded sizes) in one launch.
+hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
+                                  unsigned long long* const* partial, int* const* bound, hipStream_t stream)
+{
+    if (n < 1 || n > kRRBatchMax || plan.nb != 4 || plan.nw != 8) return hipErrorInvalidValue;
+    RRBatch b;
+    for (int i = 0; i < n; ++i) fill_params(b.p[i], *cols[i], *red[i], plan, partial[i], bound[i]);
+    for (int i = n; i < kRRBatchMax; ++i) b.p[i] = b.p[0];
+    b.n = n;
+    b.blocks_per_pair = plan.nchunks * plan.nsplit;
+    hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
+                            unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream)
+{
+    RRParams p;
+    fill_params(p, cols, red, plan, partial, bound);
     const int grid = plan.nchunks * plan.nsplit;
     return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, stream)
                      : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, stream);

@@ -168,6 +168,18 @@ int  fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
                              int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
                              int64_t* n_accepted /*page-locked*/);
 
+/* n independent image pairs in one call, enqueued like n fm_match_accepted_async calls (same output
+ * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
+ * fm_sync).  Consecutive pairs whose banks have the same padded sizes go through the distance kernel
+ * TOGETHER, up to eight pairs per launch: inside one launch the workgroups of the next pair fill the
+ * CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
+ * a 100k x 100k pair).  The reference maps its matcher over the pairs of a dataset one after the
+ * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (float32
+ * route, empty banks, a different shape) are enqueued one by one.                                */
+int  fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                             int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
+                             double* const* ratio, int64_t* const* n_accepted /*page-locked words*/);
+
 /* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
  * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
  * them) and *d_count = total accepted, both in caller-supplied DEVICE memory -- the send

@@ -35,10 +35,14 @@ for d in sorted(glob.glob("pmc_*")):
 # FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM)
 import json, re
 def mean_of(fn, counter):
+    # the headline's distance kernel: the batched launch (several image pairs per dispatch) if the bench
+    # used it, else the single-pair top-1 kernel
     try:
-        for row in csv.DictReader(open(fn)):
-            if row["counter"] == counter and "rowreduce_kernel" in row["kernel"] and ", 1," in row["kernel"]:
-                return float(row["mean_per_dispatch"])
+        rows = [r for r in csv.DictReader(open(fn)) if r["counter"] == counter]
+        for want in ("rowreduce_batch_kernel", "rowreduce_kernel<4, 1,"):
+            for row in rows:
+                if want in row["kernel"]:
+                    return float(row["mean_per_dispatch"])
     except Exception:
         return None
 fs, ws = mean_of("pmc_fetch_summary.csv", "FETCH_SIZE"), mean_of("pmc_write_summary.csv", "WRITE_SIZE")
@@ -66,4 +70,4 @@ find $OUT/trace -name "*kernel_trace.csv" -size +2M -delete
 ls -la $OUT
 cat $OUT/kernel_stats.csv | head -20
 cat $OUT/*_summary.csv | grep -i rowreduce
-tail -3 $OUT/*.err | head -40
+for f in $OUT/*.err; do tail -n 2 $f; done | head -30

@@ -315,3 +315,41 @@ def test_a_synchronous_call_completes_the_async_calls_before_it(ctx):
         rq, rt, _, _ = ctx.match_accepted(qb, tb, 0.7)
         assert m == len(rq) > 50 and np.array_equal(qa, rq) and np.array_equal(ta, rt)
     ctx.sync()
+
+
+def test_batch_call_groups_pairs_of_one_shape_into_shared_launches(ctx):
+    """fm_match_accepted_batch: seven pairs of one shape (launches of 5 + 2 pairs), then a pair of
+    another shape, a pair with an empty train bank and two more of the first shape -- every pair's
+    accepted matches equal the synchronous call's; repeated, so the workspace slots are reused.
+    (Train banks of >= 32768 rows: below that the planner picks 4-wave workgroups and the pairs are
+    enqueued one by one.)"""
+    same = [_banks(ctx, 3000, 33000, seed=120 + k) for k in range(9)]
+    other = _banks(ctx, 1700, 2100, seed=140)
+    Qe, Te, qbe, _ = _banks(ctx, 900, 800, seed=141)
+    empty_t = ctx.bank(np.zeros((0, 128), np.uint8))
+    order = same[:7] + [other] + [(Qe, None, qbe, empty_t)] + same[7:]
+    pairs = [(p[2], p[3]) for p in order]
+    want = [ctx.match_accepted(qb, tb, 0.75) for qb, tb in pairs]
+    outs = [(ctx.pinned_empty(3000, np.int32), ctx.pinned_empty(3000, np.int32),
+             ctx.pinned_empty(3000, np.float32), ctx.pinned_empty(3000, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    ctx.sync()
+    ctx.reset_stats()
+    for rep in range(3):
+        for c in counts:
+            c[0] = -1
+        ctx.match_accepted_batch(pairs, 0.75, outs, counts)
+        ctx.sync()
+        for (qa, ta, da, ra), out, cnt in zip(want, outs, counts):
+            m = int(cnt[0])
+            assert m == len(qa)
+            assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta)
+            assert np.array_equal(out[2][:m], da) and np.array_equal(out[3][:m], ra)
+    assert sum(len(w[0]) for w in want) > 1000
+    st = ctx.stats()
+    assert st["pairs"] >= 3 * 9 * 3000 * 33000          # every grouped launch is timed and accounts its pairs
+    assert st["kernel_launches"] <= 3 * 6               # 7 -> 5 + 2, 2 -> one launch, the odd ones alone
+    with pytest.raises(fastmatch_amd_error()):          # pageable outputs are refused
+        ctx.match_accepted_batch(pairs[:2], 0.75, [(np.empty(3000, np.int32), np.empty(3000, np.int32),
+                                                    np.empty(3000, np.float32), np.empty(3000, np.float64))] * 2, counts[:2])
+    ctx.sync()
