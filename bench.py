@@ -261,8 +261,15 @@ def main():
     # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
     # the timed region.  On GPUs the rows never leave HBM (fm_match_accepted_dev).
-    gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank)) if world > 1 else None
+    # Default (FM_BENCH_BATCH unset): the pairs of a step share distance-kernel launches
+    # (fm_match_accepted_dev_batch) and ONE all-gather ships the step's rows, overlapping the next step.
+    step_gather = (world > 1 and os.environ.get("FM_BENCH_SYNC") != "1" and os.environ.get("FM_BENCH_BATCH", "1") != "0"
+                   and os.environ.get("FM_BENCH_HOST_GATHER") != "1" and os.environ.get("FM_BENCH_GATHER") != "rccl")
+    gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank),
+                                      pairs_per_step=PAIRS_PER_STEP if step_gather else 1) if world > 1 else None
     device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
+    pair_args = ctx.prepare_pairs(banks) if step_gather else None
+    h_counts = ctx.pinned_empty(PAIRS_PER_STEP, np.int64)
     # FM_BENCH_GATHER=rccl: the library's own all-gather (fm_comm_init / fm_gather_matches, RCCL on the
     # matching stream) instead of torch.distributed's; the id travels by a torch broadcast
     abi_gather = None
@@ -287,6 +294,13 @@ def main():
                     ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
             ctx.sync()                                      # results of the whole batch are on the host now
             return int(sum(int(c[0]) for c in counts))
+        if step_gather:
+            rows, cnts = gatherer.send_buffers()
+            ctx.match_accepted_dev_batch(pair_args, TAU, rows.data_ptr(), cnts.data_ptr(), NQ, h_counts=h_counts,
+                                         consumer_stream=gatherer.consumer_stream())
+            gatherer.submit_device()
+            ctx.sync()
+            return int(h_counts.sum())
         if dev_async and (abi_gather is not None or device_gather):
             # no host synchronisation between pairs: K1 launches back to back on the library's stream,
             # each pair's small kernels + its all-gather beside the next pair's K1
@@ -461,7 +475,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_tag": traffic_tag, "traffic_note": traffic_note,
-                         "kernel": ("fm::rowreduce_batch_kernel<4,1,8,3,1>" if use_batch else "fm::rowreduce_kernel<4,1,true,8,3,1>")
+                         "kernel": ("fm::rowreduce_batch_kernel<4,1,8,3,1>" if (use_batch or step_gather) else "fm::rowreduce_kernel<4,1,true,8,3,1>")
                                    + " (v_mfma_i32_16x16x64_i8)",
                          "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms * pairs_per_launch,
                          "image_pairs_per_launch": pairs_per_launch,

@@ -78,6 +78,7 @@ SYMBOLS = {
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
+    "fm_match_accepted_dev_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_dev_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_xcheck1_batched": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
@@ -422,6 +423,24 @@ class Context(object):
         batch = pairs if isinstance(pairs, dict) else self.prepare_batch(pairs, outs, counts)
         n, qh, th, cap, a0, a1, a2, a3, ac = batch["args"]
         self._check(self.lib.fm_match_accepted_batch(self.handle, n, qh, th, float(tau), cap, a0, a1, a2, a3, ac))
+
+    def match_accepted_dev_batch(self, pairs, tau, rows_ptr, counts_ptr, cap, h_counts=None, consumer_stream=0):
+        """``match_accepted_batch`` with device outputs: ``rows_ptr`` = device address of an int32
+        [n, cap, 3] block, ``counts_ptr`` of an int64 [n] array; ``h_counts`` = ``pinned_empty(n, np.int64)``
+        or None; ``consumer_stream`` as in ``match_accepted_dev_async``.  ``pairs`` may be the list of
+        (query bank, train bank) or a ``prepare_pairs`` block."""
+        n, qh, th = pairs["args"] if isinstance(pairs, dict) else self.prepare_pairs(pairs)["args"]
+        if h_counts is not None and (not isinstance(h_counts, np.ndarray) or h_counts.dtype != np.int64 or h_counts.size < n):
+            raise ValueError("h_counts must be an int64 array of n words (pinned_empty(n, np.int64))")
+        self._check(self.lib.fm_match_accepted_dev_batch(self.handle, n, qh, th, float(tau), int(cap), _P(int(rows_ptr)),
+                                                         _P(int(counts_ptr)), _ptr(h_counts) if h_counts is not None else None,
+                                                         _P(int(consumer_stream)) if consumer_stream else None))
+
+    def prepare_pairs(self, pairs):
+        """The bank-handle arrays of a fixed list of pairs, built once (``match_accepted_dev_batch``)."""
+        n = len(pairs)
+        arr = lambda vals: (_P * n)(*[_P(int(v)) for v in vals])
+        return {"args": (n, arr([q.handle.value for q, _ in pairs]), arr([t.handle.value for _, t in pairs])), "keep": list(pairs)}
 
     def match_accepted_dev(self, q, t, tau, rows_ptr, count_ptr, cap):
         """X1 + R1 with the accepted matches left on the device: ``rows_ptr`` = device address of

@@ -1536,20 +1536,60 @@ extern "C" int fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_b
 // n image pairs in one call, enqueued like fm_match_accepted_async; runs of consecutive pairs of one
 // shape go through K1 TOGETHER (rowreduce_batch_kernel: up to FM_BATCH_GROUP = 8 pairs per launch), each
 // pair's small kernels follow on one of three tail streams beside the next group's K1.
+// d_rows != NULL: device outputs (fm_match_accepted_dev_batch): pair i's rows at d_rows + i * cap * 3, its
+// count at d_counts + i, optionally also in the page-locked words h_counts[i]; host outputs otherwise.
+static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                        int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
+                        double* const* ratio, int64_t* const* n_accepted,
+                        int32_t* d_rows, int64_t* d_counts, int64_t* h_counts, hipStream_t consumer);
+
 extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
                                        int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
                                        double* const* ratio, int64_t* const* n_accepted)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_batch: ctx is NULL");
+    if (n > 0 && (!qidx || !tidx || !dist || !ratio || !n_accepted)) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
+    for (int i = 0; i < n; ++i) if (!n_accepted[i]) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n_accepted is NULL");
+    return batch_common(ctx, n, q, t, tau, cap, qidx, tidx, dist, ratio, n_accepted, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int fm_match_accepted_dev_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                                           int64_t cap, int32_t* d_rows, int64_t* d_counts, int64_t* h_counts, void* consumer_stream)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_dev_batch: ctx is NULL");
+    if (n > 0) {
+        if (!d_rows || !d_counts) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_batch: device output pointer is NULL");
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_rows) != hipSuccess || at.type != hipMemoryTypeDevice ||
+            hipPointerGetAttributes(&at, d_counts) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_batch: d_rows / d_counts must be device memory");
+        }
+        if (h_counts && !pinned_device_alias(h_counts)) return fail(ctx, FM_EINVAL, "fm_match_accepted_dev_batch: h_counts must be page-locked (fm_host_alloc)");
+    }
+    return batch_common(ctx, n, q, t, tau, cap, nullptr, nullptr, nullptr, nullptr, nullptr, d_rows, d_counts, h_counts,
+                        (hipStream_t)consumer_stream);
+}
+
+static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                        int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
+                        double* const* ratio, int64_t* const* n_accepted,
+                        int32_t* d_rows, int64_t* d_counts, int64_t* h_counts, hipStream_t consumer)
+{
+    const bool to_dev = d_rows != nullptr;
     if (n < 0 || cap < 0) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n < 0 or cap < 0");
     if (n == 0) return FM_OK;
-    if (!q || !t || !qidx || !tidx || !dist || !ratio || !n_accepted) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
+    if (!q || !t) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
     int rc;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if ((rc = check_pair(ctx, q[i], t[i], "fm_match_accepted_batch")) != FM_OK) return rc;
-        if (!n_accepted[i]) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n_accepted is NULL");
-    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (to_dev && consumer) {
+        // the compactions write buffers the consumer stream reads (the previous step's collective): they wait
+        // for what that stream has been given so far
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
+        for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_consumer, 0));
+    }
     static const int group_max = [] { const char* e = getenv("FM_BATCH_GROUP"); int v = e ? atoi(e) : kRRBatchMax;
                                       return v < 1 ? 1 : (v > kRRBatchMax ? kRRBatchMax : v); }();
     auto batchable = [&](int i) {
@@ -1575,10 +1615,22 @@ extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* co
             if (pl.nb != 4 || pl.nw != 8 || !ctx->use_glds || (nb && atoi(nb) == 2)) g = 1;     // shapes the batched kernel is not built for
         }
         if (g == 1) {                  // an odd pair: the single-pair async call (which also reports its errors)
-            if (q[i]->n == 0) *n_accepted[i] = 0;
-            rc = xcheck_common(ctx, q[i], t[i], true, tau, tidx[i], dist[i], ratio[i], nullptr, n_accepted[i],
-                               "fm_match_accepted_batch", cap, qidx[i], nullptr, nullptr, true);
-            if (rc != FM_OK) return rc;
+            if (to_dev) {
+                int64_t* hc = h_counts ? h_counts + i : nullptr;
+                if (q[i]->n == 0) {
+                    HIP_TRY(ctx, hipMemsetAsync(d_counts + i, 0, 8, ctx->stream_tail));
+                    if (hc) *hc = 0;
+                } else {
+                    rc = xcheck_common(ctx, q[i], t[i], true, tau, nullptr, nullptr, nullptr, nullptr, hc, "fm_match_accepted_dev_batch",
+                                       cap, nullptr, d_rows + (size_t)i * cap * 3, (long long*)(d_counts + i), true, nullptr);
+                    if (rc != FM_OK) return rc;
+                }
+            } else {
+                if (q[i]->n == 0) *n_accepted[i] = 0;
+                rc = xcheck_common(ctx, q[i], t[i], true, tau, tidx[i], dist[i], ratio[i], nullptr, n_accepted[i],
+                                   "fm_match_accepted_batch", cap, qidx[i], nullptr, nullptr, true);
+                if (rc != FM_OK) return rc;
+            }
             ++i;
             continue;
         }
@@ -1592,11 +1644,18 @@ extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* co
         tm.timed = true; tm.call_timed = true; tm.pairs = 0;
         for (int j = 0; j < g; ++j) {
             const int k = i + j;
-            al[j][0] = pinned_device_alias(qidx[k]); al[j][1] = pinned_device_alias(tidx[k]);
-            al[j][2] = pinned_device_alias(dist[k]); al[j][3] = pinned_device_alias(ratio[k]);
-            al[j][4] = pinned_device_alias(n_accepted[k]);
-            for (int u = 0; u < 5; ++u)
-                if (!al[j][u]) { ctx->timer_pool.push_back(tm); return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: host outputs must be page-locked (fm_host_alloc)"); }
+            if (to_dev) {
+                for (int u = 0; u < 4; ++u) al[j][u] = nullptr;
+                al[j][4] = h_counts ? pinned_device_alias(h_counts + k) : nullptr;
+                if (h_counts) h_counts[k] = 0;
+            } else {
+                al[j][0] = pinned_device_alias(qidx[k]); al[j][1] = pinned_device_alias(tidx[k]);
+                al[j][2] = pinned_device_alias(dist[k]); al[j][3] = pinned_device_alias(ratio[k]);
+                al[j][4] = pinned_device_alias(n_accepted[k]);
+                for (int u = 0; u < 5; ++u)
+                    if (!al[j][u]) { ctx->timer_pool.push_back(tm); return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: host outputs must be page-locked (fm_host_alloc)"); }
+                *n_accepted[k] = 0;
+            }
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
             if (!sl.tail_done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming));
             L[j] = slot_layout(q[k]->n, pl);
@@ -1605,7 +1664,6 @@ extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* co
             part[j] = (unsigned long long*)sl.ws;
             bnd[j] = coop ? (int*)((char*)sl.ws + L[j].pbytes) : nullptr;
             tm.pairs += q[k]->n * t[k]->n;
-            *n_accepted[k] = 0;
         }
         HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
         HIP_TRY(ctx, launch_rowreduce_batch(g, cols, red, pl, part, bnd, ctx->stream));
@@ -1616,14 +1674,24 @@ extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* co
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
             if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
-                                   al[j][4], nullptr, nullptr, nullptr)) != FM_OK) return rc;
+                                   al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),
+                                   nullptr)) != FM_OK) return rc;
             HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));
             sl.in_use = true;
             if (j == g - 1) HIP_TRY(ctx, hipEventRecord(tm.c1, ts));
         }
-        ctx->rows_stream = ctx->stream;
         ctx->pending.push_back(tm);
         i += g;
+    }
+    if (to_dev) {
+        // everything the tails were given is in front of these records: the consumer waits for all of it
+        // (without a consumer stream the first tail stream collects the others: fm_gather_matches follows it)
+        for (hipStream_t ts : ctx->tails) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, ts));
+            if (consumer) HIP_TRY(ctx, hipStreamWaitEvent(consumer, ctx->ev_consumer, 0));
+            else if (ts != ctx->stream_tail) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, ctx->ev_consumer, 0));
+        }
+        ctx->rows_stream = ctx->stream_tail;
     }
     return FM_OK;
 }

@@ -196,7 +196,12 @@ class MatchGatherer(object):
     ``fill_device``: with a CPU transport (gloo dry run of the device path on a one-GPU box)
     the send buffers still live on that CUDA device and are copied to the host for transport."""
 
-    def __init__(self, device, capacity, group=None, fill_device=None):
+    def __init__(self, device, capacity, group=None, fill_device=None, pairs_per_step=1):
+        """``pairs_per_step`` > 1: a send buffer holds the rows of a whole step -- int32
+        [pairs_per_step * capacity, 3] (pair i at rows [i * capacity, (i + 1) * capacity)) and int64
+        [pairs_per_step] counts, what ``Context.match_accepted_dev_batch`` fills -- and ONE all-gather
+        ships the step (fewer, larger collectives); ``finish()`` then returns ``(counts [world,
+        pairs_per_step], rows [world, pairs_per_step, capacity, 3])``."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -204,16 +209,17 @@ class MatchGatherer(object):
         self.world = dist.get_world_size(group)
         self.dev = device
         self.capacity = int(capacity)
+        self.pps = int(pairs_per_step)
         self.on_cpu = isinstance(device, str) and device == "cpu"
         mk = lambda dev, *shape, dtype: [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(2)]
-        self.buf = mk(device, self.capacity, 3, dtype=torch.int32)
-        self.mine = mk(device, 1, dtype=torch.int64)
-        self.allbuf = mk(device, self.world * self.capacity, 3, dtype=torch.int32)
-        self.counts = mk(device, self.world, dtype=torch.int64)
+        self.buf = mk(device, self.pps * self.capacity, 3, dtype=torch.int32)
+        self.mine = mk(device, self.pps, dtype=torch.int64)
+        self.allbuf = mk(device, self.world * self.pps * self.capacity, 3, dtype=torch.int32)
+        self.counts = mk(device, self.world * self.pps, dtype=torch.int64)
         self.fill_buf = self.fill_mine = None
         if self.on_cpu and fill_device is not None:
-            self.fill_buf = mk(fill_device, self.capacity, 3, dtype=torch.int32)
-            self.fill_mine = mk(fill_device, 1, dtype=torch.int64)
+            self.fill_buf = mk(fill_device, self.pps * self.capacity, 3, dtype=torch.int32)
+            self.fill_mine = mk(fill_device, self.pps, dtype=torch.int64)
         self.pending = []
         self.slot = 0
 
@@ -225,8 +231,8 @@ class MatchGatherer(object):
     def _start(self, k):
         dist = self.dist
         if self.on_cpu:
-            self.pending = [dist.all_gather(list(self.counts[k].split(1)), self.mine[k], group=self.group, async_op=True),
-                            dist.all_gather(list(self.allbuf[k].split(self.capacity)), self.buf[k], group=self.group, async_op=True)]
+            self.pending = [dist.all_gather(list(self.counts[k].split(self.pps)), self.mine[k], group=self.group, async_op=True),
+                            dist.all_gather(list(self.allbuf[k].split(self.pps * self.capacity)), self.buf[k], group=self.group, async_op=True)]
         else:
             self.pending = [dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group, async_op=True),
                             dist.all_gather_into_tensor(self.allbuf[k], self.buf[k], group=self.group, async_op=True)]
@@ -276,4 +282,6 @@ class MatchGatherer(object):
     def finish(self):
         self._wait()
         k = self.last
+        if self.pps > 1:
+            return self.counts[k].view(self.world, self.pps), self.allbuf[k].view(self.world, self.pps, self.capacity, 3)
         return self.counts[k], self.allbuf[k].view(self.world, self.capacity, 3)

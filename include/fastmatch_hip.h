@@ -180,6 +180,15 @@ int  fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, co
                              int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
                              double* const* ratio, int64_t* const* n_accepted /*page-locked words*/);
 
+/* fm_match_accepted_batch with the results left on the device, as fm_match_accepted_dev_async leaves
+ * them: pair i's rows at d_rows + i * cap * 3 (int32 [n][cap][3]), its count at d_counts[i] (and in the
+ * page-locked word h_counts[i] if h_counts is not NULL).  One contiguous block per call, so the caller
+ * ships a whole step with ONE all-gather of n * cap rows.  consumer_stream as in
+ * fm_match_accepted_dev_async: ordered against the fills in both directions.                     */
+int  fm_match_accepted_dev_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
+                                 int64_t cap, int32_t* d_rows /*device [n][cap][3]*/, int64_t* d_counts /*device [n]*/,
+                                 int64_t* h_counts /*page-locked [n] or NULL*/, void* consumer_stream /*hipStream_t or NULL*/);
+
 /* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
  * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
  * them) and *d_count = total accepted, both in caller-supplied DEVICE memory -- the send

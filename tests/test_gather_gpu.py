@@ -163,6 +163,44 @@ else:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tdev = "cpu"
 ctx = fastmatch_amd.Context(0)
+if os.environ.get("FM_TEST_ASYNC") == "2":
+    # whole steps: three pairs per step through fm_match_accepted_dev_batch, ONE all-gather per step
+    PPS = 3
+    g = sharding.MatchGatherer(tdev, capacity=4000, fill_device=torch.device("cuda", 0), pairs_per_step=PPS)
+    keep, last = [], None
+    for step in range(3):
+        per_rank = []
+        for r in range(world):
+            per_rank.append([synth.planted_pair(4000, 33000 if i < 2 else 3000, seed=1000 * step + 10 * r + i)[:2] for i in range(PPS)])
+        banks = []
+        for Q, T in per_rank[rank]:
+            qb, tb = ctx.bank(Q), ctx.bank(T)
+            qb.set_selfdist(ctx.self_dist(qb))
+            banks.append((qb, tb))
+        keep.append(banks)
+        rows, cnts = g.send_buffers()
+        hc = ctx.pinned_empty(PPS, np.int64)
+        ctx.match_accepted_dev_batch(banks, 0.7, rows.data_ptr(), cnts.data_ptr(), 4000, h_counts=hc,
+                                     consumer_stream=g.consumer_stream())
+        g.submit_device()
+        last = per_rank
+    counts, allrows = g.finish()
+    ctx.sync()
+    assert counts.shape == (world, PPS) and allrows.shape == (world, PPS, 4000, 3)
+    for r in range(world):
+        for i, (Q, T) in enumerate(last[r]):
+            qr, tr = ctx.bank(Q), ctx.bank(T)
+            qr.set_selfdist(ctx.self_dist(qr))
+            qa, ta, da, _ = ctx.match_accepted(qr, tr, 0.7)
+            m = int(counts[r, i].item())
+            assert m == len(qa) > 100, (m, len(qa))
+            assert np.array_equal(allrows[r, i, :m].cpu().numpy(), sharding.pack_matches(qa, ta, da))
+            if r == rank:
+                assert int(hc[i]) == m
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK_OK", rank)
+    sys.exit(0)
 g = sharding.MatchGatherer(tdev, capacity=4000, fill_device=torch.device("cuda", 0))
 expect = []
 keep = []
@@ -202,7 +240,7 @@ print("RANK_OK", rank)
 def _run_ranks(world, backend, tmp_path, async_fill=False):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT % {"root": ROOT})
-    env = dict(os.environ, FM_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", FM_TEST_ASYNC="1" if async_fill else "0")
+    env = dict(os.environ, FM_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", FM_TEST_ASYNC=str(int(async_fill)))
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
@@ -353,3 +391,47 @@ def test_batch_call_groups_pairs_of_one_shape_into_shared_launches(ctx):
         ctx.match_accepted_batch(pairs[:2], 0.75, [(np.empty(3000, np.int32), np.empty(3000, np.int32),
                                                     np.empty(3000, np.float32), np.empty(3000, np.float64))] * 2, counts[:2])
     ctx.sync()
+
+
+def test_gatherer_whole_steps_one_rank_rccl(tmp_path):
+    """fm_match_accepted_dev_batch + one RCCL all-gather per step (three pairs), stream ordering only."""
+    _run_ranks(1, "nccl", tmp_path, async_fill=2)
+
+
+def test_gatherer_whole_steps_two_ranks_sharing_the_gpu(tmp_path):
+    _run_ranks(2, "gloo", tmp_path, async_fill=2)
+
+
+def test_device_rows_batch_equals_the_synchronous_calls(ctx):
+    """fm_match_accepted_dev_batch in one process: grouped and odd pairs into one [n, cap, 3] block that a
+    side stream snapshots behind the call; twice, so the second fill has to wait for the snapshot."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cap = 3000
+    pairs_full = [_banks(ctx, 3000, 33000, seed=160 + k) for k in range(4)] + [_banks(ctx, 1500, 2000, seed=170)]
+    pairs = [(p[2], p[3]) for p in pairs_full]
+    n = len(pairs)
+    want = []
+    for qb, tb in pairs:
+        qa, ta, da, _ = ctx.match_accepted(qb, tb, 0.8)
+        want.append(sharding.pack_matches(qa, ta, da))
+    rows = torch.full((n, cap, 3), -7, dtype=torch.int32, device=dev)
+    cnts = torch.zeros(n, dtype=torch.int64, device=dev)
+    hc = ctx.pinned_empty(n, np.int64)
+    side = torch.cuda.Stream(device=dev)
+    snaps = []
+    block = ctx.prepare_pairs(pairs)
+    with torch.cuda.stream(side):
+        for rep in range(2):
+            ctx.match_accepted_dev_batch(block, 0.8, rows.data_ptr(), cnts.data_ptr(), cap, h_counts=hc,
+                                         consumer_stream=side.cuda_stream)
+            snaps.append((rows.clone(), cnts.clone()))
+            rows.fill_(-5)
+    ctx.sync()
+    side.synchronize()
+    for r, c in snaps:
+        for i, w in enumerate(want):
+            assert int(c[i].item()) == len(w) == int(hc[i]) > 50
+            assert np.array_equal(r[i, :len(w)].cpu().numpy(), w)
+    with pytest.raises(fastmatch_amd_error()):
+        ctx.match_accepted_dev_batch(pairs, 0.8, np.zeros((n, cap, 3), np.int32).ctypes.data, cnts.data_ptr(), cap)
