@@ -439,7 +439,8 @@ static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t s
 {
     if constexpr (NW == 8) {
         // PRIO: s_setprio 2 while a wave issues a unit's 16 MFMAs as one burst, back to 0 for the
-        // epilogue (A/B on one box: 0.897 -> 0.887 ms); FM_PRIO=0 selects the variant without it
+        // epilogue (A/B on one box: 0.897 -> 0.887 ms); FM_PRIO=0 selects the variant without it.
+        // (The two-buffer top-2 kernel gets 1 % slower with it: 1.034 -> 1.044 ms.)
         const char* pe = getenv("FM_PRIO");
         const bool prio = !(pe && atoi(pe) == 0);
         if (glds && nbuf_choice(KTOP) == 3) {

@@ -157,6 +157,14 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int unit_row(int id, int g) { return 16 * (id >> 2) + 4 * g + (id & 3); }
 
+// median of three (v_med3_i32)
+__device__ __forceinline__ int med3i(int a, int b, int c)
+{
+    int r;      // (the compiler forms v_med3 only for clamps against constants)
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int KTOP>
 struct TopK8 {
     int key[KTOP];
@@ -185,17 +193,15 @@ struct TopK8 {
             unit[0] = up ? u : unit[0];
             return up;
         } else {
-            int a1_[4], a2_[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a1_[i] = max(k[2 * i], k[2 * i + 1]); a2_[i] = min(k[2 * i], k[2 * i + 1]); }
-            int b1[2], b2[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                b1[i] = max(a1_[2 * i], a1_[2 * i + 1]);
-                b2[i] = max(max(min(a1_[2 * i], a1_[2 * i + 1]), a2_[2 * i]), a2_[2 * i + 1]);
-            }
-            const int k1 = max(b1[0], b1[1]);
-            const int k2 = max(max(min(b1[0], b1[1]), b2[0]), b2[1]);
+            // top-2 of the 8 keys (unique inside a unit): two triples (largest = v_max3, second = v_med3)
+            // and a pair, merged as sorted pairs -- 12 VALU (the pairwise tree: 20)
+            const int a1_ = max(max(k[0], k[1]), k[2]), a2_ = med3i(k[0], k[1], k[2]);
+            const int b1_ = max(max(k[3], k[4]), k[5]), b2_ = med3i(k[3], k[4], k[5]);
+            const int c1_ = max(k[6], k[7]), c2_ = min(k[6], k[7]);
+            const int m1 = max(a1_, b1_);
+            const int m2 = max(max(min(a1_, b1_), a2_), b2_);
+            const int k1 = max(m1, c1_);
+            const int k2 = max(max(min(m1, c1_), m2), c2_);
             const int h1 = k1 >> 4, h2 = k2 >> 4, g1 = key[0] >> 4, g2 = key[1] >> 4;
             const bool enter = h1 > g2, first = h1 > g1, both = h2 > g1;
             const int n0k = first ? k1 : key[0];
