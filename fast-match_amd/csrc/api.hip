@@ -1675,7 +1675,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
             if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
                                    al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),
-                                   nullptr)) != FM_OK) return rc;
+                                   nullptr)) != FM_OK) { ctx->pending.push_back(tm); return rc; }     // (events are in flight: drained at fm_sync)
             HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));
             sl.in_use = true;
             if (j == g - 1) HIP_TRY(ctx, hipEventRecord(tm.c1, ts));

@@ -118,3 +118,37 @@ def test_metric_cache_from_arrays_computes_exact_self_distances(ctx, tmp_path):
     eds, eps, edis, eidx = mc.get(150, 100, 60)
     assert np.array_equal(idx, eidx) and np.array_equal(dis, edis)
     assert mc2.bank(ctx).n == 400                            # lazily re-created device bank
+
+
+def test_batch_calls_reject_bad_arguments_and_the_context_survives(ctx):
+    """fm_match_accepted_batch / _dev_batch: pageable outputs, missing self distances, float32-route
+    banks, host pointers for device outputs -> error with a message; an empty batch is a no-op; the
+    context keeps working afterwards."""
+    import ctypes
+    from fastmatch_amd import _ffi
+    Q, T, _ = synth.planted_pair(600, 500, seed=3)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    outs = [(ctx.pinned_empty(600, np.int32), ctx.pinned_empty(600, np.int32), ctx.pinned_empty(600, np.float32),
+             ctx.pinned_empty(600, np.float64))]
+    cnt = [ctx.pinned_empty(1, np.int64)]
+    with pytest.raises(_ffi.FastMatchHipError):                         # no self distances on the query bank
+        ctx.match_accepted_batch([(qb, tb)], 0.7, outs, cnt)
+    ctx.sync()
+    qb.set_selfdist(ctx.self_dist(qb))
+    ctx.match_accepted_batch([], 0.7, [], [])                           # empty batch
+    with pytest.raises(ValueError):                                     # lists of different lengths
+        ctx.match_accepted_batch([(qb, tb)], 0.7, outs, [])
+    qf = ctx.bank((Q.astype(np.float32) + 0.25))
+    qf.set_selfdist(ctx.self_dist(qf))
+    with pytest.raises(_ffi.FastMatchHipError):                         # float32 route: not an async path
+        ctx.match_accepted_batch([(qf, ctx.bank(T.astype(np.float32) + 0.25))], 0.7, outs, cnt)
+    ctx.sync()
+    ctx.match_accepted_batch([(qb, tb)], 0.7, outs, cnt)                # and it still works
+    ctx.sync()
+    qa, ta, da, ra = ctx.match_accepted(qb, tb, 0.7)
+    m = int(cnt[0][0])
+    assert m == len(qa) and np.array_equal(outs[0][0][:m], qa) and np.array_equal(outs[0][3][:m], ra)
+    with pytest.raises(_ffi.FastMatchHipError):                         # device outputs must be device memory
+        ctx.match_accepted_dev_batch([(qb, tb)], 0.7, np.zeros((600, 3), np.int32).ctypes.data,
+                                     np.zeros(1, np.int64).ctypes.data, 600)
+    ctx.sync()
