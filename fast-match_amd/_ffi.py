@@ -142,6 +142,11 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def _stream_arg(stream):
+    """consumer_stream of the C-ABI: None -> FM_NO_STREAM, an integer handle (0 = the null stream) as is."""
+    return _P(-1 & 0xFFFFFFFFFFFFFFFF) if stream is None else _P(int(stream))
+
+
 class _LockedLib(object):
     """The library with every call serialised on one lock.  An fm_ctx is not re-entrant (it
     owns shared workspaces, the staging list and the timing events) and ctypes releases the
@@ -424,7 +429,7 @@ class Context(object):
         n, qh, th, cap, a0, a1, a2, a3, ac = batch["args"]
         self._check(self.lib.fm_match_accepted_batch(self.handle, n, qh, th, float(tau), cap, a0, a1, a2, a3, ac))
 
-    def match_accepted_dev_batch(self, pairs, tau, rows_ptr, counts_ptr, cap, h_counts=None, consumer_stream=0):
+    def match_accepted_dev_batch(self, pairs, tau, rows_ptr, counts_ptr, cap, h_counts=None, consumer_stream=None):
         """``match_accepted_batch`` with device outputs: ``rows_ptr`` = device address of an int32
         [n, cap, 3] block, ``counts_ptr`` of an int64 [n] array; ``h_counts`` = ``pinned_empty(n, np.int64)``
         or None; ``consumer_stream`` as in ``match_accepted_dev_async``.  ``pairs`` may be the list of
@@ -434,7 +439,7 @@ class Context(object):
             raise ValueError("h_counts must be an int64 array of n words (pinned_empty(n, np.int64))")
         self._check(self.lib.fm_match_accepted_dev_batch(self.handle, n, qh, th, float(tau), int(cap), _P(int(rows_ptr)),
                                                          _P(int(counts_ptr)), _ptr(h_counts) if h_counts is not None else None,
-                                                         _P(int(consumer_stream)) if consumer_stream else None))
+                                                         _stream_arg(consumer_stream)))
 
     def prepare_pairs(self, pairs):
         """The bank-handle arrays of a fixed list of pairs, built once (``match_accepted_dev_batch``)."""
@@ -452,17 +457,18 @@ class Context(object):
                                                    _P(int(rows_ptr)), _P(int(count_ptr)), ctypes.byref(n)))
         return n.value
 
-    def match_accepted_dev_async(self, q, t, tau, rows_ptr, count_ptr, cap, h_count=None, consumer_stream=0):
+    def match_accepted_dev_async(self, q, t, tau, rows_ptr, count_ptr, cap, h_count=None, consumer_stream=None):
         """``match_accepted_dev`` enqueued without a synchronisation (``sync()`` later).  ``h_count``:
         a ``pinned_empty(1, np.int64)`` array that also receives the count, or None;
         ``consumer_stream``: the raw handle of the stream that will read the buffers
-        (``torch.cuda.current_stream().cuda_stream``), ordered against the fill in both directions."""
+        (``torch.cuda.current_stream().cuda_stream`` -- 0 is a stream, PyTorch's default one), ordered
+        against the fill in both directions; None = no such stream."""
         if h_count is not None and (not isinstance(h_count, np.ndarray) or h_count.dtype != np.int64 or h_count.size < 1):
             raise ValueError("h_count must be an int64 array (pinned_empty(1, np.int64))")
         self._check(self.lib.fm_match_accepted_dev_async(self.handle, q.handle, t.handle, float(tau), int(cap),
                                                          _P(int(rows_ptr)), _P(int(count_ptr)),
                                                          _ptr(h_count) if h_count is not None else None,
-                                                         _P(int(consumer_stream)) if consumer_stream else None))
+                                                         _stream_arg(consumer_stream)))
 
     def knn2_ratio(self, q, t, tau, out=None):
         """Classic Ratio-Match: 2-NN + d1/d2 < tau, accepted matches in ascending query index:

@@ -60,6 +60,8 @@ struct fm_ctx {
     hipStream_t tails[kTails] = {nullptr, nullptr, nullptr};   // fm_match_accepted_batch spreads the pairs' tails over these
     hipStream_t rows_stream = nullptr;      // stream that produced the last device-resident rows (fm_gather_matches follows it)
     hipEvent_t ev_consumer = nullptr;
+    hipEvent_t ev_tail_end[3] = {nullptr, nullptr, nullptr};   // one per tail stream (an event re-recorded on another stream
+                                                               // before its waiters ran is not a safe handshake)
     struct AsyncSlot {
         void* ws = nullptr; size_t bytes = 0;
         int64_t nq = -1, ncols_alloc = -1, partial_bytes = -1;   // layout the arrays were initialised for
@@ -561,6 +563,9 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
             (e = hipEventCreateWithFlags(&ctx->aslot[0].tail_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->aslot[1].tail_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->ev_consumer, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->ev_tail_end[0], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->ev_tail_end[1], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->ev_tail_end[2], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->aslot[0].k_done, hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->aslot[1].k_done, hipEventDisableTiming)) != hipSuccess) {
             fm_ctx_destroy(ctx);
@@ -597,6 +602,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     for (auto& sl : ctx->aslot) free_slot(sl);
     for (auto& sl : ctx->bslot) free_slot(sl);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
+    for (hipEvent_t ev : ctx->ev_tail_end) if (ev) (void)hipEventDestroy(ev);
     for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamDestroy(ts);
     if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
     for (auto* v : {&ctx->pending, &ctx->timer_pool})
@@ -1164,6 +1170,9 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 // X1 (+R1) entry points
 // ---------------------------------------------------------------------------------------
 // Workspace of one bank pair in flight (async calls): partial | bound | qbest | tidx | dist | ratio | pass | block counts
+// "no consumer stream": NULL is a stream (the null stream, which PyTorch's default stream is)
+static const hipStream_t kNoStream = (hipStream_t)FM_NO_STREAM;
+
 struct SlotLayout {
     size_t pbytes, a_qbest, a_tidx, a_dist, a_ratio, a_pass, a_bc, a_end;
     int nblk;
@@ -1244,7 +1253,7 @@ static int enqueue_tail(fm_ctx* ctx, hipStream_t ts, fm_ctx::AsyncSlot& sl, cons
         // the rows go to the caller's device buffers, which a consumer stream (the result gather)
         // reads: the compaction waits for what that stream has been given so far (the gather that
         // last read these buffers), and the stream waits for the compaction
-        if (consumer) {
+        if (consumer != kNoStream) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
             HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_consumer, 0));
         }
@@ -1265,7 +1274,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
                          int32_t* tidx, float* dist, double* ratio, uint8_t* pass, int64_t* n_pass,
                          const char* who, int64_t compact_cap = -1, int32_t* c_qidx = nullptr,
                          int32_t* dev_rows = nullptr, long long* dev_count = nullptr, bool async_mode = false,
-                         hipStream_t consumer = nullptr)
+                         hipStream_t consumer = kNoStream)
 {
     const bool compact = compact_cap >= 0;
     const bool to_device = dev_rows != nullptr;
@@ -1343,7 +1352,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
                                to_device ? dev_rows : nullptr, dev_count, consumer)) != FM_OK) return rc;
         if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream_tail));
         HIP_TRY(ctx, hipEventRecord(sl.tail_done, ctx->stream_tail));
-        if (to_device && consumer) HIP_TRY(ctx, hipStreamWaitEvent(consumer, sl.tail_done, 0));
+        if (to_device && consumer != kNoStream) HIP_TRY(ctx, hipStreamWaitEvent(consumer, sl.tail_done, 0));
         ctx->rows_stream = to_device ? ctx->stream_tail : ctx->stream;
         sl.in_use = true;
         ctx->pending.push_back(tm);
@@ -1550,7 +1559,7 @@ extern "C" int fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* co
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_match_accepted_batch: ctx is NULL");
     if (n > 0 && (!qidx || !tidx || !dist || !ratio || !n_accepted)) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
     for (int i = 0; i < n; ++i) if (!n_accepted[i]) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: n_accepted is NULL");
-    return batch_common(ctx, n, q, t, tau, cap, qidx, tidx, dist, ratio, n_accepted, nullptr, nullptr, nullptr, nullptr);
+    return batch_common(ctx, n, q, t, tau, cap, qidx, tidx, dist, ratio, n_accepted, nullptr, nullptr, nullptr, kNoStream);
 }
 
 extern "C" int fm_match_accepted_dev_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
@@ -1584,7 +1593,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
     for (int i = 0; i < n; ++i)
         if ((rc = check_pair(ctx, q[i], t[i], "fm_match_accepted_batch")) != FM_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (to_dev && consumer) {
+    if (to_dev && consumer != kNoStream) {
         // the compactions write buffers the consumer stream reads (the previous step's collective): they wait
         // for what that stream has been given so far
         HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
@@ -1622,7 +1631,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
                     if (hc) *hc = 0;
                 } else {
                     rc = xcheck_common(ctx, q[i], t[i], true, tau, nullptr, nullptr, nullptr, nullptr, hc, "fm_match_accepted_dev_batch",
-                                       cap, nullptr, d_rows + (size_t)i * cap * 3, (long long*)(d_counts + i), true, nullptr);
+                                       cap, nullptr, d_rows + (size_t)i * cap * 3, (long long*)(d_counts + i), true, kNoStream);
                     if (rc != FM_OK) return rc;
                 }
             } else {
@@ -1675,7 +1684,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
             if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
                                    al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),
-                                   nullptr)) != FM_OK) { ctx->pending.push_back(tm); return rc; }     // (events are in flight: drained at fm_sync)
+                                   kNoStream)) != FM_OK) { ctx->pending.push_back(tm); return rc; }     // (events are in flight: drained at fm_sync)
             HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));
             sl.in_use = true;
             if (j == g - 1) HIP_TRY(ctx, hipEventRecord(tm.c1, ts));
@@ -1686,10 +1695,11 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
     if (to_dev) {
         // everything the tails were given is in front of these records: the consumer waits for all of it
         // (without a consumer stream the first tail stream collects the others: fm_gather_matches follows it)
-        for (hipStream_t ts : ctx->tails) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, ts));
-            if (consumer) HIP_TRY(ctx, hipStreamWaitEvent(consumer, ctx->ev_consumer, 0));
-            else if (ts != ctx->stream_tail) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, ctx->ev_consumer, 0));
+        for (int u = 0; u < fm_ctx::kTails; ++u) {
+            hipStream_t ts = ctx->tails[u];
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tail_end[u], ts));
+            if (consumer != kNoStream) HIP_TRY(ctx, hipStreamWaitEvent(consumer, ctx->ev_tail_end[u], 0));
+            else if (ts != ctx->stream_tail) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, ctx->ev_tail_end[u], 0));
         }
         ctx->rows_stream = ctx->stream_tail;
     }
@@ -1728,7 +1738,7 @@ extern "C" int fm_match_accepted_dev_async(fm_ctx* ctx, const fm_bank* q, const 
     if (q && q->n == 0) {
         HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream_tail));
         if (h_count) *h_count = 0;
-        if (consumer_stream) {
+        if (consumer_stream != FM_NO_STREAM) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, ctx->stream_tail));
             HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)consumer_stream, ctx->ev_consumer, 0));
         }

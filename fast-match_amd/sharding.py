@@ -262,10 +262,10 @@ class MatchGatherer(object):
 
     def consumer_stream(self):
         """Raw handle of the stream the collectives of this gatherer are ordered on (torch's current
-        stream): what ``Context.match_accepted_dev_async`` takes as ``consumer_stream``.  0 on CPU."""
+        stream): what ``Context.match_accepted_dev_async`` takes as ``consumer_stream``.  None on CPU."""
         if self.on_cpu and self.fill_buf is None:
-            return 0
-        return int(self.torch.cuda.current_stream().cuda_stream)
+            return None
+        return int(self.torch.cuda.current_stream().cuda_stream)        # (0 = the null stream: a stream all the same)
 
     def submit_device(self):
         """Start the all-gather of the slot handed out by the last ``send_buffers()``.  The fill

@@ -32,6 +32,7 @@ extern "C" {
 #define FM_EUNSUPPORTED -4   /* valid request this build cannot serve (e.g. dim > 128)        */
 
 /* Bank kinds (fm_bank_info) */
+#define FM_NO_STREAM ((void*)(intptr_t)-1)   /* "no consumer stream" (NULL is the null stream) */
 #define FM_BANK_I8   1       /* uint8 / integer-valued float32 rows: exact int8-MFMA route    */
 #define FM_BANK_F32  2       /* general float32 rows: fp32 fma-chain route                    */
 
@@ -187,7 +188,7 @@ int  fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, co
  * fm_match_accepted_dev_async: ordered against the fills in both directions.                     */
 int  fm_match_accepted_dev_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
                                  int64_t cap, int32_t* d_rows /*device [n][cap][3]*/, int64_t* d_counts /*device [n]*/,
-                                 int64_t* h_counts /*page-locked [n] or NULL*/, void* consumer_stream /*hipStream_t or NULL*/);
+                                 int64_t* h_counts /*page-locked [n] or NULL*/, void* consumer_stream /*hipStream_t or FM_NO_STREAM*/);
 
 /* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
  * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
@@ -203,15 +204,15 @@ int  fm_match_accepted_dev(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, doub
 /* fm_match_accepted_dev without the synchronisation: the call enqueues and returns.  The match
  * kernel (K1) goes to the context's stream, the small kernels behind it (election, ratio test,
  * compaction into d_rows / d_count) to a second stream, where they overlap the NEXT pair's K1.
- * consumer_stream (a hipStream_t, or NULL) is the stream that will read d_rows / d_count -- the
- * stream the caller's all-gather is enqueued on: the compaction first waits for the work that
+ * consumer_stream is the stream that will read d_rows / d_count -- the stream the caller's all-gather
+ * is enqueued on; NULL is the null stream (PyTorch's default stream), FM_NO_STREAM means none: the compaction first waits for the work that
  * stream has been given so far (the collective that last read these buffers), and the stream is
  * made to wait for the compaction, so the caller needs no host synchronisation between pairs.
  * h_count: page-locked host word (fm_host_alloc) that also receives the count, or NULL.
  * Integer-valued banks only.  fm_gather_matches called next follows the same ordering.         */
 int  fm_match_accepted_dev_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
                                  int32_t* d_rows /*device [cap][3]*/, int64_t* d_count /*device*/,
-                                 int64_t* h_count /*page-locked or NULL*/, void* consumer_stream /*hipStream_t or NULL*/);
+                                 int64_t* h_count /*page-locked or NULL*/, void* consumer_stream /*hipStream_t or FM_NO_STREAM*/);
 
 /* ---- K4: many match_position rounds in one launch ------------------------------------
  * Round b matches the query rows  q_rows[q_off[b] .. q_off[b+1])  of bank q (the radius

@@ -241,10 +241,20 @@ def _run_ranks(world, backend, tmp_path, async_fill=False):
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT % {"root": ROOT})
     env = dict(os.environ, FM_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", FM_TEST_ASYNC=str(int(async_fill)))
-    port = 29600 + os.getpid() % 300
+    import socket
+    with socket.socket() as sk:                # a port of its own per launch (the tests of this file follow each other)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if p.returncode != 0:                      # keep the evidence where a later look can find it
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "rank_failure_%d_%s_%s.log" % (world, backend, int(async_fill))), "w") as f:
+                f.write(p.stdout[-20000:] + "\n---- stderr ----\n" + p.stderr[-40000:])
+        except OSError:
+            pass
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert p.stdout.count("RANK_OK") == world
 
@@ -435,3 +445,38 @@ def test_device_rows_batch_equals_the_synchronous_calls(ctx):
             assert np.array_equal(r[i, :len(w)].cpu().numpy(), w)
     with pytest.raises(fastmatch_amd_error()):
         ctx.match_accepted_dev_batch(pairs, 0.8, np.zeros((n, cap, 3), np.int32).ctypes.data, cnts.data_ptr(), cap)
+
+
+def test_the_null_stream_is_a_consumer_stream_too(ctx):
+    """PyTorch's default stream has the handle 0: passing it as consumer_stream must order the fills
+    against it like any other stream (FM_NO_STREAM / None is the value for "none").  Copies issued on
+    the default stream right behind each call see the finished rows, every one of 40 back-to-back calls
+    (found by scripts/stress_async.py: the copy ran ahead of the compaction)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cap = 6000
+    pairs_full = [_banks(ctx, 6000, 33000, seed=210 + k) for k in range(5)] + [_banks(ctx, 2000, 1500, seed=220)]
+    pairs = [(p[2], p[3]) for p in pairs_full]
+    n = len(pairs)
+    want = []
+    for qb, tb in pairs:
+        qa, ta, da, _ = ctx.match_accepted(qb, tb, 0.75)
+        want.append(sharding.pack_matches(qa, ta, da))
+    rows = torch.zeros((n, cap, 3), dtype=torch.int32, device=dev)
+    cnts = torch.zeros(n, dtype=torch.int64, device=dev)
+    block = ctx.prepare_pairs(pairs)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    for it in range(40):
+        rows.fill_(-1)
+        ctx.match_accepted_dev_batch(block, 0.75, rows.data_ptr(), cnts.data_ptr(), cap, consumer_stream=0)
+        got_rows, got_cnt = rows.cpu().numpy(), cnts.cpu().numpy()
+        for j, w in enumerate(want):
+            assert int(got_cnt[j]) == len(w) > 50, (it, j)
+            assert np.array_equal(got_rows[j, :len(w)], w), (it, j)
+        rows1 = torch.full((cap, 3), -1, dtype=torch.int32, device=dev)
+        cnt1 = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.match_accepted_dev_async(pairs[it % n][0], pairs[it % n][1], 0.75, rows1.data_ptr(), cnt1.data_ptr(), cap,
+                                     consumer_stream=0)
+        w = want[it % n]
+        assert int(cnt1.cpu()[0]) == len(w) and np.array_equal(rows1.cpu().numpy()[:len(w)], w), it
+    ctx.sync()
