@@ -77,6 +77,8 @@ SYMBOLS = {
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
+    "fm_mark": (_INT, [_P, ctypes.POINTER(_I64)]),
+    "fm_wait": (_INT, [_P, _I64]),
     "fm_match_accepted_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
@@ -572,6 +574,15 @@ class Context(object):
 
     def sync(self):
         self._check(self.lib.fm_sync(self.handle))
+
+    def mark(self):
+        """Ticket for "everything enqueued so far" (``wait(ticket)`` blocks until it is done, later work keeps running)."""
+        t = _I64(0)
+        self._check(self.lib.fm_mark(self.handle, ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        self._check(self.lib.fm_wait(self.handle, int(ticket)))
 
     def f32_filter_stats(self):
         """(row-reduces routed through the bf16x3 filter, of which redone by the all-pairs kernel)."""

@@ -70,6 +70,10 @@ struct fm_ctx {
     } aslot[2];
     int aslot_next = 0;
     std::vector<AsyncSlot> bslot;           // fm_match_accepted_batch: one per position in the call
+    // fm_mark / fm_wait: points in the enqueued work a caller can wait for without draining what follows
+    static constexpr int kMarks = 8;
+    struct Mark { hipEvent_t ev[1 + kTails] = {nullptr, nullptr, nullptr, nullptr}; int64_t id = -1; } marks[kMarks];
+    int64_t next_mark = 0;
     void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
     int   comm_ranks = 0;
     fm_stats stats{};
@@ -599,6 +603,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
         if (sl.tail_done) (void)hipEventDestroy(sl.tail_done);
         if (sl.k_done) (void)hipEventDestroy(sl.k_done);
     };
+    for (auto& m : ctx->marks) for (hipEvent_t ev : m.ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->aslot) free_slot(sl);
     for (auto& sl : ctx->bslot) free_slot(sl);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
@@ -651,6 +656,36 @@ extern "C" int fm_sync(fm_ctx* ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamSynchronize(ts));
     return drain_pending(ctx);
+}
+
+// fm_mark: remember "everything enqueued on this context so far"; fm_wait: block until that point is
+// reached.  Work enqueued after the mark keeps running: a consumer can read the results of batch i while
+// batch i + 1 is already on the device (double-buffered outputs) -- fm_sync would drain both.
+extern "C" int fm_mark(fm_ctx* ctx, int64_t* ticket)
+{
+    if (!ctx || !ticket) return fail(ctx, FM_EINVAL, "fm_mark: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_ctx::Mark& m = ctx->marks[ctx->next_mark % fm_ctx::kMarks];
+    for (int u = 0; u < 1 + fm_ctx::kTails; ++u) {
+        if (!m.ev[u]) HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev[u], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(m.ev[u], u == 0 ? ctx->stream : ctx->tails[u - 1]));
+    }
+    m.id = ctx->next_mark;
+    *ticket = ctx->next_mark++;
+    return FM_OK;
+}
+
+extern "C" int fm_wait(fm_ctx* ctx, int64_t ticket)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_wait: ctx is NULL");
+    if (ticket < 0 || ticket >= ctx->next_mark) return fail(ctx, FM_EINVAL, "fm_wait: unknown ticket");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_ctx::Mark& m = ctx->marks[ticket % fm_ctx::kMarks];
+    if (m.id != ticket) {            // the slot has been re-used by a later mark: everything older is covered by it
+        if (m.id < ticket) return fail(ctx, FM_EINVAL, "fm_wait: unknown ticket");
+    }
+    for (hipEvent_t ev : m.ev) if (ev) HIP_TRY(ctx, hipEventSynchronize(ev));
+    return FM_OK;
 }
 
 extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)

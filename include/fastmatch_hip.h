@@ -169,6 +169,13 @@ int  fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
                              int32_t* qidx, int32_t* tidx, float* dist, double* ratio,
                              int64_t* n_accepted /*page-locked*/);
 
+/* Completion points for the enqueue-only calls.  fm_mark remembers everything enqueued on the context
+ * so far and returns a ticket; fm_wait(ticket) blocks until that work is complete, while work enqueued
+ * after the mark keeps running -- the results of batch i can be consumed while batch i + 1 computes
+ * (double-buffered outputs).  fm_sync waits for everything.  Tickets are valid for the next 8 marks.  */
+int  fm_mark(fm_ctx* ctx, int64_t* ticket);
+int  fm_wait(fm_ctx* ctx, int64_t ticket);
+
 /* n independent image pairs in one call, enqueued like n fm_match_accepted_async calls (same output
  * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
  * fm_sync).  Consecutive pairs whose banks have the same padded sizes go through the distance kernel

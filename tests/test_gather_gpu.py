@@ -480,3 +480,44 @@ def test_the_null_stream_is_a_consumer_stream_too(ctx):
         w = want[it % n]
         assert int(cnt1.cpu()[0]) == len(w) and np.array_equal(rows1.cpu().numpy()[:len(w)], w), it
     ctx.sync()
+
+
+def test_mark_and_wait_let_a_consumer_trail_the_enqueued_batches_by_one(ctx):
+    """fm_mark / fm_wait: batch i + 1 is enqueued before the host waits for batch i (two output sets);
+    what the host reads after wait(ticket_i) is batch i's complete result, for 12 batches in a row."""
+    from fastmatch_amd import _ffi
+    shapes = [(5000, 33000)] * 4 + [(1800, 2500)]
+    pairs_full = [_banks(ctx, nq, nt, seed=230 + k) for k, (nq, nt) in enumerate(shapes)]
+    pairs = [(p[2], p[3]) for p in pairs_full]
+    want = [ctx.match_accepted(qb, tb, 0.75) for qb, tb in pairs]
+    sets = []
+    for _ in range(2):
+        outs = [(ctx.pinned_empty(5000, np.int32), ctx.pinned_empty(5000, np.int32), ctx.pinned_empty(5000, np.float32),
+                 ctx.pinned_empty(5000, np.float64)) for _ in pairs]
+        cnts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+        sets.append((outs, cnts, ctx.prepare_batch(pairs, outs, cnts)))
+
+    def check(s):
+        outs, cnts, _ = sets[s]
+        for (qa, ta, da, ra), out, cnt in zip(want, outs, cnts):
+            m = int(cnt[0])
+            assert m == len(qa) > 50
+            assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta) and np.array_equal(out[3][:m], ra)
+            out[0][:m] = -1                      # so that a stale buffer cannot pass the next time round
+            cnt[0] = -1
+
+    prev = None
+    for i in range(12):
+        s = i % 2
+        ctx.match_accepted_batch(sets[s][2], 0.75)
+        ticket = ctx.mark()
+        if prev is not None:
+            ctx.wait(prev[1])
+            check(prev[0])
+        prev = (s, ticket)
+    ctx.wait(prev[1])
+    check(prev[0])
+    ctx.wait(0)                                  # an old ticket: covered by the marks that followed it
+    with pytest.raises(_ffi.FastMatchHipError):
+        ctx.wait(10 ** 6)
+    ctx.sync()
