@@ -62,7 +62,7 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                 else        bf[j][c] = v4i{0, 0, 0, 0};
             }
         }
-        TopK<1> top[NB];
+        TopTile top[NB];
         int thr[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; top[j].init(); }
@@ -138,8 +138,8 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
         // lane halves, then the four waves through tbest
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int mh = top[j].hi(0);
-            int mi = (top[j].tile[0] >= 0) ? top[j].index(0, h) : -1;
+            const int mh = top[j].hi();
+            int mi = (top[j].tile >= 0) ? top[j].index(h) : -1;
             if (mi >= nq) mi = -1;                  // padding slot
             const int oh = __shfl_xor(mh, 32);
             const int oi = __shfl_xor(mi, 32);

@@ -68,84 +68,36 @@ __device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r 
 // tile < 0: -1 = empty slot.
 constexpr int kNoKey = INT32_MIN;
 
-template <int KTOP>
-struct TopK {
-    int key[KTOP];
-    int tile[KTOP];
+// Best candidate of one lane for one train row over 32x32 tiles (the per-round kernels keep one: the
+// cross-check needs the nearest query row only).
+struct TopTile {
+    int key;
+    int tile;
 
-    __device__ __forceinline__ void init()
-    {
-#pragma unroll
-        for (int k = 0; k < KTOP; ++k) { key[k] = kNoKey; tile[k] = -1; }
-    }
-    // hi of the K-th best, or kNoKey>>4 when fewer than K candidates were seen
-    __device__ __forceinline__ int kth_hi() const { return key[KTOP - 1] >> 4; }
-    __device__ __forceinline__ bool full() const { return tile[KTOP - 1] >= 0; }
+    __device__ __forceinline__ void init() { key = kNoKey; tile = -1; }
+    // Smallest accumulator value that can still enter: needs 2*acc + npar > hi, possible iff acc >= ceil(hi / 2).
+    __device__ __forceinline__ int own_threshold() const { return tile >= 0 ? (((key >> 4) + 1) >> 1) : INT32_MIN; }
 
-    // Smallest accumulator value that can still enter: needs 2*acc + npar > kth_hi,
-    // possible iff acc >= ceil(kth_hi / 2).
-    __device__ __forceinline__ int own_threshold() const
-    {
-        return full() ? ((kth_hi() + 1) >> 1) : INT32_MIN;
-    }
-
-    // Exact update with the 16 candidates of tile `t`.  Returns true if the K-th best
-    // improved (the caller may then publish the new bound).
-    __device__ __forceinline__ bool update(const v16i& acc, const v16i& low, int t)
+    // Exact update with the 16 candidates of tile `t`.
+    __device__ __forceinline__ void update(const v16i& acc, const v16i& low, int t)
     {
         int k[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) k[r] = (acc[r] << 5) | low[r];
-        if constexpr (KTOP == 1) {
-            const int m0 = max(max(k[0], k[1]), k[2]);
-            const int m1 = max(max(k[3], k[4]), k[5]);
-            const int m2 = max(max(k[6], k[7]), k[8]);
-            const int m3 = max(max(k[9], k[10]), k[11]);
-            const int m4 = max(max(k[12], k[13]), k[14]);
-            const int km = max(max(max(m0, m1), m2), max(max(m3, m4), k[15]));
-            const bool up = (km >> 4) > (key[0] >> 4);
-            key[0] = up ? km : key[0];
-            tile[0] = up ? t : tile[0];
-            return up;
-        } else {
-            // tile top-2 by a merge tree of sorted pairs (keys inside a tile are unique)
-            int a1[8], a2[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { a1[i] = max(k[2 * i], k[2 * i + 1]); a2[i] = min(k[2 * i], k[2 * i + 1]); }
-            int b1[4], b2[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                b1[i] = max(a1[2 * i], a1[2 * i + 1]);
-                b2[i] = max(max(min(a1[2 * i], a1[2 * i + 1]), a2[2 * i]), a2[2 * i + 1]);
-            }
-            int c1[2], c2[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                c1[i] = max(b1[2 * i], b1[2 * i + 1]);
-                c2[i] = max(max(min(b1[2 * i], b1[2 * i + 1]), b2[2 * i]), b2[2 * i + 1]);
-            }
-            const int k1 = max(c1[0], c1[1]);
-            const int k2 = max(max(min(c1[0], c1[1]), c2[0]), c2[1]);
-            const int h1 = k1 >> 4, h2 = k2 >> 4, g1 = key[0] >> 4, g2 = key[1] >> 4;
-            const bool enter = h1 > g2;          // k1 beats the running 2nd
-            const bool first = h1 > g1;          // k1 beats the running 1st
-            const bool both  = h2 > g1;          // k2 also beats the running 1st
-            // new (1st, 2nd):  first & both -> (k1,k2);  first -> (k1, old1);  enter -> (old1, k1)
-            const int n0k = first ? k1 : key[0];
-            const int n0t = first ? t : tile[0];
-            const int n1k = first ? (both ? k2 : key[0]) : (enter ? k1 : key[1]);
-            const int n1t = first ? (both ? t : tile[0]) : (enter ? t : tile[1]);
-            key[0] = n0k; tile[0] = n0t; key[1] = n1k; tile[1] = n1t;
-            return enter;
-        }
+        const int m0 = max(max(k[0], k[1]), k[2]);
+        const int m1 = max(max(k[3], k[4]), k[5]);
+        const int m2 = max(max(k[6], k[7]), k[8]);
+        const int m3 = max(max(k[9], k[10]), k[11]);
+        const int m4 = max(max(k[12], k[13]), k[14]);
+        const int km = max(max(max(m0, m1), m2), max(max(m3, m4), k[15]));
+        const bool up = (km >> 4) > (key >> 4);
+        key = up ? km : key;
+        tile = up ? t : tile;
     }
 
-    // Decode slot k: hi and the reduced-bank row index (valid only if tile[k] >= 0).
-    __device__ __forceinline__ int hi(int k) const { return key[k] >> 4; }
-    __device__ __forceinline__ int index(int k, int h) const
-    {
-        return tile[k] * kTileRows + tile_row(15 - (key[k] & 15), h);
-    }
+    // hi and the row index inside the gathered subset (valid only if tile >= 0).
+    __device__ __forceinline__ int hi() const { return key >> 4; }
+    __device__ __forceinline__ int index(int h) const { return tile * kTileRows + tile_row(15 - (key & 15), h); }
 };
 
 // ---- the same state for the 16x16x64 tile shape (rowreduce.hip) ---------------------------
