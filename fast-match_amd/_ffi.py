@@ -79,6 +79,7 @@ SYMBOLS = {
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_mark": (_INT, [_P, ctypes.POINTER(_I64)]),
     "fm_wait": (_INT, [_P, _I64]),
+    "fm_expand_fetch_many": (_INT, [_P, ctypes.c_int32, _P, ctypes.POINTER(_I64), _P, _P, _P]),
     "fm_match_accepted_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
@@ -574,6 +575,18 @@ class Context(object):
 
     def sync(self):
         self._check(self.lib.fm_sync(self.handle))
+
+    def expand_fetch_many(self, expanders, counts):
+        """(index, positions, ratio) arrays of several Expanders after one ``expand_run``: every copy
+        enqueued, one synchronisation (``Expander.fetch`` costs one per pair)."""
+        n = len(expanders)
+        out = [(np.empty(c, dtype=np.int32), np.empty((c, 2, 2), dtype=np.float64), np.empty(c, dtype=np.float64)) for c in counts]
+        if n:
+            arr = lambda vals: (_P * n)(*[_P(int(v)) if v is not None else None for v in vals])
+            self._check(self.lib.fm_expand_fetch_many(self.handle, n, arr([e.handle.value for e in expanders]),
+                                                      (_I64 * n)(*[int(c) for c in counts]), arr([_ptr(o[0]) for o in out]),
+                                                      arr([_ptr(o[1]) for o in out]), arr([_ptr(o[2]) for o in out])))
+        return out
 
     def mark(self):
         """Ticket for "everything enqueued so far" (``wait(ticket)`` blocks until it is done, later work keeps running)."""

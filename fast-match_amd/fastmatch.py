@@ -108,7 +108,9 @@ def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=Fals
     where the device gave up (caller falls back to the host loop)."""
     out = []
     results = context.expand_run(expanders, seeds, taus)
-    for ex, (n_matches, n_rounds, n_pairs, status) in zip(expanders, results):
+    ok = [i for i, r in enumerate(results) if r[3] == 0]
+    fetched = dict(zip(ok, context.expand_fetch_many([expanders[i] for i in ok], [results[i][0] for i in ok])))
+    for i, (ex, (n_matches, n_rounds, n_pairs, status)) in enumerate(zip(expanders, results)):
         if status != 0:
             if stats is not None:
                 stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
@@ -118,7 +120,7 @@ def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=Fals
             stats["device_loops"] = stats.get("device_loops", 0) + 1
             stats["rounds"] = stats.get("rounds", 0) + n_rounds
             stats["pairs"] = stats.get("pairs", 0) + n_pairs
-        index, pos, ratio = ex.fetch(n_matches)
+        index, pos, ratio = fetched[i]
         if as_arrays:
             out.append((index, pos, ratio))
         else:

@@ -288,6 +288,11 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
  * (query x,y then target x,y) and ratio -- the tuples do_iter appends (fastmatch.pyx:86). */
 int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index,
                      double* positions, double* ratio);
+/* fm_expand_fetch for several pairs of one fm_expand_run with a single synchronisation: n[i] results of
+ * ex[i] into index[i] / positions[i] / ratio[i] (any of the three arrays of pointers, or single
+ * entries, may be NULL).                                                                          */
+int  fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int64_t* n,
+                          int32_t* const* index, double* const* positions, double* const* ratio);
 
 /* ---- result gather across the GPUs of a node (RCCL over xGMI) --------------------------------
  * Independent image pairs are sharded over ranks (one process per GPU, pair i -> rank i mod N);
