@@ -253,12 +253,10 @@ class MatchGatherer(object):
         self._start(k)
 
     def send_buffers(self):
-        """(rows int32[capacity, 3], count int64[1]) device tensors of the free slot."""
-        if self.on_cpu:
-            if self.fill_buf is None:
-                raise ValueError("send_buffers() needs device tensors (backend nccl, or fill_device=...)")
+        """(rows int32[pairs_per_step * capacity, 3], counts int64[pairs_per_step]) tensors of the free slot."""
+        if self.on_cpu and self.fill_buf is not None:
             return self.fill_buf[self.slot], self.fill_mine[self.slot]
-        return self.buf[self.slot], self.mine[self.slot]
+        return self.buf[self.slot], self.mine[self.slot]     # (pure CPU: host tensors the caller fills itself)
 
     def consumer_stream(self):
         """Raw handle of the stream the collectives of this gatherer are ordered on (torch's current
@@ -274,7 +272,7 @@ class MatchGatherer(object):
         self._wait()
         k = self.slot
         self.slot ^= 1
-        if self.on_cpu:                    # dry run: device buffers, CPU transport
+        if self.on_cpu and self.fill_buf is not None:      # dry run: device buffers, CPU transport
             self.buf[k].copy_(self.fill_buf[k])
             self.mine[k].copy_(self.fill_mine[k])
         self._start(k)

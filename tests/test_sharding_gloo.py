@@ -51,6 +51,28 @@ for r in range(world):
     assert int(counts[r]) == n_r, (rank, r, int(counts[r]), n_r)
     if r == rank:
         assert np.array_equal(rows[r, :n_r].numpy(), mine[:n_r])
+# whole steps: three pairs per step in one send buffer, ONE all-gather per step (what bench.py does at
+# N > 1 with fm_match_accepted_dev_batch; here the buffers are filled on the host)
+import torch
+PPS, CAP = 3, 16
+gs = sharding.MatchGatherer("cpu", capacity=CAP, pairs_per_step=PPS)
+assert gs.consumer_stream() is None
+for step in range(4):
+    rows_t, cnts_t = gs.send_buffers()
+    assert rows_t.shape == (PPS * CAP, 3) and cnts_t.shape == (PPS,)
+    for i in range(PPS):
+        m = (step + 2 * i + 3 * rank) %% (CAP + 1)
+        cnts_t[i] = m
+        rows_t[i * CAP:i * CAP + m] = torch.arange(m * 3, dtype=torch.int32).view(m, 3) + 1000 * rank + 100 * i + step
+    gs.submit_device()
+counts_s, rows_s = gs.finish()
+assert counts_s.shape == (world, PPS) and rows_s.shape == (world, PPS, CAP, 3)
+for r in range(world):
+    for i in range(PPS):
+        m = (3 + 2 * i + 3 * r) %% (CAP + 1)
+        assert int(counts_s[r, i]) == m, (rank, r, i)
+        exp = torch.arange(m * 3, dtype=torch.int32).view(m, 3) + 1000 * r + 100 * i + 3
+        assert torch.equal(rows_s[r, i, :m], exp), (rank, r, i)
 # ONE large problem, train rows sharded: election keys per shard (here from the CPU oracle, on
 # the GPU from fm_xcheck1_keys), one all-reduce(min), decode == the unsharded cross-check
 sys.path.insert(0, %r)
