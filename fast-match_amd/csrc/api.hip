@@ -69,7 +69,9 @@ struct fm_ctx {
         bool in_use = false;
     } aslot[2];
     int aslot_next = 0;
-    std::vector<AsyncSlot> bslot;           // fm_match_accepted_batch: one per position in the call
+    std::vector<AsyncSlot> bslot;           // fm_match_accepted_batch: a ring of kBatchSlots workspaces
+    static constexpr int kBatchSlots = 16;  // (two launches of up to 8 pairs in flight; a slot is re-used behind its tail's event)
+    int64_t bslot_next = 0;
     // fm_mark / fm_wait: points in the enqueued work a caller can wait for without draining what follows
     static constexpr int kMarks = 8;
     struct Mark { hipEvent_t ev[1 + kTails] = {nullptr, nullptr, nullptr, nullptr}; int64_t id = -1; } marks[kMarks];
@@ -1639,7 +1641,8 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
     auto batchable = [&](int i) {
         return q[i]->kind != FM_BANK_F32 && q[i]->n > 0 && t[i]->n > 0 && q[i]->selfdist != nullptr;
     };
-    if ((int)ctx->bslot.size() < n) ctx->bslot.resize((size_t)n);
+    static_assert(fm_ctx::kBatchSlots >= 2 * kRRBatchMax, "two full launches must find distinct workspaces");
+    if ((int)ctx->bslot.size() < fm_ctx::kBatchSlots) ctx->bslot.resize((size_t)fm_ctx::kBatchSlots);
     refresh_tuning(ctx);
     int i = 0;
     while (i < n) {
@@ -1680,6 +1683,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         }
         const bool coop = ctx->use_coop && pl.nsplit > 1;
         void* al[kRRBatchMax][5];
+        int slot_of[kRRBatchMax];
         SlotLayout L[kRRBatchMax];
         const Bank* cols[kRRBatchMax]; const Bank* red[kRRBatchMax];
         unsigned long long* part[kRRBatchMax]; int* bnd[kRRBatchMax];
@@ -1700,7 +1704,8 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
                     if (!al[j][u]) { ctx->timer_pool.push_back(tm); return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: host outputs must be page-locked (fm_host_alloc)"); }
                 *n_accepted[k] = 0;
             }
-            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
+            slot_of[j] = (int)(ctx->bslot_next++ % fm_ctx::kBatchSlots);
+            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             if (!sl.tail_done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming));
             L[j] = slot_layout(q[k]->n, pl);
             if ((rc = slot_prepare(ctx, sl, L[j], q[k]->n, pl, ctx->stream)) != FM_OK) { ctx->timer_pool.push_back(tm); return rc; }
@@ -1715,7 +1720,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         for (int j = 0; j < g; ++j) {
             const int k = i + j;
             hipStream_t ts = ctx->tails[j % fm_ctx::kTails];
-            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)k];
+            fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
             if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
                                    al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),

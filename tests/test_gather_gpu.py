@@ -521,3 +521,25 @@ def test_mark_and_wait_let_a_consumer_trail_the_enqueued_batches_by_one(ctx):
     with pytest.raises(_ffi.FastMatchHipError):
         ctx.wait(10 ** 6)
     ctx.sync()
+
+
+def test_batch_of_more_pairs_than_workspace_slots(ctx):
+    """20 same-shape pairs in one fm_match_accepted_batch call (launches of 8 + 8 + 2 + ... pairs; the
+    ring of 16 workspaces wraps inside the call), twice: every pair equals its synchronous call."""
+    base = [_banks(ctx, 2500, 33000, seed=300 + k) for k in range(5)]
+    pairs = [(base[k % 5][2], base[(k * 2 + 1) % 5][3]) for k in range(20)]          # 20 distinct (query, train) combinations
+    want = [ctx.match_accepted(qb, tb, 0.9) for qb, tb in pairs]
+    outs = [(ctx.pinned_empty(2500, np.int32), ctx.pinned_empty(2500, np.int32),
+             ctx.pinned_empty(2500, np.float32), ctx.pinned_empty(2500, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    block = ctx.prepare_batch(pairs, outs, counts)
+    for rep in range(2):
+        for c in counts:
+            c[0] = -1
+        ctx.match_accepted_batch(block, 0.9)
+        ctx.sync()
+        for j, ((qa, ta, da, ra), out, cnt) in enumerate(zip(want, outs, counts)):
+            m = int(cnt[0])
+            assert m == len(qa), j
+            assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta) and np.array_equal(out[3][:m], ra), j
+    assert sum(len(w[0]) for w in want) > 100
