@@ -223,6 +223,14 @@ def main():
     dev = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
     legs = not args.no_legs
 
+    # Steps are pipelined two deep by default (FM_BENCH_PIPELINE=0: one fm_sync per step): step i + 1 is
+    # enqueued before the host waits for step i (fm_mark / fm_wait, two output sets), so a step's ten pairs
+    # can share ONE distance-kernel launch -- its small kernels run beside the next step's launch.  Without
+    # the pipeline the library ends a run of pairs with a short launch instead (8 + 2).
+    pipelined = os.environ.get("FM_BENCH_PIPELINE", "1") != "0" and os.environ.get("FM_BENCH_SYNC") != "1"
+    if pipelined:
+        os.environ.setdefault("FM_BATCH_GROUP", "16")
+        os.environ.setdefault("FM_BATCH_TAIL", "0")
     import fastmatch_amd
     from fastmatch_amd import synth, sharding
     ctx = fastmatch_amd.Context(local_rank)
@@ -257,6 +265,13 @@ def main():
     dev_async = world > 1 and os.environ.get("FM_BENCH_SYNC") != "1"
     use_batch = use_async and os.environ.get("FM_BENCH_BATCH", "1") != "0"
     batch_args = ctx.prepare_batch(banks, outbufs, counts) if use_batch else None
+    counts_sets, batch_sets = [counts], [batch_args]
+    if use_batch and pipelined:                             # second output set for the two-deep pipeline
+        outbufs2 = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
+                     ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64)) for _ in range(PAIRS_PER_STEP)]
+        counts2 = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
+        counts_sets.append(counts2)
+        batch_sets.append(ctx.prepare_batch(banks, outbufs2, counts2))
 
     # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
     # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
@@ -270,6 +285,7 @@ def main():
     device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
     pair_args = ctx.prepare_pairs(banks) if step_gather else None
     h_counts = ctx.pinned_empty(PAIRS_PER_STEP, np.int64)
+    h_counts_sets = [h_counts, ctx.pinned_empty(PAIRS_PER_STEP, np.int64)]
     # FM_BENCH_GATHER=rccl: the library's own all-gather (fm_comm_init / fm_gather_matches, RCCL on the
     # matching stream) instead of torch.distributed's; the id travels by a torch broadcast
     abi_gather = None
@@ -284,8 +300,38 @@ def main():
                       "all_counts": torch.zeros(world, dtype=torch.int64, device=cdev)}
         gatherer = None
 
+    pipe = {"i": 0, "prev": None, "last": 0}
+
+    def consume(prev):                                      # the host reads step i's results while step i + 1 runs
+        s, ticket = prev
+        ctx.wait(ticket)
+        if use_async:
+            return int(sum(int(c[0]) for c in counts_sets[s]))
+        return int(h_counts_sets[s].sum())
+
+    def finish_steps():
+        if pipe["prev"] is not None:
+            pipe["last"] = consume(pipe["prev"])
+            pipe["prev"] = None
+        return pipe["last"]
+
     def step():
         n_acc = 0
+        if pipelined and (use_batch or step_gather):
+            s = pipe["i"] % 2
+            pipe["i"] += 1
+            if use_batch:
+                ctx.match_accepted_batch(batch_sets[s], TAU)
+            else:
+                rows, cnts = gatherer.send_buffers()
+                ctx.match_accepted_dev_batch(pair_args, TAU, rows.data_ptr(), cnts.data_ptr(), NQ, h_counts=h_counts_sets[s],
+                                             consumer_stream=gatherer.consumer_stream())
+                gatherer.submit_device()
+            ticket = ctx.mark()
+            if pipe["prev"] is not None:
+                pipe["last"] = consume(pipe["prev"])
+            pipe["prev"] = (s, ticket)
+            return pipe["last"]
         if use_async:
             if use_batch:                                   # pairs of one shape share distance-kernel launches
                 ctx.match_accepted_batch(batch_args, TAU)
@@ -340,8 +386,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish_steps()
     if gatherer is not None:
         gatherer.finish()
+    ctx.sync()
     ctx.reset_stats()
     barrier()
     torch.cuda.synchronize()
@@ -349,6 +397,8 @@ def main():
     npass = 0
     for _ in range(args.steps):
         npass = step()
+    if pipelined and (use_batch or step_gather):
+        npass = finish_steps()                              # the last step's results, still inside the timed region
     if gatherer is not None:
         gatherer.finish()
     if abi_gather is not None:
@@ -462,6 +512,8 @@ def main():
                 pmc = json.load(f)
             if pmc.get("k1_source_sha256") == k1_source_hash():
                 traffic, traffic_src, traffic_tag = pmc["hbm_bytes_per_launch"], pmc["source"], pmc.get("tag")
+                if pmc.get("image_pairs_per_launch"):       # counters are per dispatch: rescale to this run's launches
+                    traffic *= pairs_per_launch / float(pmc["image_pairs_per_launch"])
                 busy = pmc.get("mfma_pipe_busy_frac")
                 traffic_note = "counters collected from this kernel source (sha256 match)"
             else:

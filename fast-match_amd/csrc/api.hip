@@ -70,7 +70,7 @@ struct fm_ctx {
     } aslot[2];
     int aslot_next = 0;
     std::vector<AsyncSlot> bslot;           // fm_match_accepted_batch: a ring of kBatchSlots workspaces
-    static constexpr int kBatchSlots = 16;  // (two launches of up to 8 pairs in flight; a slot is re-used behind its tail's event)
+    static constexpr int kBatchSlots = 32;  // (two launches of up to 16 pairs in flight; a slot is re-used behind its tail's event)
     int64_t bslot_next = 0;
     // fm_mark / fm_wait: points in the enqueued work a caller can wait for without draining what follows
     static constexpr int kMarks = 8;
@@ -1580,7 +1580,7 @@ extern "C" int fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_b
 }
 
 // n image pairs in one call, enqueued like fm_match_accepted_async; runs of consecutive pairs of one
-// shape go through K1 TOGETHER (rowreduce_batch_kernel: up to FM_BATCH_GROUP = 8 pairs per launch), each
+// shape go through K1 TOGETHER (rowreduce_batch_kernel: up to FM_BATCH_GROUP pairs per launch, at most 16), each
 // pair's small kernels follow on one of three tail streams beside the next group's K1.
 // d_rows != NULL: device outputs (fm_match_accepted_dev_batch): pair i's rows at d_rows + i * cap * 3, its
 // count at d_counts + i, optionally also in the page-locked words h_counts[i]; host outputs otherwise.
@@ -1636,8 +1636,12 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
         for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_consumer, 0));
     }
-    static const int group_max = [] { const char* e = getenv("FM_BATCH_GROUP"); int v = e ? atoi(e) : kRRBatchMax;
+    // FM_BATCH_GROUP: most pairs per launch (default 8); FM_BATCH_TAIL: size of the short launch a run ends
+    // with (default 2; 0 = none, for callers that enqueue the next batch before they wait for this one:
+    // the small kernels of the last launch then overlap the next batch, see fm_mark / fm_wait)
+    static const int group_max = [] { const char* e = getenv("FM_BATCH_GROUP"); int v = e ? atoi(e) : 8;
                                       return v < 1 ? 1 : (v > kRRBatchMax ? kRRBatchMax : v); }();
+    static const int tail_n = [] { const char* e = getenv("FM_BATCH_TAIL"); int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }();
     auto batchable = [&](int i) {
         return q[i]->kind != FM_BANK_F32 && q[i]->n > 0 && t[i]->n > 0 && q[i]->selfdist != nullptr;
     };
@@ -1652,9 +1656,10 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         if (batchable(i))
             while (i + run < n && batchable(i + run) && q[i + run]->n_pad == q[i]->n_pad && t[i + run]->n_pad == t[i]->n_pad) ++run;
         int g = run;
-        if (run > group_max + 2) g = group_max;
-        else if (run > 4) g = run - 2 < group_max ? run - 2 : group_max;
+        if (run > group_max + tail_n) g = group_max;
+        else if (run > 4 && tail_n > 0) g = run - tail_n < group_max ? run - tail_n : group_max;
         if (g > group_max) g = group_max;
+        if (g < 1) g = 1;
         RowReducePlan pl;
         if (g > 1) {
             pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);

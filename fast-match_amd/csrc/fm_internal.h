@@ -105,7 +105,7 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
                              double* d_ratio, hipStream_t stream);
 
 // ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
-constexpr int kRRBatchMax = 8;            // bank pairs per batched row-reduce launch
+constexpr int kRRBatchMax = 16;           // bank pairs per batched row-reduce launch
 hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
                                   unsigned long long* const* partial, int* const* bound, hipStream_t stream);
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream);   // all pairs of one kind / capacity

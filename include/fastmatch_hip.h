@@ -179,11 +179,14 @@ int  fm_wait(fm_ctx* ctx, int64_t ticket);
 /* n independent image pairs in one call, enqueued like n fm_match_accepted_async calls (same output
  * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
  * fm_sync).  Consecutive pairs whose banks have the same padded sizes go through the distance kernel
- * TOGETHER, up to eight pairs per launch: inside one launch the workgroups of the next pair fill the
+ * TOGETHER, up to eight (FM_BATCH_GROUP: sixteen) pairs per launch: inside one launch the workgroups of the next pair fill the
  * CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
  * a 100k x 100k pair).  The reference maps its matcher over the pairs of a dataset one after the
  * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (float32
- * route, empty banks, a different shape) are enqueued one by one.                                */
+ * route, empty banks, a different shape) are enqueued one by one.  A run of pairs ends with a short
+ * launch (2 pairs) because only the LAST launch's small kernels are exposed to a caller that
+ * synchronises after the call; a caller that enqueues the next batch first (fm_mark / fm_wait) sets
+ * the environment variables FM_BATCH_TAIL=0 and FM_BATCH_GROUP=16 (read once) for one launch per run. */
 int  fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
                              int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
                              double* const* ratio, int64_t* const* n_accepted /*page-locked words*/);

@@ -61,6 +61,12 @@ if fs is not None and ws is not None:
     for rel in ("fast-match_amd/csrc/rowreduce.hip", "fast-match_amd/csrc/tile_ops.h"):
         h.update(open(os.path.join(os.environ["FM_REPO"], rel), "rb").read())
     d.update({"k1_source_sha256": h.hexdigest(), "tag": os.environ.get("FM_PROFILE_TAG", "")})
+    # image pairs per dispatch of that kernel in the profiled runs (the counters above are per dispatch)
+    try:
+        line = [l for l in open("bench_trace.json") if l.startswith("{")][-1]
+        d["image_pairs_per_launch"] = json.loads(line)["roofline"]["image_pairs_per_launch"]
+    except Exception:
+        d["image_pairs_per_launch"] = None
     json.dump(d, open("latest_pmc.json", "w"))
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     os.system("cp %s %s/kernel_stats.csv" % (f, out))
