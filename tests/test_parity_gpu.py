@@ -505,7 +505,7 @@ def test_f32_route_close_to_opencv_order(ctx):
     # The device accumulates the float32 chain in ONE fixed order (fma chain, oracle order 1:
     # bit-exact, tested above).  OpenCV's own order depends on the build -- generic unrolled-by-4
     # (order 0), 2.4.x SSE2 lanes (order 2), 4.x 128-bit SIMD lanes (order 3) -- and differs from
-    # the chain only in rounding.  Measured on BASELINE config 5 data (scripts/f32_ulp_report.py,
+    # the chain only in rounding.  Measured on BASELINE config 5 data (tests/tools/f32_ulp_report.py,
     # profiles/r02_f32_ulp_vs_opencv_orders.json): same neighbours in every row, distances
     # 0 ulp 34-36 %, <= 1 ulp 74-78 %, <= 2 ulp 95-97 %, max 5 ulp.  So the "within 1 ulp" of the
     # north star holds against the oracle's restatement of the device order, NOT against an

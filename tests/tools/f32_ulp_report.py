@@ -11,7 +11,7 @@ CPU only (the oracle): BASELINE config 5 data (synthetic SIFT + uniform(-0.5, 0.
 and the index agreement of the 2-NN lists and of the cross-checked match.
 """
 import argparse, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from fastmatch_amd import synth

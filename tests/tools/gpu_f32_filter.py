@@ -1,7 +1,7 @@
 """Float32 route: bf16x3 filter (K8) vs all-pairs kernel (K5) vs oracle -- parity and timing."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fastmatch_amd
 from fastmatch_amd import _ffi, synth
 import oracle

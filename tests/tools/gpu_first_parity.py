@@ -1,6 +1,6 @@
 """First-light GPU script: HIP path vs oracle on a ladder of sizes, both staging modes."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 import fastmatch_amd as fm

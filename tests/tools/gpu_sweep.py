@@ -2,7 +2,7 @@
 FM_GLDS); prints HIP-event kernel time for X1 and K2 at N x N.  Each variant also checks
 results (X1 against the first variant, K2 rows against the oracle)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 import fastmatch_amd as fm

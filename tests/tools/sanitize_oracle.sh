@@ -2,7 +2,7 @@
 # Host-side sanitizer pass (CPU only; GPU ASan is not available on this pool): builds the
 # oracle with AddressSanitizer + UBSan and runs the oracle known-answer tests against it.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -ffp-contract=off -fPIC -shared \
     -o /tmp/liboracle_asan.so oracle/bfmatch_oracle.c -lm
 cp oracle/liboracle.so /tmp/liboracle_backup.so
