@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 NQ = NT = 100000
 TAU = 0.7
 SEED = 20250002
-PAIRS_PER_STEP = 10               # independent 100k x 100k pairs per GPU and step (timed region >= 0.2 s at 20 steps)
+PAIRS_PER_STEP = 12               # independent 100k x 100k pairs per GPU and step (timed region >= 0.2 s at 20 steps)
 PROFILE_JSON = os.path.join(ROOT, "profiles", "latest_pmc.json")   # written by scripts/profile.sh
 K1_SOURCES = ("fast-match_amd/csrc/rowreduce.hip", "fast-match_amd/csrc/tile_ops.h")
 INT8_DENSE_PEAK_TOPS = 5000.0     # MI355X dense int8 MFMA (2x bf16's ~2.5 PF), MI355X_MICROARCH.md
@@ -224,7 +224,7 @@ def main():
     legs = not args.no_legs
 
     # Steps are pipelined two deep by default (FM_BENCH_PIPELINE=0: one fm_sync per step): step i + 1 is
-    # enqueued before the host waits for step i (fm_mark / fm_wait, two output sets), so a step's ten pairs
+    # enqueued before the host waits for step i (fm_mark / fm_wait, two output sets), so a step's twelve pairs
     # can share ONE distance-kernel launch -- its small kernels run beside the next step's launch.  Without
     # the pipeline the library ends a run of pairs with a short launch instead (8 + 2).
     pipelined = os.environ.get("FM_BENCH_PIPELINE", "1") != "0" and os.environ.get("FM_BENCH_SYNC") != "1"
