@@ -543,3 +543,42 @@ def test_batch_of_more_pairs_than_workspace_slots(ctx):
             assert m == len(qa), j
             assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta) and np.array_equal(out[3][:m], ra), j
     assert sum(len(w[0]) for w in want) > 100
+
+
+def test_batch_outputs_shorter_than_the_accepted_lists_are_truncated_not_overrun(ctx):
+    """Capacity smaller than the number of accepted matches (host and device outputs of the batch calls):
+    the count is the full number, the buffers hold the first `cap` rows in query order and nothing is
+    written beyond them."""
+    import torch
+    pairs_full = [_banks(ctx, 3000, 33000, seed=400 + k) for k in range(3)]
+    pairs = [(p[2], p[3]) for p in pairs_full]
+    want = [ctx.match_accepted(qb, tb, 0.9) for qb, tb in pairs]
+    cap = 64
+    assert all(len(w[0]) > cap for w in want)
+    guard = 16
+    outs, raw = [], []
+    for _ in pairs:
+        bufs = (ctx.pinned_empty(cap + guard, np.int32), ctx.pinned_empty(cap + guard, np.int32),
+                ctx.pinned_empty(cap + guard, np.float32), ctx.pinned_empty(cap + guard, np.float64))
+        for b in bufs:
+            b[:] = 77
+        raw.append(bufs)
+        outs.append(tuple(b[:cap] for b in bufs))
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    ctx.match_accepted_batch(pairs, 0.9, outs, counts)
+    ctx.sync()
+    for (qa, ta, da, ra), out, bufs, cnt in zip(want, outs, raw, counts):
+        assert int(cnt[0]) == len(qa)
+        assert np.array_equal(out[0], qa[:cap]) and np.array_equal(out[1], ta[:cap]) and np.array_equal(out[3], ra[:cap])
+        assert all((b[cap:] == 77).all() for b in bufs)
+    dev = torch.device("cuda", 0)
+    cnts = torch.zeros(len(pairs), dtype=torch.int64, device=dev)
+    # (device rows: pair i at rows_ptr + i * cap * 3 -- a flat buffer with the exact stride and a guard at the very end)
+    flat = torch.full((len(pairs) * cap + guard, 3), -7, dtype=torch.int32, device=dev)
+    ctx.match_accepted_dev_batch(pairs, 0.9, flat.data_ptr(), cnts.data_ptr(), cap)
+    ctx.sync()
+    got = flat.cpu().numpy()
+    for i, (qa, ta, da, ra) in enumerate(want):
+        assert int(cnts[i].item()) == len(qa)
+        assert np.array_equal(got[i * cap:(i + 1) * cap], sharding.pack_matches(qa, ta, da)[:cap])
+    assert (got[len(pairs) * cap:] == -7).all()
