@@ -53,6 +53,8 @@ _INT = ctypes.c_int
 SYMBOLS = {
     "fm_ctx_create": (_INT, [_INT, ctypes.POINTER(_P)]),
     "fm_ctx_destroy": (_INT, [_P]),
+    "fm_ctx_set_option": (_INT, [_P, ctypes.c_char_p, _I64]),
+    "fm_ctx_get_option": (_INT, [_P, ctypes.c_char_p, ctypes.POINTER(_I64)]),
     "fm_last_error": (ctypes.c_char_p, [_P]),
     "fm_sync": (_INT, [_P]),
     "fm_get_stats": (_INT, [_P, ctypes.POINTER(fm_stats)]),
@@ -278,6 +280,17 @@ class Context(object):
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
+        "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
+        "async_time_every", "expand_big", "expand_prof".  Results never depend on them."""
+        self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = _I64(0)
+        self._check(self.lib.fm_ctx_get_option(self.handle, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def pinned_empty(self, shape, dtype):
         """ndarray in page-locked host memory (lives as long as the context): pass it as an

@@ -34,11 +34,8 @@ struct fm_ctx {
     void*  ws_partial = nullptr; size_t ws_partial_bytes = 0;
     void*  ws_out = nullptr;     size_t ws_out_bytes = 0;
     void*  ws_in = nullptr;      size_t ws_in_bytes = 0;
-    // configuration (env overridable, for experiments)
-    int force_nb = 0, force_nsplit = 0, force_nw = 0;
-    bool use_glds = true;
-    bool use_coop = true;   // cross-block K-th-best bounds (rowreduce.hip)
-    int  f32_filter = 1;    // float32 route: 0 = K5 only, 1 = fp16 filter for large calls, 2 = always
+    // configuration: fm_ctx_set_option (the FM_* environment variables seed it at creation)
+    Tuning tune;
     int* d_counters = nullptr;   // device words of the fp16 filter (layout: fm_internal.h, launch_filter)
     int64_t filter_launches = 0;
     unsigned long long* h_scratch = nullptr;   // pinned host words the kernels can write (counts)
@@ -102,6 +99,17 @@ static int fail(fm_ctx* ctx, int code, const std::string& msg)
         }                                                                                   \
     } while (0)
 
+// Ablation builds only (-DFM_ABLATE, scripts/ablate): FM_ABLATE_KEEP_BOUNDS leaves the bounds of a finished
+// run in place (measures what the exact path costs).  The product build always resets them.
+static inline bool ablate_keep_bounds()
+{
+#ifdef FM_ABLATE
+    return getenv("FM_ABLATE_KEEP_BOUNDS") != nullptr;
+#else
+    return false;
+#endif
+}
+
 static int ws_ensure(fm_ctx* ctx, void** p, size_t* cap, size_t need)
 {
     if (need <= *cap && *p) return FM_OK;
@@ -117,7 +125,8 @@ static int ws_ensure(fm_ctx* ctx, void** p, size_t* cap, size_t need)
 // ---------------------------------------------------------------------------------------
 // One 256-thread block per 32-row tile; thread (r = tid>>3, c = tid&7) owns the 16 bytes
 // [16c, 16c+16) of tile row r.  SRC_F32: source rows are float32; values are converted to
-// uint8 and *nonint is raised if any value is not an integer in [0,255].
+// uint8 and nonint[0] is raised if any value is not an integer in [0,255]; nonint[1] = max over the
+// rows of the squared norm of the uint8 row (Bank::usq_max).
 template <bool SRC_F32>
 __global__ __launch_bounds__(256)
 void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
@@ -129,7 +138,7 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
     const int64_t tile = blockIdx.x;
     const int64_t row = tile * kTileRows + r;
     unsigned w[4] = {0, 0, 0, 0};
-    int sumsq = 0;
+    int sumsq = 0, usq = 0;
     bool bad = false;
     if (row < n) {
 #pragma unroll
@@ -148,6 +157,7 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
                     } else {
                         u = ((const uint8_t*)src)[row * dim + k];
                     }
+                    usq += u * u;
                 }
                 const int s = u - 128;               // == (int8)(u ^ 0x80)
                 sumsq += s * s;
@@ -160,6 +170,13 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
     sumsq += __shfl_xor(sumsq, 1);
     sumsq += __shfl_xor(sumsq, 2);
     sumsq += __shfl_xor(sumsq, 4);
+    usq += __shfl_xor(usq, 1);
+    usq += __shfl_xor(usq, 2);
+    usq += __shfl_xor(usq, 4);
+    usq = max(usq, __shfl_xor(usq, 8));
+    usq = max(usq, __shfl_xor(usq, 16));
+    usq = max(usq, __shfl_xor(usq, 32));
+    if ((tid & 63) == 0 && usq > 0) atomicMax(nonint + 1, usq);
     if (c == 0) {
         // aux words of the 32-row unit in the accumulator order of v_mfma_i32_16x16x64_i8
         // (two 16-row tiles; tile row rr sits in lane group rr >> 2, register rr & 3)
@@ -263,7 +280,9 @@ void bank_prep_f16_kernel(const float* __restrict__ rowsf, int64_t n, int64_t n_
 // knnMatch(k=2): merge nsplit partial top-2 lists per query row (keys are (d2<<32)|idx,
 // ascending = cv::batchDistance order) and emit idx / sqrtf(d2).
 // Partial keys carry the exact integer d2 (int8 route) or the float32 bits of the distance
-// itself (float32 route) in their high word; both orders are the distance order.
+// itself (float32 route) in their high word.  The d2 order is OpenCV's (float32 distance, index)
+// order as long as the second best d2 stays below kSqrtTieMin (tile_ops.h); output rows beyond that
+// are listed in fix[] (fix[0] = count, rows from fix[4] on) and redone by sqrt_fix_kernel<2>.
 __device__ __forceinline__ float key_dist(unsigned long long key, int f32)
 {
     const unsigned hi = (unsigned)(key >> 32);
@@ -272,7 +291,7 @@ __device__ __forceinline__ float key_dist(unsigned long long key, int f32)
 
 __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial, int nsplit,
                                   int ncols_alloc, int64_t n, int32_t* __restrict__ idx,
-                                  float* __restrict__ dist, int f32)
+                                  float* __restrict__ dist, int f32, unsigned* __restrict__ fix = nullptr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -290,18 +309,84 @@ __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial
     idx[2 * i + 1] = (b1 == ~0ull) ? -1 : (int32_t)(unsigned)b1;
     dist[2 * i]     = (b0 == ~0ull) ? INFINITY : key_dist(b0, f32);
     dist[2 * i + 1] = (b1 == ~0ull) ? INFINITY : key_dist(b1, f32);
+    if (fix && b1 != ~0ull && (unsigned)(b1 >> 32) >= kSqrtTieMin) fix[4 + atomicAdd(fix, 1u)] = (unsigned)i;
+}
+
+// Exact repair of the output rows listed in fix[] (see knn2_merge_kernel / xcheck_scatter_kernel): one
+// workgroup per listed row scans ALL reduced rows with exact integer arithmetic and orders them the way
+// cv::batchDistance does, by (float32 bits of sqrtf(d2), index).  KTOP = 2: rewrites the row's 2-NN
+// list; KTOP = 1: the row is a train row, the winner is the query row it elects -> scatter-min into
+// qbest (the step xcheck_scatter_kernel left out for this row).  Cold: rows whose K-th best d2 is
+// >= kSqrtTieMin = 4 197 200 (SIFT descriptors: d2 <= 1.05e6).
+template <int KTOP>
+__global__ __launch_bounds__(256)
+void sqrt_fix_kernel(const unsigned* __restrict__ fix, const int8_t* __restrict__ col_rows,
+                     const int32_t* __restrict__ col_norm, const int8_t* __restrict__ red_rows,
+                     const int32_t* __restrict__ red_norm, int nred,
+                     unsigned long long* __restrict__ qbest, unsigned t_offset,
+                     int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ unsigned long long best[2];
+    const int tid = threadIdx.x;
+    const unsigned n = fix[0];
+    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+        const unsigned c = fix[4 + e];
+        if (tid == 0) { best[0] = ~0ull; best[1] = ~0ull; }
+        __syncthreads();
+        v4i cr[kDim / 16];
+#pragma unroll
+        for (int w = 0; w < kDim / 16; ++w) cr[w] = *(const v4i*)(col_rows + (size_t)c * kDim + 16 * w);
+        const int cn = col_norm[c];
+        unsigned long long k0 = ~0ull, k1 = ~0ull;
+        for (int m = tid; m < nred; m += 256) {
+            int dot = 0;
+#pragma unroll
+            for (int w = 0; w < kDim / 16; ++w) {
+                const v4i y = *(const v4i*)(red_rows + (size_t)m * kDim + 16 * w);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot = __builtin_amdgcn_sdot4(cr[w][u], y[u], dot, false);
+            }
+            const unsigned d2 = (unsigned)(cn + red_norm[m] - 2 * dot);
+            const unsigned long long key = ((unsigned long long)sqrt_bits(d2) << 32) | (unsigned)m;
+            if (key < k0) { k1 = k0; k0 = key; }
+            else if (key < k1) k1 = key;
+        }
+        if (k0 != ~0ull) atomicMin(&best[0], k0);
+        __syncthreads();
+        const unsigned long long g0 = best[0];
+        if constexpr (KTOP == 2) {
+            const unsigned long long mine = (k0 == g0) ? k1 : k0;
+            if (mine != ~0ull) atomicMin(&best[1], mine);
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long g1 = best[1];
+                idx[2 * (size_t)c]     = (g0 == ~0ull) ? -1 : (int32_t)(unsigned)g0;
+                idx[2 * (size_t)c + 1] = (g1 == ~0ull) ? -1 : (int32_t)(unsigned)g1;
+                dist[2 * (size_t)c]     = (g0 == ~0ull) ? INFINITY : __uint_as_float((unsigned)(g0 >> 32));
+                dist[2 * (size_t)c + 1] = (g1 == ~0ull) ? INFINITY : __uint_as_float((unsigned)(g1 >> 32));
+            }
+        } else {
+            if (tid == 0 && g0 != ~0ull)
+                atomicMin(&qbest[(unsigned)g0], (g0 & 0xffffffff00000000ull) | (unsigned long long)(c + t_offset));
+        }
+        __syncthreads();
+    }
 }
 
 // Cross-check step 2: train row t elects rq = argmin_q d(q,t)
 // (lowest q on ties) = min over the split partials; then scatter-min of (d2<<32 | t)
 // into qbest[rq]: q keeps the closest electing train row, lowest t on ties.  64-bit
-// atomicMin is order independent, so the result is deterministic.
+// atomicMin is order independent, so the result is deterministic.  The key's high word is the float32
+// distance (bits of sqrtf(d2); f32: the partial keys carry those bits already): OpenCV compares the
+// distances, and above kSqrtTieMin two d2 can share one.  fix != null: a train row whose best d2 shares
+// its root with d2 + 1 may elect a LOWER query index that sits at d2 + 1 -- it is listed in fix[] and
+// left to sqrt_fix_kernel<1>.
 // bound_reset (async calls): the K1 that produced `partial` is complete, so its bound[] array is
 // put back to "no bound" here for the next K1 that uses this workspace slot.
 __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ partial, int nsplit,
                                       int ncols_alloc, int64_t nt,
-                                      unsigned long long* __restrict__ qbest, unsigned t_offset = 0,
-                                      int* __restrict__ bound_reset = nullptr)
+                                      unsigned long long* __restrict__ qbest, unsigned t_offset, int f32,
+                                      int* __restrict__ bound_reset, unsigned* __restrict__ fix)
 {
     // four lanes per train row, each takes every 4th split: short independent load chains
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,19 +406,23 @@ __global__ void xcheck_scatter_kernel(const unsigned long long* __restrict__ par
     b = o < b ? o : b;
     if (t >= nt || part != 0 || b == ~0ull) return;
     const unsigned q = (unsigned)b;
+    unsigned hi = (unsigned)(b >> 32);
+    if (!f32) {
+        if (fix && hi >= kSqrtTieMin && sqrt_ties_up(hi)) { fix[4 + atomicAdd(fix, 1u)] = (unsigned)t; return; }
+        hi = sqrt_bits(hi);
+    }
     // (t_offset: global index of this bank's first row when the train set is sharded over ranks)
-    const unsigned long long key = (b & 0xffffffff00000000ull) | (unsigned long long)((unsigned)t + t_offset);
+    const unsigned long long key = ((unsigned long long)hi << 32) | (unsigned long long)((unsigned)t + t_offset);
     atomicMin(&qbest[q], key);
 }
 
-// Cross-check step 3 + optional R1: decode qbest, distance = sqrtf(d2) (float32, exact
-// for integer d2 < 2^24), ratio = (double)dist / selfdist[q] in float64, pass = ratio < tau
+// Cross-check step 3 + optional R1: decode qbest (high word = float32 distance bits), ratio = (double)dist / selfdist[q] in float64, pass = ratio < tau
 // (fastmatch.pyx:124,165; :50,75,82).
 __global__ void xcheck_finalize_kernel(const unsigned long long* qbest, int64_t nq,
                                        const double* __restrict__ selfdist, double tau,
                                        int32_t* __restrict__ tidx, float* __restrict__ dist,
                                        double* __restrict__ ratio, uint8_t* __restrict__ pass,
-                                       unsigned long long* __restrict__ npass, int f32,
+                                       unsigned long long* __restrict__ npass,
                                        int* __restrict__ block_counts,
                                        unsigned long long* qbest_reset = nullptr)
 {
@@ -348,7 +437,7 @@ __global__ void xcheck_finalize_kernel(const unsigned long long* qbest, int64_t 
         double r = NAN;
         if (key != ~0ull) {
             ti = (int32_t)(unsigned)key;
-            d = key_dist(key, f32);
+            d = __uint_as_float((unsigned)(key >> 32));
             if (selfdist) { r = (double)d / selfdist[q]; p = r < tau; }
         }
         tidx[q] = ti;
@@ -510,15 +599,40 @@ extern "C" const char* fm_last_error(const fm_ctx* ctx)
     return copy.c_str();
 }
 
-// FM_TUNE_LIVE=1: the launch-shape overrides are re-read before every plan (A/B runs inside one
-// process, scripts/gpu_k12_ab.py); otherwise they are read once when the context is created.
-static void refresh_tuning(fm_ctx* ctx)
+// Options of a context by name (include/fastmatch_hip.h lists them).
+struct OptionDef { const char* name; int Tuning::* field; int lo, hi; const char* env; };
+static const OptionDef kOptions[] = {
+    {"nb", &Tuning::nb, 0, 8, "FM_NB"}, {"nsplit", &Tuning::nsplit, 0, 1 << 20, "FM_NSPLIT"}, {"nw", &Tuning::nw, 0, 16, "FM_NW"},
+    {"nbuf", &Tuning::nbuf, 0, 3, "FM_NBUF"}, {"prio", &Tuning::prio, 0, 1, "FM_PRIO"},
+    {"glds", &Tuning::glds, 0, 1, "FM_GLDS"}, {"coop", &Tuning::coop, 0, 1, "FM_COOP"},
+    {"f32_filter", &Tuning::f32_filter, 0, 2, "FM_F32_FILTER"}, {"f32_nw", &Tuning::f32_nw, 0, 8, "FM_F32_NW"},
+    {"f32_nsplit", &Tuning::f32_nsplit, 0, 1 << 20, "FM_F32_NSPLIT"}, {"f32_fused", &Tuning::f32_fused, -1, 1, "FM_F32_FUSED"},
+    {"f32_lpc", &Tuning::f32_lpc, 0, 64, "FM_F32_LPC"},
+    {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
+    {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
+    {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
+};
+
+extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value)
 {
-    if (!getenv("FM_TUNE_LIVE")) return;
-    const char* s;
-    ctx->force_nb = (s = getenv("FM_NB")) ? atoi(s) : 0;
-    ctx->force_nsplit = (s = getenv("FM_NSPLIT")) ? atoi(s) : 0;
-    ctx->force_nw = (s = getenv("FM_NW")) ? atoi(s) : 0;
+    if (!ctx || !name) return fail(ctx, FM_EINVAL, "fm_ctx_set_option: NULL argument");
+    for (const OptionDef& o : kOptions) {
+        if (strcmp(o.name, name) != 0) continue;
+        if (value < o.lo || value > o.hi) return fail(ctx, FM_EINVAL, std::string("fm_ctx_set_option: value out of range for ") + name);
+        if (o.field == &Tuning::f32_filter && value != 0 && !ctx->d_counters)
+            return fail(ctx, FM_EDEVICE, "fm_ctx_set_option: the fp16 filter's counters could not be allocated on this context");
+        ctx->tune.*(o.field) = (int)value;
+        return FM_OK;
+    }
+    return fail(ctx, FM_EINVAL, std::string("fm_ctx_set_option: unknown option ") + name);
+}
+
+extern "C" int fm_ctx_get_option(fm_ctx* ctx, const char* name, int64_t* value)
+{
+    if (!ctx || !name || !value) return fail(ctx, FM_EINVAL, "fm_ctx_get_option: NULL argument");
+    for (const OptionDef& o : kOptions)
+        if (strcmp(o.name, name) == 0) { *value = ctx->tune.*(o.field); return FM_OK; }
+    return fail(ctx, FM_EINVAL, std::string("fm_ctx_get_option: unknown option ") + name);
 }
 
 extern "C" int fm_ctx_destroy(fm_ctx* ctx);
@@ -579,16 +693,15 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
         }
     }
     if (hipHostMalloc((void**)&ctx->h_scratch, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_scratch = nullptr; }
-    if (const char* s = getenv("FM_NB")) ctx->force_nb = atoi(s);
-    if (const char* s = getenv("FM_NSPLIT")) ctx->force_nsplit = atoi(s);
-    if (const char* s = getenv("FM_NW")) ctx->force_nw = atoi(s);
-    if (const char* s = getenv("FM_GLDS")) ctx->use_glds = atoi(s) != 0;
-    if (const char* s = getenv("FM_COOP")) ctx->use_coop = atoi(s) != 0;
-    if (const char* s = getenv("FM_F32_FILTER")) ctx->f32_filter = atoi(s);
+    // defaults from the environment (experiments; a value out of range is ignored), then per context
+    // through fm_ctx_set_option
+    for (const OptionDef& o : kOptions)
+        if (o.env) if (const char* s = getenv(o.env)) { const long v = atol(s); if (v >= o.lo && v <= o.hi) ctx->tune.*(o.field) = (int)v; }
+    if (getenv("FM_EXPAND_NO_BIG")) ctx->tune.expand_big = 0;
     if (hipMalloc((void**)&ctx->d_counters, filter_flag_bytes()) != hipSuccess || hipMemset(ctx->d_counters, 0, filter_flag_bytes()) != hipSuccess) {
         (void)hipGetLastError();
         ctx->d_counters = nullptr;
-        ctx->f32_filter = 0;
+        ctx->tune.f32_filter = 0;
     }
     *out = ctx;
     return FM_OK;
@@ -931,7 +1044,7 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     BTRY(hipMalloc((void**)&b->norm, (size_t)b->n_pad * 4));
     BTRY(hipMalloc((void**)&b->aux, (size_t)(b->n_pad / kTileRows) * kAuxPerTile * 4));
     if (src_bytes) BTRY(hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
-    BTRY(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
     const int ntiles = (int)(b->n_pad / kTileRows);
     if (f32)
         hipLaunchKernelGGL(bank_prep_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream,
@@ -940,9 +1053,11 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
         hipLaunchKernelGGL(bank_prep_kernel<false>, dim3(ntiles), dim3(256), 0, ctx->stream,
                            (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag);
     BTRY(hipGetLastError());
-    int flag = 0;
-    BTRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    int flags[2] = {0, 0};
+    BTRY(hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
     BTRY(hipStreamSynchronize(ctx->stream));
+    const int flag = flags[0];
+    b->usq_max = flags[1];
     if (f32 && (flag || (keep_f32 && n > 0))) {
         // not integer-valued (or the caller wants the float32 route): keep a float32 bank for the fma-chain route
         b->kind = FM_BANK_F32;
@@ -1047,10 +1162,10 @@ static int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const cha
 // Leaves the packed keys in ws_partial in `pl`'s layout (K5's plan) either way.
 static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* red, int ktop, RowReducePlan* pl_out)
 {
-    const RowReducePlan pl = plan_rowreduce_f32(cols->n_pad, red->n_pad, ctx->force_nsplit);
+    const RowReducePlan pl = plan_rowreduce_f32(cols->n_pad, red->n_pad, ctx->tune.nsplit);
     *pl_out = pl;
-    const bool filter = ctx->f32_filter != 0 && filter_usable(*cols, *red) &&
-                        (ctx->f32_filter >= 2 || (double)cols->n * (double)red->n >= 4.0e6);
+    const bool filter = ctx->tune.f32_filter != 0 && filter_usable(*cols, *red) &&
+                        (ctx->tune.f32_filter >= 2 || (double)cols->n * (double)red->n >= 4.0e6);
     const size_t part = (pl.partial_bytes(ktop) + 255) & ~(size_t)255;
     if (!filter) {
         int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part);
@@ -1060,7 +1175,7 @@ static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* 
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         return FM_OK;
     }
-    const FilterPlan fp = plan_filter(cols->n_pad, red->n_pad);
+    const FilterPlan fp = plan_filter(cols->n_pad, red->n_pad, ctx->tune);
     int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part + fp.slots_bytes() + fp.bound_bytes() + 64);
     if (rc != FM_OK) return rc;
     unsigned long long* d_part = (unsigned long long*)ctx->ws_partial;
@@ -1074,6 +1189,36 @@ static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* 
     HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, d_part, ctx->d_counters, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->filter_launches += 1;
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// float32-root ties of the integer route (tile_ops.h: kSqrtTieMin)
+// ---------------------------------------------------------------------------------------
+constexpr int kFixGrid = 1024;                 // workgroups of a sqrt_fix_kernel launch (each walks the list)
+static inline size_t fix_bytes(int64_t rows) { return ((size_t)rows * 4 + 16 + 15) & ~(size_t)15; }
+
+// Election of the cross-check on stream s: per train row the minimum over K1's split partials, scatter-min
+// into qbest; for bank pairs whose norms allow d2 >= kSqrtTieMin, the listed rows are then redone exactly.
+// fix: device words [4 + nt] (only touched for such pairs).
+static int enqueue_election(fm_ctx* ctx, hipStream_t s, const fm_bank* q, const fm_bank* t,
+                            const unsigned long long* partial, const RowReducePlan& pl,
+                            unsigned long long* qbest, unsigned t_offset, int* bound_reset, unsigned* fix)
+{
+    const int64_t nt = t->n;
+    const int f32 = q->kind == FM_BANK_F32;
+    const bool guard = !f32 && fix && sqrt_tie_possible(*q, *t);
+    if (guard) HIP_TRY(ctx, hipMemsetAsync(fix, 0, 16, s));
+    const int64_t sthreads = (bound_reset && (int64_t)pl.ncols_alloc > nt * 4) ? (int64_t)pl.ncols_alloc : nt * 4;
+    hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, s,
+                       partial, pl.nsplit, pl.ncols_alloc, nt, qbest, t_offset, f32, bound_reset, guard ? fix : (unsigned*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    if (guard) {
+        hipLaunchKernelGGL(sqrt_fix_kernel<1>, dim3(kFixGrid), dim3(256), 0, s, (const unsigned*)fix,
+                           (const int8_t*)t->rows8, (const int32_t*)t->norm, (const int8_t*)q->rows8, (const int32_t*)q->norm,
+                           (int)q->n, qbest, t_offset, (int32_t*)nullptr, (float*)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     return FM_OK;
 }
 
@@ -1097,23 +1242,31 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     if (f32) {
         if ((rc = rowreduce_f32_route(ctx, q, t, 2, &pl)) != FM_OK) return rc;
     } else {
-        refresh_tuning(ctx);
-        pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes())) != FM_OK) return rc;
+        pl = plan_rowreduce(q->n_pad, t->n_pad, ctx->tune);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(2) + pl.bound_bytes() + fix_bytes(nq))) != FM_OK) return rc;
         int* d_bound = nullptr;
-        if (ctx->use_coop && pl.nsplit > 1) {
+        if ((ctx->tune.coop != 0) && pl.nsplit > 1) {
             d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(2));      // bound1 | bound2 (rowreduce.hip)
-            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc * 2, ctx->stream));
+            if (!ablate_keep_bounds()) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc * 2, ctx->stream));
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce(*q, *t, 2, pl, (unsigned long long*)ctx->ws_partial, d_bound, (ctx->tune.glds != 0), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     }
     ctx->kernel_timed = true;
     ctx->pending_pairs += nq * t->n;
+    // (output rows whose second best d2 reaches kSqrtTieMin are redone in OpenCV's float32 order)
+    unsigned* d_fix = (!f32 && sqrt_tie_possible(*q, *t)) ? (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(2) + pl.bound_bytes()) : nullptr;
+    if (d_fix) HIP_TRY(ctx, hipMemsetAsync(d_fix, 0, 16, ctx->stream));
     hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nq, d_idx, d_dist, f32);
+                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nq, d_idx, d_dist, f32, d_fix);
     HIP_TRY(ctx, hipGetLastError());
+    if (d_fix) {
+        hipLaunchKernelGGL(sqrt_fix_kernel<2>, dim3(kFixGrid), dim3(256), 0, ctx->stream, (const unsigned*)d_fix,
+                           (const int8_t*)q->rows8, (const int32_t*)q->norm, (const int8_t*)t->rows8, (const int32_t*)t->norm,
+                           (int)t->n, (unsigned long long*)nullptr, 0u, d_idx, d_dist);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     return FM_OK;
 }
 
@@ -1211,11 +1364,11 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 static const hipStream_t kNoStream = (hipStream_t)FM_NO_STREAM;
 
 struct SlotLayout {
-    size_t pbytes, a_qbest, a_tidx, a_dist, a_ratio, a_pass, a_bc, a_end;
+    size_t pbytes, a_qbest, a_tidx, a_dist, a_ratio, a_pass, a_bc, a_fix, a_end;
     int nblk;
 };
 
-static SlotLayout slot_layout(int64_t nq, const RowReducePlan& pl)
+static SlotLayout slot_layout(int64_t nq, int64_t nt, const RowReducePlan& pl)
 {
     SlotLayout L;
     L.nblk = (int)((nq + 255) / 256);
@@ -1223,7 +1376,9 @@ static SlotLayout slot_layout(int64_t nq, const RowReducePlan& pl)
     const size_t bbytes = ((size_t)pl.ncols_alloc * 4 + 15) & ~(size_t)15;
     L.a_qbest = L.pbytes + bbytes; L.a_tidx = L.a_qbest + (size_t)nq * 8; L.a_dist = L.a_tidx + (size_t)nq * 4;
     L.a_ratio = (L.a_dist + (size_t)nq * 4 + 7) & ~(size_t)7; L.a_pass = L.a_ratio + (size_t)nq * 8;
-    L.a_bc = (L.a_pass + (size_t)nq + 15) & ~(size_t)15; L.a_end = L.a_bc + (size_t)L.nblk * 4 + 16;
+    L.a_bc = (L.a_pass + (size_t)nq + 15) & ~(size_t)15;
+    L.a_fix = (L.a_bc + (size_t)L.nblk * 4 + 16 + 15) & ~(size_t)15;       // tie-repair list (enqueue_election)
+    L.a_end = L.a_fix + fix_bytes(nt);
     return L;
 }
 
@@ -1265,7 +1420,7 @@ static int take_timer(fm_ctx* ctx, fm_ctx::PendingTimer* tm)
 // which must already wait for that K1.  Host outputs (a_* = device aliases of page-locked memory) or,
 // with dev_rows, the 12-byte rows of the result gather.  Leaves the slot's bound[] / qbest[] clean.
 static int enqueue_tail(fm_ctx* ctx, hipStream_t ts, fm_ctx::AsyncSlot& sl, const SlotLayout& L, const fm_bank* q,
-                        int64_t nq, int64_t nt, const RowReducePlan& pl, double tau, int64_t compact_cap,
+                        const fm_bank* t, int64_t nq, int64_t nt, const RowReducePlan& pl, double tau, int64_t compact_cap,
                         void* a_q, void* a_t, void* a_d, void* a_r, void* a_c,
                         int32_t* dev_rows, long long* dev_count, hipStream_t consumer)
 {
@@ -1279,13 +1434,12 @@ static int enqueue_tail(fm_ctx* ctx, hipStream_t ts, fm_ctx::AsyncSlot& sl, cons
     uint8_t* s_pass = (uint8_t*)(sb + L.a_pass);
     int* s_bc = (int*)(sb + L.a_bc);
     if (nt > 0) {
-        const int64_t sthreads = nt * 4 > (int64_t)pl.ncols_alloc ? nt * 4 : (int64_t)pl.ncols_alloc;
-        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ts,
-                           (const unsigned long long*)s_partial, pl.nsplit, pl.ncols_alloc, nt, s_qbest, 0u, s_bound);
+        int rc = enqueue_election(ctx, ts, q, t, s_partial, pl, s_qbest, 0u, s_bound, (unsigned*)(sb + L.a_fix));
+        if (rc != FM_OK) return rc;
     }
     hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ts,
                        (const unsigned long long*)s_qbest, nq, (const double*)q->selfdist, tau, s_tidx, s_dist, s_ratio,
-                       s_pass, (unsigned long long*)nullptr, 0, s_bc, s_qbest);
+                       s_pass, (unsigned long long*)nullptr, s_bc, s_qbest);
     if (dev_rows) {
         // the rows go to the caller's device buffers, which a consumer stream (the result gather)
         // reads: the compaction waits for what that stream has been given so far (the gather that
@@ -1346,10 +1500,9 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     RowReducePlan pl;
     int* d_bound = nullptr;
     if (!f32) {
-        refresh_tuning(ctx);
-        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
-        if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
+        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->tune);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes() + fix_bytes(nt))) != FM_OK) return rc;
+        if ((ctx->tune.coop != 0) && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
     }
 
     if (async_mode) {
@@ -1367,25 +1520,25 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         tm.pairs = nq * nt;
         fm_ctx::AsyncSlot& sl = ctx->aslot[ctx->aslot_next];
         ctx->aslot_next ^= 1;
-        const SlotLayout L = slot_layout(nq, pl);
+        const SlotLayout L = slot_layout(nq, nt, pl);
         if ((rc = slot_prepare(ctx, sl, L, nq, pl, ctx->stream)) != FM_OK) return rc;
-        const bool coop = ctx->use_coop && pl.nsplit > 1;
+        const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
         // Every event record is a packet the K1 launches of consecutive calls queue behind; the
         // start-of-kernel event is therefore taken for every async_time_every-th call only (those
         // calls are the ones fm_get_stats accounts as timed K1 launches; FM_ASYNC_TIME_EVERY, default 4).
-        static const int time_every = [] { const char* e = getenv("FM_ASYNC_TIME_EVERY"); return e ? atoi(e) : 4; }();
+        const int time_every = ctx->tune.async_time_every;
         const bool timed_call = time_every > 0 && (ctx->async_calls++ % time_every) == 0;
         tm.timed = tm.timed && timed_call;
         tm.call_timed = timed_call;
         if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
         if (nt > 0)
             HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)sl.ws, coop ? (int*)((char*)sl.ws + L.pbytes) : nullptr,
-                                          ctx->use_glds, ctx->stream));
+                                          (ctx->tune.glds != 0), ctx->stream));
         // (untimed calls hand over through the slot's own event, created without timing)
         hipEvent_t handover = timed_call ? tm.k1 : sl.k_done;
         HIP_TRY(ctx, hipEventRecord(handover, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_tail, handover, 0));
-        if ((rc = enqueue_tail(ctx, ctx->stream_tail, sl, L, q, nq, nt, pl, tau, compact_cap, a_q, a_t, a_d, a_r, a_c,
+        if ((rc = enqueue_tail(ctx, ctx->stream_tail, sl, L, q, t, nq, nt, pl, tau, compact_cap, a_q, a_t, a_d, a_r, a_c,
                                to_device ? dev_rows : nullptr, dev_count, consumer)) != FM_OK) return rc;
         if (timed_call) HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream_tail));
         HIP_TRY(ctx, hipEventRecord(sl.tail_done, ctx->stream_tail));
@@ -1400,24 +1553,24 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
     if (!compact) HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
     if (nt > 0) {
         if (d_bound)
-            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            if (!ablate_keep_bounds()) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         if (f32) {
             if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
         } else {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, (ctx->tune.glds != 0), ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
-        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest);
-        HIP_TRY(ctx, hipGetLastError());
+        // (the float32 route's partial layout has no tie list behind it, and needs none)
+        unsigned* d_fix = f32 ? nullptr : (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(1) + pl.bound_bytes());
+        if ((rc = enqueue_election(ctx, ctx->stream, q, t, (const unsigned long long*)ctx->ws_partial, pl, d_qbest, 0u, nullptr, d_fix)) != FM_OK) return rc;
     }
     hipLaunchKernelGGL(xcheck_finalize_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)d_qbest, nq, with_ratio ? (const double*)q->selfdist : (const double*)nullptr,
                        tau, d_tidx, d_dist, with_ratio ? d_ratio : (double*)nullptr,
-                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr, f32,
+                       with_ratio ? d_pass : (uint8_t*)nullptr, with_ratio ? d_cnt : (unsigned long long*)nullptr,
                        compact ? (int*)(base + o_bc) : (int*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long cnt = 0;
@@ -1523,28 +1676,26 @@ static int xcheck1_keys_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
     RowReducePlan pl;
     int* d_bound = nullptr;
     if (!f32) {
-        refresh_tuning(ctx);
-        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes())) != FM_OK) return rc;
-        if (ctx->use_coop && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
+        pl = plan_rowreduce(t->n_pad, q->n_pad, ctx->tune);
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pl.partial_bytes(1) + pl.bound_bytes() + fix_bytes(nt))) != FM_OK) return rc;
+        if ((ctx->tune.coop != 0) && pl.nsplit > 1) d_bound = (int*)((char*)ctx->ws_partial + pl.partial_bytes(1));
     }
     CallScope cs(ctx);
     HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
     if (nt > 0) {
         if (d_bound)
-            if (!getenv("FM_ABLATE_KEEP_BOUNDS")) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            if (!ablate_keep_bounds()) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
         if (f32) {
             if ((rc = rowreduce_f32_route(ctx, t, q, 1, &pl)) != FM_OK) return rc;
         } else {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, ctx->use_glds, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce(*t, *q, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, (ctx->tune.glds != 0), ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
-        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((nt * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, (unsigned)t_offset);
-        HIP_TRY(ctx, hipGetLastError());
+        unsigned* d_fix = f32 ? nullptr : (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(1) + pl.bound_bytes());
+        if ((rc = enqueue_election(ctx, ctx->stream, q, t, (const unsigned long long*)ctx->ws_partial, pl, d_qbest, (unsigned)t_offset, nullptr, d_fix)) != FM_OK) return rc;
     }
     if (keys_on_device) HIP_TRY(ctx, hipMemcpyAsync(keys, d_qbest, (size_t)nq * 8, hipMemcpyDeviceToDevice, ctx->stream));
     else HIP_TRY(ctx, d2h(ctx, keys, d_qbest, (size_t)nq * 8));
@@ -1580,7 +1731,7 @@ extern "C" int fm_match_accepted_async(fm_ctx* ctx, const fm_bank* q, const fm_b
 }
 
 // n image pairs in one call, enqueued like fm_match_accepted_async; runs of consecutive pairs of one
-// shape go through K1 TOGETHER (rowreduce_batch_kernel: up to FM_BATCH_GROUP pairs per launch, at most 16), each
+// shape go through K1 TOGETHER (rowreduce_batch_kernel: up to `batch_group` pairs per launch, at most 16), each
 // pair's small kernels follow on one of three tail streams beside the next group's K1.
 // d_rows != NULL: device outputs (fm_match_accepted_dev_batch): pair i's rows at d_rows + i * cap * 3, its
 // count at d_counts + i, optionally also in the page-locked words h_counts[i]; host outputs otherwise.
@@ -1636,18 +1787,15 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         HIP_TRY(ctx, hipEventRecord(ctx->ev_consumer, consumer));
         for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamWaitEvent(ts, ctx->ev_consumer, 0));
     }
-    // FM_BATCH_GROUP: most pairs per launch (default 8); FM_BATCH_TAIL: size of the short launch a run ends
+    // options batch_group: most pairs per launch (default 8); batch_tail: size of the short launch a run ends
     // with (default 2; 0 = none, for callers that enqueue the next batch before they wait for this one:
     // the small kernels of the last launch then overlap the next batch, see fm_mark / fm_wait)
-    static const int group_max = [] { const char* e = getenv("FM_BATCH_GROUP"); int v = e ? atoi(e) : 8;
-                                      return v < 1 ? 1 : (v > kRRBatchMax ? kRRBatchMax : v); }();
-    static const int tail_n = [] { const char* e = getenv("FM_BATCH_TAIL"); int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }();
+    const int group_max = ctx->tune.batch_group, tail_n = ctx->tune.batch_tail;
     auto batchable = [&](int i) {
         return q[i]->kind != FM_BANK_F32 && q[i]->n > 0 && t[i]->n > 0 && q[i]->selfdist != nullptr;
     };
     static_assert(fm_ctx::kBatchSlots >= 2 * kRRBatchMax, "two full launches must find distinct workspaces");
     if ((int)ctx->bslot.size() < fm_ctx::kBatchSlots) ctx->bslot.resize((size_t)fm_ctx::kBatchSlots);
-    refresh_tuning(ctx);
     int i = 0;
     while (i < n) {
         // run of same-shape pairs from i on, then this launch's share of it: a launch's small kernels overlap
@@ -1662,9 +1810,8 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         if (g < 1) g = 1;
         RowReducePlan pl;
         if (g > 1) {
-            pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->force_nb, ctx->force_nsplit, ctx->force_nw);
-            const char* nb = getenv("FM_NBUF");
-            if (pl.nb != 4 || pl.nw != 8 || !ctx->use_glds || (nb && atoi(nb) == 2)) g = 1;     // shapes the batched kernel is not built for
+            pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->tune);
+            if (pl.nb != 4 || pl.nw != 8 || !(ctx->tune.glds != 0) || pl.nbuf == 2) g = 1;     // shapes the batched kernel is not built for
         }
         if (g == 1) {                  // an odd pair: the single-pair async call (which also reports its errors)
             if (to_dev) {
@@ -1686,7 +1833,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             ++i;
             continue;
         }
-        const bool coop = ctx->use_coop && pl.nsplit > 1;
+        const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
         void* al[kRRBatchMax][5];
         int slot_of[kRRBatchMax];
         SlotLayout L[kRRBatchMax];
@@ -1712,7 +1859,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             slot_of[j] = (int)(ctx->bslot_next++ % fm_ctx::kBatchSlots);
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             if (!sl.tail_done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming));
-            L[j] = slot_layout(q[k]->n, pl);
+            L[j] = slot_layout(q[k]->n, t[k]->n, pl);
             if ((rc = slot_prepare(ctx, sl, L[j], q[k]->n, pl, ctx->stream)) != FM_OK) { ctx->timer_pool.push_back(tm); return rc; }
             cols[j] = t[k]; red[j] = q[k];            // reverse NN: output rows = train rows, reduced over the query rows
             part[j] = (unsigned long long*)sl.ws;
@@ -1727,7 +1874,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             hipStream_t ts = ctx->tails[j % fm_ctx::kTails];
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
-            if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
+            if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], t[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
                                    al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),
                                    kNoStream)) != FM_OK) { ctx->pending.push_back(tm); return rc; }     // (events are in flight: drained at fm_sync)
             HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));
@@ -1989,6 +2136,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;
     P.t_rows8 = d->target->rows8; P.t_norm = d->target->norm;
     P.f32 = f32 ? 1 : 0;
+    P.tie_guard = (!f32 && sqrt_tie_possible(*d->query, *d->target)) ? 1 : 0;
     P.rf = RoundF32{};
     if (f32) fill_round_f32(&P.rf, *d->query, *d->target);
     P.cell_off = (const int64_t*)(b + o_coff); P.t_pos = (const double*)(b + o_tpos);
@@ -2001,7 +2149,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.m_index = (int32_t*)(b + o_mi); P.m_pos = (double*)(b + o_mp); P.m_ratio = (double*)(b + o_mr);
     P.match_cap = match_cap;
     P.result = (long long*)(b + o_res);
-    P.prof = getenv("FM_EXPAND_PROF") ? 1 : 0;
+    P.prof = 0;                        // (set per run from the context's expand_prof option)
     *out = ex;
     return FM_OK;
 }
@@ -2050,6 +2198,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         host[i].seeds = ex->d_seeds;
         host[i].n_seeds = n_seeds[i];
         host[i].tau = tau[i];
+        host[i].prof = ctx->tune.expand_prof;
     }
     // the int8 and the float32 pairs are two kernels: descriptors grouped by kind, one launch each
     std::vector<ExpandPair> grouped;
@@ -2071,7 +2220,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // the start, in the larger-capacity variant of the kernel (int8 banks); the rest keep their results.
     {
         std::vector<int> redo;
-        for (int i = 0; i < n; ++i) if (res[(size_t)i * 4 + 3] == 2 && !host[i].f32 && !getenv("FM_EXPAND_NO_BIG")) redo.push_back(i);
+        for (int i = 0; i < n; ++i) if (res[(size_t)i * 4 + 3] == 2 && !host[i].f32 && ctx->tune.expand_big) redo.push_back(i);
         if (!redo.empty()) {
             grouped.clear();
             for (int i : redo) {
@@ -2088,7 +2237,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         }
     }
     for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
-    if (getenv("FM_EXPAND_PROF")) {
+    if (ctx->tune.expand_prof) {
         long long pr[16];
         (void)hipMemcpy(pr, pairs[0]->dev.result, sizeof(pr), hipMemcpyDeviceToHost);
         static const char* names[12] = {"pop:barrier", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "pop:thread0",

@@ -43,7 +43,7 @@ struct ExpCfg {
     static constexpr int kSR = CAND <= 2048 ? 512 : 256;                     // query rows gathered per staging step
     static constexpr int kStageBytes = kSR * kDim + kSR / 32 * 256;
     static constexpr int kPosCap = (kStageBytes - CAND * 8) / 32;            // accepted matches whose positions are kept in LDS
-    static constexpr int kLdsBytes = kStageBytes + CAND * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + 128 * 8;
+    static constexpr int kLdsBytes = kStageBytes + CAND * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + kTbestWords * 8;
     // float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
     static constexpr int kClistCap = (CAND * (8 + 4) + 2 * 1024 * 4) / 4;
     static_assert((1 << kSlotBits) >= CAND, "slot bits");
@@ -348,7 +348,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<const int32_t> idx_order, idx_start;
         double idx_bucket, idx_x0, idx_y0; int idx_nbx, idx_nby;
         gptr<const int8_t> t_rows8; gptr<const int32_t> t_norm; gptr<const int64_t> cell_off; gptr<const double> t_pos;
-        int width, height, cell_w, cell_h, rows, cols, margin, radius, f32;
+        int width, height, cell_w, cell_h, rows, cols, margin, radius, f32, tie_guard;
         gptr<const double> seeds; int64_t n_seeds; double tau;
         gptr<double> stack; int64_t stack_cap;
         gptr<unsigned long long> seen; int64_t seen_cap;
@@ -363,7 +363,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.t_rows8 = (gptr<const int8_t>)M.t_rows8; P.t_norm = (gptr<const int32_t>)M.t_norm;
     P.cell_off = (gptr<const int64_t>)M.cell_off; P.t_pos = (gptr<const double>)M.t_pos;
     P.width = M.width; P.height = M.height; P.cell_w = M.cell_w; P.cell_h = M.cell_h;
-    P.rows = M.rows; P.cols = M.cols; P.margin = M.margin; P.radius = M.radius; P.f32 = M.f32;
+    P.rows = M.rows; P.cols = M.cols; P.margin = M.margin; P.radius = M.radius; P.f32 = M.f32; P.tie_guard = M.tie_guard;
     P.seeds = (gptr<const double>)M.seeds; P.n_seeds = M.n_seeds; P.tau = M.tau;
     P.stack = (gptr<double>)M.stack; P.stack_cap = M.stack_cap;
     P.seen = (gptr<unsigned long long>)M.seen; P.seen_cap = M.seen_cap;
@@ -543,7 +543,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (!ok) { status = kExpListFull; break; }
         } else {
             x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
-                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.prof ? pt : nullptr, &tstamp);
+                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp);
         }
         lds_barrier();
 
@@ -562,8 +562,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
-                    // high word: exact integer d^2 (int8 route) or the float32 distance bits (float32 route)
-                    const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : sqrtf((float)(unsigned)(qb >> 32));
+                    // high word: the float32 distance bits (both routes)
+                    const float d = __uint_as_float((unsigned)(qb >> 32));
                     // the positions step (b) needs ride on the same memory round trip as the self distance
                     const int qrow = cand[i];
                     t_local = (int)(unsigned)qb;

@@ -23,6 +23,7 @@ struct ExpandPair {
     int width, height, cell_w, cell_h, rows, cols, margin, radius;
     // float32 route (banks that are not integer valued): planes and scale terms of both banks
     int      f32;                  // non-zero: x1_round_f32 instead of the int8 round
+    int      tie_guard;            // int8 round: the banks' norms allow d2 >= kSqrtTieMin (tile_ops.h)
     RoundF32 rf;
     // run inputs
     const double* seeds;           // [n_seeds][2][2]

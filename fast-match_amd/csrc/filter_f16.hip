@@ -553,11 +553,12 @@ void rescan_kernel(RParams p, int nred)
     }
 }
 
-FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
+FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
 {
     FilterPlan pl;
-    pl.nw = 4;
-    if (const char* e = getenv("FM_F32_NW")) { const int v = atoi(e); if (v == 4 || v == 8) pl.nw = v; }
+    pl.nw = (tn.f32_nw == 4 || tn.f32_nw == 8) ? tn.f32_nw : 4;
+    pl.fused = tn.f32_fused;
+    pl.lpc = tn.f32_lpc;
     pl.nc = 4;                                        // (NC = 2 at 4 waves/SIMD was tried: it spills)
     const int cb = 16 * pl.nc * pl.nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
@@ -576,7 +577,7 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad)
         if (nsplit > nstages / 4) nsplit = nstages / 4;
         if (nsplit < 1) nsplit = 1;
     }
-    if (const char* e = getenv("FM_F32_NSPLIT")) { const int v = atoi(e); if (v > 0) nsplit = v; }
+    if (tn.f32_nsplit > 0) nsplit = tn.f32_nsplit;
     if (nsplit > nstages) nsplit = nstages > 0 ? nstages : 1;
     int64_t per = (nstages + nsplit - 1) / nsplit;
     if (per < 1) per = 1;
@@ -629,7 +630,7 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     p.bound = bound;
     p.flag = flag;
     p.fused = (pl.nsplit == 1 && cols.n > 0) ? 1 : 0;
-    if (const char* e = getenv("FM_F32_FUSED")) p.fused = (atoi(e) != 0 && pl.nsplit == 1 && cols.n > 0) ? 1 : 0;
+    if (pl.fused >= 0) p.fused = (pl.fused != 0 && pl.nsplit == 1 && cols.n > 0) ? 1 : 0;
     p.col_rowsf = cols.rowsf;
     p.red_rowsf = red.rowsf;
     p.partial = partial;
@@ -666,7 +667,7 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
         // then runs a chain), else 16 or 64 lanes share a row's slots
         const int nslots = pl.nsplit * 4 * kFP;
         int lpc = nslots <= 32 ? (cols.n >= 65536 ? 1 : 16) : 64;
-        if (const char* e = getenv("FM_F32_LPC")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 64) lpc = v; }
+        if (pl.lpc == 1 || pl.lpc == 16 || pl.lpc == 64) lpc = pl.lpc;
         const int rgrid = (int)((cols.n * lpc + 255) / 256);
 #define FM_LAUNCH_RESCORE(K_)                                                                                  \
         do {                                                                                                   \

@@ -34,6 +34,7 @@ struct Bank {
     int8_t*  rows8  = nullptr;
     int32_t* norm   = nullptr;
     int32_t* aux    = nullptr;
+    int32_t  usq_max = 0;      // FM_BANK_I8: largest |row|^2 of the uint8 rows (sqrt_tie_possible below)
     float*   rowsf  = nullptr; // FM_BANK_F32: [n_pad][128] float32, zero padded
     // FM_BANK_F32, for the fp16 filter (filter_f16.hip); "scaled" = times 2^kscale:
     uint16_t* rowsh = nullptr; // [n_pad][128] fp16 of the scaled rows
@@ -43,6 +44,34 @@ struct Bank {
     int      kscale = 0;       // largest scaled magnitude lies in [2^13, 2^14)
     bool     filt_ok = false;  // every value is finite
     double*  selfdist = nullptr;
+};
+
+// OpenCV orders candidates by the float32 root of d2; the integer route orders by d2, which is the same
+// order unless a d2 reaches 4 197 200, where two integers start to share a float32 root (kSqrtTieMin,
+// tile_ops.h).  Rows are non-negative, so d2(a, b) <= |a|^2 + |b|^2: a bank pair whose largest row
+// norms stay below that can skip every repair step (all SIFT banks: |d|^2 ~ 2.6e5).
+inline bool sqrt_tie_possible(const Bank& a, const Bank& b)
+{
+    return (int64_t)a.usq_max + (int64_t)b.usq_max >= 4197200;
+}
+
+// ---- per-context tuning (fm_ctx_set_option; the FM_* environment variables only seed the defaults
+// when a context is created) -------------------------------------------------------------------
+struct Tuning {
+    int nb = 0, nsplit = 0, nw = 0;   // K1 launch shape overrides, 0 = the built-in rule
+    int nbuf = 0;                     // K1 LDS stage buffers: 0 = 3 for the top-1 kernel, 2 for top-2
+    int prio = 1;                     // s_setprio around a unit's MFMA burst (three-buffer kernel)
+    int glds = 1;                     // LDS-DMA staging (0: through registers)
+    int coop = 1;                     // cross-workgroup K-th-best bounds
+    int f32_filter = 1;               // float32 route: 0 = K5 only, 1 = fp16 filter for large calls, 2 = always
+    int f32_nw = 0, f32_nsplit = 0;   // K8 launch shape overrides
+    int f32_fused = -1;               // K8: rescoring inside the filter (-1 = when the plan has one split)
+    int f32_lpc = 0;                  // K8 rescoring: lanes per output row (0 = rule)
+    int batch_group = 8;              // fm_match_accepted_batch: most pairs per distance-kernel launch (<= kRRBatchMax)
+    int batch_tail = 2;               // ... pairs of the short launch a run ends with (0 = none)
+    int async_time_every = 4;         // async calls: every n-th call carries kernel timing events (0 = none)
+    int expand_big = 1;               // K7: re-run pairs that overflow the 2048-row round in the 4096-row variant
+    int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
 };
 
 // ---- K1: row-reduce kernel launcher ---------------------------------------------------
@@ -57,10 +86,12 @@ struct RowReducePlan {
     int nchunks;
     int nsplit;
     int stages_per_split;
+    int nbuf = 0;      // stage buffers (0 = rule: 3 for top-1, 2 for top-2)
+    int prio = 1;      // s_setprio around the MFMA burst
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 4 * 2; }   // (top-2 launches keep two arrays)
 };
-RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw);
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn);
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
                             unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream);
 
@@ -83,10 +114,11 @@ struct FilterPlan {
     int nchunks;
     int nsplit;
     int stages_per_split;   // 128-row stages
+    int fused = -1, lpc = 0; // Tuning::f32_fused / f32_lpc
     size_t slots_bytes() const { return (size_t)nsplit * ncols_alloc * 16 * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 8; }   // best and 2nd best
 };
-FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad);
+FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn);
 int filter_empty_bound();
 size_t filter_flag_bytes();       // size of the device words launch_filter's `flag` points at
 bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry filter planes of compatible scale

@@ -7,13 +7,15 @@
 namespace fm {
 
 // x1_round_wsplit: on return (after the caller's next __syncthreads) qbest[slot], slot in
-// [0, nq), holds (d2 << 32 | local train index) of the cross-checked match of query slot `slot`,
-// or ~0.  q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
+// [0, nq), holds (float32 bits of the distance << 32 | local train index) of the cross-checked match
+// of query slot `slot`, or ~0 (the distance itself, not d2: OpenCV compares the square roots, and
+// above kSqrtTieMin two d2 can share one; tile_ops.h).  q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
 // qbest must be pre-filled with ~0 for slots [0, nq) (visible to all threads).  The bank pointers are
 // global-memory pointers (gptr, tile_ops.h): callers convert theirs once.
 // SR = query rows gathered per staging step (128 in round_kernel, 512 in expand_kernel so that a
 // typical round needs ONE global round trip); smem must hold SR * 128 + SR / 32 * 256 bytes.
 // NT = threads of the workgroup (256 in round_kernel, 512 in expand_kernel).
+// tie_guard: the banks' row norms allow d2 >= kSqrtTieMin (uniform); tbest must hold kTbestWords words.
 //
 // Every wave owns ALL four 32-column
 // blocks of a 128-column chunk (four independent MFMA chains per tile, so the dependent
@@ -21,12 +23,14 @@ namespace fm {
 // four waves' reverse-NN candidates meet in an LDS table tbest[128] through 64-bit
 // atomicMin on (d2 << 32 | slot) -- min d2, then lowest slot, exactly the order
 // cv::batchDistance keeps -- before the scatter-min into qbest.
+constexpr int kTbestWords = 128 + 4;       // 128 train rows of a chunk + the tie repair's two masks and its accumulator
+
 template <int SR, int NT = 256>
 __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr<const int32_t> q_norm,
                                                 const int* q_rows, int nq,
                                                 gptr<const int8_t> t_rows8, gptr<const int32_t> t_norm,
                                                 int64_t t0, int nt, char* smem, unsigned long long* qbest,
-                                                unsigned long long* tbest /* LDS [128] */,
+                                                unsigned long long* tbest /* LDS [kTbestWords] */, int tie_guard,
                                                 long long* pt = nullptr, long long* ts = nullptr)
 {
 #define X1_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
@@ -153,10 +157,48 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             }
         }
         lds_barrier();
+        bool tied = false;                               // (rows whose election the float32 root may change)
         if (tid < 128 && cb0 + tid < nt) {
             const unsigned long long tb = tbest[tid];
-            if (tb != ~0ull)
-                atomicMin(&qbest[(unsigned)tb], (tb & 0xffffffff00000000ull) | (unsigned)(cb0 + tid));
+            if (tb != ~0ull) {
+                const unsigned d2 = (unsigned)(tb >> 32);
+                tied = tie_guard && d2 >= kSqrtTieMin && sqrt_ties_up(d2);
+                if (!tied)
+                    atomicMin(&qbest[(unsigned)tb], ((unsigned long long)sqrt_bits(d2) << 32) | (unsigned)(cb0 + tid));
+            }
+        }
+        if (tie_guard) {
+            // Cold path (never with SIFT-range descriptors): train row n's best d2 shares its float32
+            // root with d2 + 1, so a query slot at d2 + 1 with a LOWER slot number is the one OpenCV
+            // elects.  Exact rescan of the slots below the elected one, row by row.
+            if (tid < 128) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(tied);
+                if (lane == 0) tbest[128 + wave] = m;
+            }
+            lds_barrier();
+            for (int w = 0; w < 2; ++w) {
+                unsigned long long m = tbest[128 + w];          // (the same in every lane: kept scalar)
+                m = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)m);
+                while (m) {
+                    const int f = 64 * w + (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const unsigned long long tb = tbest[f];
+                    const unsigned d2 = (unsigned)(tb >> 32), smin = (unsigned)tb;
+                    unsigned* acc = (unsigned*)&tbest[130];
+                    if (tid == 0) *acc = smin;
+                    lds_barrier();
+                    gptr<const int8_t> trow = t_rows8 + (size_t)(t0 + cb0 + f) * kDim;
+                    const int tn = t_norm[t0 + cb0 + f];
+                    for (unsigned s = tid; s < smin; s += NT) {
+                        const int qi = q_rows[s];
+                        if (exact_d2_i8(q_rows8 + (size_t)qi * kDim, q_norm[qi], trow, tn) == d2 + 1u) atomicMin(acc, s);
+                    }
+                    lds_barrier();
+                    if (tid == 0) atomicMin(&qbest[*acc], ((unsigned long long)sqrt_bits(d2) << 32) | (unsigned)(cb0 + f));
+                    lds_barrier();
+                }
+            }
         }
         lds_barrier();
         X1_STAMP(11);

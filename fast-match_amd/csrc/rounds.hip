@@ -10,10 +10,10 @@
 //      (int8 MFMA tiles, same in-lane reduction as rowreduce.hip; query rows are gathered
 //      128 at a time into a swizzled LDS image, their accumulator-init words are built on
 //      the fly from the bank's row norms),
-//   2. scatter-min of (d2 << 32 | t) into an LDS table indexed by query slot
-//      (ds_min_u64; SURVEY.md Appendix A.3: lowest t wins ties),
-//   3. decode: tidx, dist = sqrtf(d2), ratio = double(dist) / selfdist[q_row]  (float64,
-//      fastmatch.pyx:165).
+//   2. scatter-min of (float32 bits of sqrtf(d2) << 32 | t) into an LDS table indexed by query
+//      slot (ds_min_u64; SURVEY.md Appendix A.3: lowest t wins ties -- ties of the float32
+//      distance, which is what OpenCV compares),
+//   3. decode: tidx, dist, ratio = double(dist) / selfdist[q_row]  (float64, fastmatch.pyx:165).
 // Rounds are tiny (~400 x 125 descriptors), so the kernel is latency bound; what matters
 // is that a round costs one launch and no host round trip between its three steps.
 #include "round_body.h"
@@ -35,6 +35,7 @@ struct RoundParams {
     int32_t*       tidx;          // device [tot]
     float*         dist;
     double*        ratio;         // may be null
+    int            tie_guard;     // the banks' norms allow d2 >= kSqrtTieMin (tile_ops.h)
 };
 
 __global__ __launch_bounds__(256)
@@ -42,7 +43,7 @@ void round_kernel(RoundParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[kStageBytes];
     __shared__ unsigned long long qbest[kRoundQCap];
-    __shared__ unsigned long long tbest[128];
+    __shared__ unsigned long long tbest[kTbestWords];
 
     const int tid  = threadIdx.x;
     const int b    = blockIdx.x;
@@ -56,7 +57,7 @@ void round_kernel(RoundParams p)
     __syncthreads();
     if (nq > 0 && nt > 0)
         x1_round_wsplit<kStageRows>((gptr<const int8_t>)p.q_rows8, (gptr<const int32_t>)p.q_norm, p.q_rows + q0, nq,
-                                    (gptr<const int8_t>)p.t_rows8, (gptr<const int32_t>)p.t_norm, t0, nt, smem, qbest, tbest);
+                                    (gptr<const int8_t>)p.t_rows8, (gptr<const int32_t>)p.t_norm, t0, nt, smem, qbest, tbest, p.tie_guard);
     __syncthreads();
     for (int i = tid; i < nq; i += 256) {
         const unsigned long long key = qbest[i];
@@ -65,7 +66,7 @@ void round_kernel(RoundParams p)
         double r = NAN;
         if (key != ~0ull) {
             ti = (int32_t)(unsigned)key;
-            d = sqrtf((float)(unsigned)(key >> 32));
+            d = __uint_as_float((unsigned)(key >> 32));
             if (p.q_selfdist) r = (double)d / p.q_selfdist[p.q_rows[q0 + i]];
         }
         p.tidx[q0 + i] = ti;
@@ -156,6 +157,7 @@ hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, 
     p.q_rows = d_q_rows; p.q_off = d_q_off;
     p.t_rows8 = t.rows8; p.t_norm = t.norm; p.t_off = d_t_off;
     p.tidx = d_tidx; p.dist = d_dist; p.ratio = d_ratio;
+    p.tie_guard = sqrt_tie_possible(q, t) ? 1 : 0;
     hipLaunchKernelGGL(round_kernel, dim3((unsigned)n_rounds), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

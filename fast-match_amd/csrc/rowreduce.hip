@@ -391,9 +391,12 @@ void rowreduce_batch_kernel(RRBatch b)
     rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
 }
 
-RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, int force_nsplit, int force_nw)
+RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
 {
+    const int force_nb = tn.nb, force_nsplit = tn.nsplit, force_nw = tn.nw;
     RowReducePlan pl;
+    pl.nbuf = (tn.nbuf == 2 || tn.nbuf == 3) ? tn.nbuf : 0;
+    pl.prio = tn.prio;
     const int64_t nstages = nred_pad / kStageRows;
     // nb = blocks of 16 output rows per wave: 4 (64 rows, ~110 VGPRs, 4 waves/SIMD) by default,
     // 8 via FM_NB; nw = waves per workgroup sharing the staged tiles: 8 for big problems,
@@ -427,23 +430,21 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, int force_nb, 
 }
 
 // stage buffers: 3 for the top-1 kernel (its DMA wait leaves the hand-over), 2 for top-2 (at the
-// 128-VGPR limit the third buffer's bookkeeping spills); FM_NBUF overrides (read per launch)
-static int nbuf_choice(int ktop)
+// 128-VGPR limit the third buffer's bookkeeping spills); the plan (Tuning::nbuf) overrides
+static int nbuf_choice(int ktop, int plan_nbuf)
 {
-    if (const char* e = getenv("FM_NBUF")) { const int v = atoi(e); if (v == 2 || v == 3) return v; }
+    if (plan_nbuf == 2 || plan_nbuf == 3) return plan_nbuf;
     return ktop == 1 ? 3 : 2;
 }
 
 template <int NC, int KTOP, int NW>
-static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t stream)
+static hipError_t launch_t(const RRParams& p, int grid, bool glds, int plan_nbuf, bool prio, hipStream_t stream)
 {
     if constexpr (NW == 8) {
         // PRIO: s_setprio 2 while a wave issues a unit's 16 MFMAs as one burst, back to 0 for the
-        // epilogue (A/B on one box: 0.897 -> 0.887 ms); FM_PRIO=0 selects the variant without it.
+        // epilogue (A/B on one box: 0.897 -> 0.887 ms); Tuning::prio = 0 selects the variant without it.
         // (The two-buffer top-2 kernel gets 1 % slower with it: 1.034 -> 1.044 ms.)
-        const char* pe = getenv("FM_PRIO");
-        const bool prio = !(pe && atoi(pe) == 0);
-        if (glds && nbuf_choice(KTOP) == 3) {
+        if (glds && nbuf_choice(KTOP, plan_nbuf) == 3) {
             if (prio) hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 1>), dim3(grid), dim3(64 * NW), 0, stream, p);
             else      hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 0>), dim3(grid), dim3(64 * NW), 0, stream, p);
             return hipGetLastError();
@@ -455,20 +456,20 @@ static hipError_t launch_t(const RRParams& p, int grid, bool glds, hipStream_t s
 }
 
 template <int KTOP>
-static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool glds, hipStream_t stream)
+static hipError_t launch_k(const RRParams& p, int grid, int nb, int nw, bool glds, int plan_nbuf, bool prio, hipStream_t stream)
 {
     if (nb == 6) {
-        if (nw == 8) return launch_t<6, KTOP, 8>(p, grid, glds, stream);
-        return launch_t<6, KTOP, 4>(p, grid, glds, stream);
+        if (nw == 8) return launch_t<6, KTOP, 8>(p, grid, glds, plan_nbuf, prio, stream);
+        return launch_t<6, KTOP, 4>(p, grid, glds, plan_nbuf, prio, stream);
     }
     if (nb == 8) {
-        if (nw == 16) return launch_t<8, KTOP, 16>(p, grid, glds, stream);
-        if (nw == 8) return launch_t<8, KTOP, 8>(p, grid, glds, stream);
-        return launch_t<8, KTOP, 4>(p, grid, glds, stream);
+        if (nw == 16) return launch_t<8, KTOP, 16>(p, grid, glds, plan_nbuf, prio, stream);
+        if (nw == 8) return launch_t<8, KTOP, 8>(p, grid, glds, plan_nbuf, prio, stream);
+        return launch_t<8, KTOP, 4>(p, grid, glds, plan_nbuf, prio, stream);
     }
-    if (nw == 16) return launch_t<4, KTOP, 16>(p, grid, glds, stream);
-    if (nw == 8) return launch_t<4, KTOP, 8>(p, grid, glds, stream);
-    return launch_t<4, KTOP, 4>(p, grid, glds, stream);
+    if (nw == 16) return launch_t<4, KTOP, 16>(p, grid, glds, plan_nbuf, prio, stream);
+    if (nw == 8) return launch_t<4, KTOP, 8>(p, grid, glds, plan_nbuf, prio, stream);
+    return launch_t<4, KTOP, 4>(p, grid, glds, plan_nbuf, prio, stream);
 }
 
 static void fill_params(RRParams& p, const Bank& cols, const Bank& red, const RowReducePlan& plan,
@@ -509,8 +510,8 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
     RRParams p;
     fill_params(p, cols, red, plan, partial, bound);
     const int grid = plan.nchunks * plan.nsplit;
-    return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, stream)
-                     : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, stream);
+    return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, plan.nbuf, plan.prio != 0, stream)
+                     : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, plan.nbuf, plan.prio != 0, stream);
 }
 
 }  // namespace fm

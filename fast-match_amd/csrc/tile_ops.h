@@ -171,6 +171,37 @@ struct TopK8 {
     }
 };
 
+// ---- float32 sqrt ties of the integer route -------------------------------------------------
+// cv::batchDistance takes dist = sqrtf((float)d2) BEFORE the k-NN insertion and the cross-check
+// compare, so candidates are ordered by (float32 bits of the distance,
+// index), not by (d2, index).  The two orders differ only where two integers share one float32
+// square root: never below kSqrtTieMin (exhaustive check over [0, 128 * 255^2]), and above it only
+// as pairs {n, n + 1} (no three integers share a root).  The matrix-core kernels order by d2; the
+// callers repair the rows where that can matter -- the K-th best d2 reached kSqrtTieMin -- by an
+// exact rescan (sqrt_fix_* kernels in api.hip, the cold branch of x1_round_wsplit), and only for bank
+// pairs whose row norms allow such a distance at all (Bank::usq_max): SIFT-range descriptors
+// (|d|^2 ~ 2.6e5) never take any of it.
+constexpr unsigned kSqrtTieMin = 4197200u;
+
+__device__ __forceinline__ unsigned sqrt_bits(unsigned d2) { return __float_as_uint(sqrtf((float)d2)); }
+// d2 (>= kSqrtTieMin) shares its float32 root with d2 + 1
+__device__ __forceinline__ bool sqrt_ties_up(unsigned d2) { return sqrt_bits(d2 + 1u) == sqrt_bits(d2); }
+
+// Exact squared distance of two bank rows (int8 = u8 - 128, 128 bytes each) from their norms.
+template <class PA, class PB>
+__device__ __forceinline__ unsigned exact_d2_i8(PA a, int na, PB b, int nb)
+{
+    int dot = 0;
+#pragma unroll
+    for (int c = 0; c < kDim / 16; ++c) {
+        const v4i x = *(const __attribute__((address_space(1))) v4i*)(a + 16 * c);
+        const v4i y = *(const __attribute__((address_space(1))) v4i*)(b + 16 * c);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(x[w], y[w], dot, false);
+    }
+    return (unsigned)(na + nb - 2 * dot);
+}
+
 // (hi, idx) a is better than b: larger hi, then lower index.  idx < 0 means "none".
 __device__ __forceinline__ bool better(int ah, int ai, int bh_, int bi_)
 {

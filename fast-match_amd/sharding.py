@@ -119,14 +119,16 @@ def reduce_keys_device(keys_t, group=None):
     return res
 
 
-def decode_keys(keys, float32_route=False):
+def decode_keys(keys, float32_route=None):
     """(tidx int32[nq] (-1 = no match), dist float32[nq] (+inf = no match)) from election keys:
-    what fm_xcheck1 returns.  Integer route: dist = sqrtf(float32(d^2)), exact for d^2 < 2^24."""
+    what fm_xcheck1 returns.  The high word of a key is the float32 distance (its bits) on both routes:
+    OpenCV's cross-check compares the float32 distances, and two integer d^2 >= 4 197 200 can share one
+    (``float32_route`` is accepted for older callers and ignored)."""
     keys = np.asarray(keys, dtype=np.uint64)
     none = keys == np.uint64(0xFFFFFFFFFFFFFFFF)
     tidx = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64).astype(np.int32)
     hi = (keys >> np.uint64(32)).astype(np.uint32)
-    dist = hi.view(np.float32).copy() if float32_route else np.sqrt(hi.astype(np.float32))
+    dist = hi.view(np.float32).copy()
     tidx[none] = -1
     dist[none] = np.inf
     return tidx, dist
@@ -146,7 +148,7 @@ def xcheck1_sharded(ctx, qbank, tbank_shard, t_offset, device=None, group=None):
     else:
         keys = ctx.xcheck1_keys(qbank, tbank_shard, t_offset)
         keys = reduce_keys(keys, device=device, group=group)
-    return decode_keys(keys, float32_route=(qbank.kind == _ffi.FM_BANK_F32))
+    return decode_keys(keys)
 
 
 def gather_row_shards(local, n_rows, device=None, group=None):

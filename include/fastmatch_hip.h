@@ -50,6 +50,25 @@ typedef struct fm_stats {
 /* ---- context ---------------------------------------------------------------------- */
 int  fm_ctx_create(int device_id, fm_ctx** ctx);
 int  fm_ctx_destroy(fm_ctx* ctx);
+/* Per-context options: batch shape and launch tuning by name.  RESULTS NEVER DEPEND ON THEM (the parity
+ * tests run the kernels under several settings); they replace the process-wide FM_* environment
+ * variables, which now only seed a new context's defaults.  The reference has no counterpart: cv2 is
+ * configured per matcher object (fastmatch.pyx:122, 161 build one per call).
+ *   "batch_group"  1..16  fm_match_accepted_batch: most image pairs per distance-kernel launch (8)
+ *   "batch_tail"   0..16  ... pairs in the short launch a run of pairs ends with (2; 0 = none: for callers
+ *                         that enqueue the next batch before waiting for this one, fm_mark / fm_wait)
+ *   "nsplit" "nb" "nw"    K1 grid shape: splits of the reduction range, 16-row blocks per wave (4 | 6 | 8),
+ *                         waves per workgroup (4 | 8 | 16); 0 = built-in rule
+ *   "nbuf"         0|2|3  K1 LDS stage buffers (0 = 3 for top-1, 2 for top-2)
+ *   "prio" "glds" "coop"  0|1  s_setprio around the MFMA burst / LDS-DMA staging / cross-workgroup bounds
+ *   "f32_filter"   0..2   float32 route: 0 = all-pairs kernel only, 1 = fp16 filter for large calls, 2 = always
+ *   "f32_nw" "f32_nsplit" "f32_fused" "f32_lpc"   K8 launch shape (0 / -1 = rule)
+ *   "async_time_every"    every n-th async call carries kernel-timing events (4; 0 = none)
+ *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
+ *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
+ * Unknown names and out-of-range values return FM_EINVAL.                                          */
+int  fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value);
+int  fm_ctx_get_option(fm_ctx* ctx, const char* name, int64_t* value);
 const char* fm_last_error(const fm_ctx* ctx);
 int  fm_sync(fm_ctx* ctx);
 int  fm_get_stats(fm_ctx* ctx, fm_stats* out);
@@ -93,8 +112,9 @@ int  fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* selfdist /*[
 /* ---- K2: brute-force 2-NN ------------------------------------------------------------
  * Replaces cv2.BFMatcher(cv2.NORM_L2, crossCheck=False).knnMatch(q, t, k=2)
  *   matchutil.py:39-43 (bf_match), called from cache.pyx:250; Classic Matching.ipynb:63.
- * idx[2*i+r], dist[2*i+r] = r-th nearest train row of query row i (ascending distance,
- * lower train index first on ties); idx -1 / dist +inf where t has fewer than 2 rows.   */
+ * idx[2*i+r], dist[2*i+r] = r-th nearest train row of query row i (ascending float32 distance,
+ * lower train index first on ties -- ties of the float32 distance, as in cv::batchDistance: d^2 = n
+ * and n + 1 can share a root from 4 197 200 on); idx -1 / dist +inf where t has fewer than 2 rows. */
 int  fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
              int32_t* idx /*[nq*2]*/, float* dist /*[nq*2]*/);
 
@@ -122,8 +142,10 @@ int  fm_xcheck1(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
 
 /* X1 up to the election, for a train set sharded over ranks (one process per GPU): keys[q] =
  * (distance key << 32) | (t_offset + train row in this bank) of the closest row of THIS bank
- * that elects q, ~0 if none; distance key = the integer d^2 (integer-valued banks) or the
- * float32 bits of the distance (float32 route).  The element-wise minimum over the ranks
+ * that elects q, ~0 if none; distance key = the float32 bits of the distance on both routes
+ * (cv::batchDistance takes the square root BEFORE it compares, and two integer d^2 >= 4 197 200
+ * can share one float32 root: the order of the roots, not of d^2, is OpenCV's).  The element-wise
+ * minimum over the ranks
  * (one all-reduce(min) of nq words) equals the keys of the unsharded fm_xcheck1: same
  * matches, same tie-breaks (cv::BFMatcher cross-check, fastmatch.pyx:122-123, 161-162).   */
 int  fm_xcheck1_keys(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int64_t t_offset, uint64_t* keys);

@@ -6,11 +6,12 @@ import numpy as np
 import fastmatch_amd as fm
 from fastmatch_amd import synth
 
-os.environ["FM_TUNE_LIVE"] = "1"
 ctx = fm.Context(0)
+DEFAULTS = {k: ctx.get_option(k) for k in ("nbuf", "prio", "nsplit", "nw", "nb")}
 Q, T, _ = synth.planted_pair(100000, 100000, 20250002)
 qb, tb = ctx.bank(Q), ctx.bank(T)
-variants = [dict(s.split("=") for s in v.split(",") if s) for v in (sys.argv[1:] or ["FM_NBUF=2", "FM_NBUF=3"])]
+# variants: comma separated option=value lists (fm_ctx_set_option names), e.g.  nbuf=2  nbuf=3,prio=0
+variants = [dict(s.split("=") for s in v.split(",") if s) for v in (sys.argv[1:] or ["nbuf=2", "nbuf=3"])]
 res = {i: {"k1": [], "k2": [], "stream": []} for i in range(len(variants))}
 import time
 qb.set_selfdist(ctx.self_dist(qb))
@@ -33,9 +34,10 @@ def stream_ms():
 ref = None
 for rep in range(6):
     for i, env in enumerate(variants):
-        for k in ("FM_NBUF", "FM_PRIO", "FM_NSPLIT", "FM_NW", "FM_NB", "FM_ABLATE_KEEP_BOUNDS"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+        for k, v in DEFAULTS.items():
+            ctx.set_option(k, v)
+        for k, v in env.items():
+            ctx.set_option(k, int(v))
         for name, fn in (("k1", lambda: ctx.xcheck1(qb, tb)), ("k2", lambda: ctx.knn2(qb, tb))):
             fn()
             ctx.reset_stats()

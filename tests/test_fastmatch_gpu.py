@@ -110,6 +110,38 @@ def test_device_loop_equals_oracle_and_host_loop(ctx, size, n, opts, monkeypatch
         assert stats["pairs"] == hstats["pairs"]
 
 
+def test_device_and_host_loop_in_the_sqrt_tie_range(ctx):
+    """Descriptors whose every query/target d2 is >= 4 197 200 (kat.far_image_pair): the election of
+    each round is decided by OpenCV's float32-root order.  Device loop (K7), host loop (K4 rounds) and
+    oracle agree on every match and on the round count."""
+    from kat import far_image_pair
+    q, t = synth.image_pair((400, 320), 800, 5, n_thumb=300)
+    q, t = far_image_pair(q, t)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"],
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    assert np.array_equal(mc.original["distances"], oq.distances)
+    stats, hstats = {}, {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})
+    hget = fastmatch.match(mc, fi, {"context": ctx, "stats": hstats, "device_loop": False})
+    oget = fo.o_match(oq, ot, {})
+    for tau, on_device in ((970.0, True), (1045.0, False)):       # (the second exceeds the device's result capacity of 4 nq)
+        stats.clear()
+        hstats.clear()
+        got, host, exp = get(tau), hget(tau), oget(tau)
+        assert len(exp) > 500
+        _same_matches(got, exp)
+        _same_matches(host, exp)
+        assert stats["rounds"] == hstats["rounds"] == oget.rounds
+        if on_device:
+            assert stats.get("device_loops", 0) == 1
+
+
 def test_device_loop_return_arrays_and_many_pairs(ctx):
     pairs, oracles = [], []
     for k in range(5):

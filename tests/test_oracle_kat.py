@@ -4,10 +4,11 @@ import numpy as np
 import pytest
 
 import oracle
-from kat import xcheck_cases, knn2_cases, selfdist_case
+from kat import (xcheck_cases, knn2_cases, selfdist_case, sqrt_tie_knn2_cases, sqrt_tie_xcheck_cases,
+                 SQRT_TIE_MIN, row_with_sumsq, far_banks)
 
 
-@pytest.mark.parametrize("case", xcheck_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("case", xcheck_cases() + sqrt_tie_xcheck_cases(), ids=lambda c: c[0])
 @pytest.mark.parametrize("as_f32", [False, True])
 def test_xcheck_kat(case, as_f32):
     _, Q, T, etidx, edist = case
@@ -18,7 +19,7 @@ def test_xcheck_kat(case, as_f32):
     assert np.array_equal(dist, np.array(edist, dtype=np.float32))
 
 
-@pytest.mark.parametrize("case", knn2_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("case", knn2_cases() + sqrt_tie_knn2_cases(), ids=lambda c: c[0])
 def test_knn2_kat(case):
     _, Q, T, eidx, edist = case
     idx, dist = oracle.bf_knn(Q, T, 2)
@@ -92,3 +93,32 @@ def test_against_numpy_bruteforce():
 def test_dtype_mismatch_raises():
     with pytest.raises(TypeError):
         oracle.bf_xcheck1(np.zeros((2, 4), np.uint8), np.zeros((2, 4), np.float32))
+
+
+def test_sqrt_tie_table():
+    """The facts the device's tie repair rests on (tile_ops.h kSqrtTieMin): below 4 197 200 no two
+    integers share a float32 square root; up to 128 * 255^2 no three do."""
+    n = np.arange(0, 128 * 255 * 255 + 2, dtype=np.int64)
+    bits = np.sqrt(n.astype(np.float32)).view(np.uint32)
+    same = bits[1:] == bits[:-1]
+    assert int(n[:-1][same][0]) == SQRT_TIE_MIN
+    assert not np.any(same[1:] & same[:-1])
+    assert np.all(np.diff(bits.astype(np.int64)) >= 0)          # the root is monotone: ties are runs
+    for target in (SQRT_TIE_MIN, SQRT_TIE_MIN + 1, 8323200, 1, 0):
+        r = row_with_sumsq(target).astype(np.int64)
+        assert int((r * r).sum()) == target
+
+
+def test_far_banks_separate_float_order_from_integer_order():
+    """The tie-heavy banks of the GPU parity tests really tell the two orders apart: on them the
+    oracle (OpenCV's float32 order) and an integer-d2 order disagree for many rows."""
+    rng = np.random.default_rng(1)
+    Q, T = far_banks(300, 200, rng)
+    d2 = ((Q[:, None].astype(np.int64) - T[None].astype(np.int64)) ** 2).sum(-1)
+    assert d2.min() >= SQRT_TIE_MIN
+    idx, _ = oracle.bf_knn(Q, T, 2)
+    by_int = np.argsort(d2, axis=1, kind="stable")[:, :2]
+    assert (idx != by_int).any(axis=1).sum() > 20
+    # and the oracle is the float32 order: stable sort on the float32 roots
+    by_f32 = np.argsort(np.sqrt(d2.astype(np.float32)), axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, by_f32)

@@ -5,8 +5,9 @@ import numpy as np
 import pytest
 
 import oracle
-from fastmatch_amd import synth, matchutil, _ffi
-from kat import xcheck_cases, knn2_cases, selfdist_case
+from fastmatch_amd import synth, matchutil, sharding, _ffi
+from kat import (xcheck_cases, knn2_cases, selfdist_case, sqrt_tie_knn2_cases, sqrt_tie_xcheck_cases,
+                 SQRT_TIE_MIN, row_with_sumsq, far_banks)
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +17,7 @@ def _eq(a, b):
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
-@pytest.mark.parametrize("case", xcheck_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("case", xcheck_cases() + sqrt_tie_xcheck_cases(), ids=lambda c: c[0])
 @pytest.mark.parametrize("as_f32", [False, True])
 def test_xcheck_kat(ctx, case, as_f32):
     _, Q, T, etidx, edist = case
@@ -27,7 +28,7 @@ def test_xcheck_kat(ctx, case, as_f32):
     assert _eq(dist, np.array(edist, dtype=np.float32))
 
 
-@pytest.mark.parametrize("case", knn2_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("case", knn2_cases() + sqrt_tie_knn2_cases(), ids=lambda c: c[0])
 def test_knn2_kat(ctx, case):
     _, Q, T, eidx, edist = case
     idx, dist = ctx.knn2(ctx.bank(Q), ctx.bank(T))
@@ -110,6 +111,156 @@ def test_extreme_values_and_short_dim(ctx):
     idx, d = ctx.knn2(ctx.bank(Q64), ctx.bank(T64))
     oidx, od = oracle.bf_knn(Q64, T64, 2)
     assert _eq(idx, oidx) and _eq(d, od)
+
+
+# ---- float32 square-root ties (d2 >= 4 197 200: OpenCV orders by the float32 root, then index) -----
+@pytest.mark.parametrize("nq,nt,small", [(300, 200, (10, 1)), (393, 125, (6, 2)), (2500, 3100, (10, 1)), (129, 4000, (8, 1))])
+def test_sqrt_tie_range_dense_parity(ctx, nq, nt, small):
+    rng = np.random.default_rng(nq + nt)
+    Q, T = far_banks(nq, nt, rng, *small)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    idx, d2 = ctx.knn2(qb, tb)
+    oidx, od2 = oracle.bf_knn(Q, T, 2)
+    assert _eq(idx, oidx) and _eq(d2, od2)
+    tidx, dist = ctx.xcheck1(qb, tb)
+    otidx, odist = oracle.bf_xcheck1(Q, T)
+    assert _eq(tidx, otidx) and _eq(dist, odist)
+    assert _eq(ctx.self_dist(tb), oracle.self_dist(T))            # (train rows are 0 apart in the far dims: no ties here)
+    # the same banks as integer-valued float32 input (int8 route) and on the float32 route
+    qf, tf = ctx.bank(Q.astype(np.float32)), ctx.bank(T.astype(np.float32))
+    assert qf.kind == _ffi.FM_BANK_I8
+    t2, x2 = ctx.xcheck1(qf, tf)
+    assert _eq(t2, otidx) and _eq(x2, odist)
+    qr, tr = ctx.bank(Q, float_route=True), ctx.bank(T, float_route=True)
+    t3, x3 = ctx.xcheck1(qr, tr)
+    i3, k3 = ctx.knn2(qr, tr)
+    assert _eq(t3, otidx) and _eq(x3, odist) and _eq(i3, oidx) and _eq(k3, od2)
+
+
+@pytest.mark.parametrize("nsplit", [1, 2, 5, 13])
+def test_sqrt_tie_across_split_boundaries(nsplit):
+    """The two members of a tie group sit in different splits of the reduction range (different
+    workgroups, merged by the election / the top-2 merge): filler rows are farther than both."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    c.set_option("nsplit", nsplit)
+    assert c.get_option("nsplit") == nsplit
+    n = SQRT_TIE_MIN + 2122                                       # 4 199 322 / 4 199 323 share a root too
+    assert np.sqrt(np.float32(n)) == np.sqrt(np.float32(n + 1))
+    lo, hi = row_with_sumsq(n), row_with_sumsq(n + 1)
+    filler = np.zeros(128, np.uint8)
+    filler[:66] = 255                                             # d2 = 4 291 650 from the zero row
+    rows = 13 * 1024 + 300
+    T = np.tile(filler, (rows, 1))
+    for a, b in ((100, rows - 50), (rows // 2 - 1, rows // 2 + 700), (5, 6)):
+        T2 = T.copy()
+        T2[a], T2[b] = hi, lo                                     # the LARGER d2 has the lower index
+        z = np.zeros((3, 128), np.uint8)
+        z[1, 127] = 200                                           # other queries, far from everything
+        z[2, 126] = 201
+        qb, tb = c.bank(z), c.bank(T2)
+        idx, d = c.knn2(qb, tb)
+        oidx, od = oracle.bf_knn(z, T2, 2)
+        assert _eq(idx, oidx) and _eq(d, od) and idx[0].tolist() == [a, b]
+        tidx, xd = c.xcheck1(qb, tb)
+        otidx, oxd = oracle.bf_xcheck1(z, T2)
+        assert _eq(tidx, otidx) and _eq(xd, oxd)
+        # the election side: many query rows, one train row (the zero row): the lower query index wins
+        tz = c.bank(np.zeros((1, 128), np.uint8))
+        qq = c.bank(T2)
+        tidx, xd = c.xcheck1(qq, tz)
+        otidx, oxd = oracle.bf_xcheck1(T2, np.zeros((1, 128), np.uint8))
+        assert _eq(tidx, otidx) and _eq(xd, oxd) and tidx[a] == 0 and tidx[b] == -1
+    c.close()
+
+
+def test_sqrt_tie_rounds_and_keys(ctx):
+    """K4 rounds (fm_xcheck1_batched) and the sharded election keys on tie-range banks."""
+    rng = np.random.default_rng(99)
+    Q, T = far_banks(3000, 2000, rng)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    sizes = [(393, 125), (1, 1), (130, 257), (1000, 33), (2048, 100), (37, 300)]
+    q_rows, q_off, t_off = [], [0], [0]
+    for nq, nt in sizes:
+        q_rows.append(rng.choice(3000, nq, replace=False))
+        q_off.append(q_off[-1] + nq)
+        t_off.append(t_off[-1] + nt)
+    q_rows = np.concatenate(q_rows).astype(np.int32)
+    tidx, dist, _ = ctx.xcheck1_batched(qb, q_rows, q_off, tb, t_off)
+    differs = 0
+    for b, (nq, nt) in enumerate(sizes):
+        rows = q_rows[q_off[b]:q_off[b + 1]]
+        ot, od = oracle.bf_xcheck1(Q[rows], T[t_off[b]:t_off[b + 1]])
+        sl = slice(q_off[b], q_off[b + 1])
+        assert _eq(tidx[sl], ot) and _eq(dist[sl], od), "round %d" % b
+        d2 = ((Q[rows][:, None].astype(np.int64) - T[t_off[b]:t_off[b + 1]][None].astype(np.int64)) ** 2).sum(-1)
+        differs += int((np.argmin(d2, axis=0) != np.argmin(np.sqrt(d2.astype(np.float32)), axis=0)).sum())
+    assert differs > 10                                           # (the rounds do contain elections the root decides)
+    full_t, full_d = ctx.xcheck1(qb, tb)
+    ot, od = oracle.bf_xcheck1(Q, T)
+    assert _eq(full_t, ot) and _eq(full_d, od)
+    for world in (2, 3):
+        keys = None
+        for r in range(world):
+            lo, hi = sharding.shard_rows(T.shape[0], r, world)
+            k = ctx.xcheck1_keys(qb, ctx.bank(T[lo:hi]), lo)
+            keys = k if keys is None else np.minimum(keys, k)
+        t, d = sharding.decode_keys(keys)
+        assert _eq(t, ot) and _eq(d, od)
+
+
+def test_sqrt_tie_accepted_paths(ctx):
+    """fm_match_accepted (sync), _async and _batch on tie-range banks == oracle."""
+    rng = np.random.default_rng(5)
+    pairs, exp = [], []
+    for k in range(3):
+        Q, T = far_banks(2000, 2300, rng)
+        Q[:, 111:128] = rng.integers(0, 2, (2000, 17), dtype=np.uint8)     # distinct query rows: non-zero self distances
+        qb, tb = ctx.bank(Q), ctx.bank(T)
+        sd = oracle.self_dist(Q)
+        assert _eq(ctx.self_dist(qb), sd)
+        qb.set_selfdist(sd)
+        ot, od = oracle.bf_xcheck1(Q, T)
+        m = ot >= 0
+        tau = float(np.median(od[m] / sd[m]))
+        orat, opass = oracle.ratio_filter(od[m], sd, tau, qrows=np.nonzero(m)[0].astype(np.int32))
+        acc = np.nonzero(m)[0][opass]
+        pairs.append((qb, tb, tau))
+        exp.append((acc.astype(np.int32), ot[acc], od[acc], orat[opass]))
+        got = ctx.match_accepted(qb, tb, tau)
+        assert all(_eq(a, b) for a, b in zip(got, exp[-1]))
+    outs = [tuple(ctx.pinned_empty(2000, dt) for dt in (np.int32, np.int32, np.float32, np.float64)) for _ in pairs]
+    cnts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    for (qb, tb, tau), o, c in zip(pairs, outs, cnts):
+        ctx.match_accepted_async(qb, tb, tau, o, c)
+    ctx.sync()
+    for e, o, c in zip(exp, outs, cnts):
+        m = int(c[0])
+        assert m == len(e[0]) and all(_eq(a[:m], b) for a, b in zip(o, e))
+    # one batched launch (same shapes, same tau for all: use pair 0's threshold)
+    tau0 = pairs[0][2]
+    ctx.match_accepted_batch([(q, t) for q, t, _ in pairs], tau0, outs, cnts)
+    ctx.sync()
+    for (qb, tb, _), o, c in zip(pairs, outs, cnts):
+        e = ctx.match_accepted(qb, tb, tau0)
+        m = int(c[0])
+        assert m == len(e[0]) and all(_eq(a[:m], b) for a, b in zip(o, e))
+
+
+def test_ctx_options_api(ctx):
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    assert c.get_option("batch_group") == 8 and c.get_option("batch_tail") == 2
+    c.set_option("batch_group", 16)
+    c.set_option("batch_tail", 0)
+    assert c.get_option("batch_group") == 16 and c.get_option("batch_tail") == 0
+    assert ctx.get_option("batch_group") == 8                     # per context, not per process
+    for bad in (("batch_group", 0), ("batch_group", 17), ("nbuf", 5), ("no_such_option", 1)):
+        with pytest.raises(_ffi.FastMatchHipError):
+            c.set_option(*bad)
+    with pytest.raises(_ffi.FastMatchHipError):
+        c.get_option("no_such_option")
+    c.close()
 
 
 @pytest.mark.parametrize("nsplit,nb", [(1, 4), (1, 8), (3, 4), (8, 8), (16, 4)])
@@ -609,7 +760,7 @@ def test_train_sharded_crosscheck_keys_reduce_to_the_unsharded_result(ctx, as_f3
             lo, hi = sharding.shard_rows(T.shape[0], r, world)
             k = ctx.xcheck1_keys(qb, ctx.bank(T[lo:hi]), lo)
             keys = k if keys is None else np.minimum(keys, k)
-        t, d = sharding.decode_keys(keys, float32_route=as_f32)
+        t, d = sharding.decode_keys(keys)
         assert _eq(t, full_t) and _eq(d, full_d)
     # single process: the helper is the plain call
     t, d = sharding.xcheck1_sharded(ctx, qb, ctx.bank(T), 0)
@@ -628,7 +779,7 @@ def test_train_sharded_crosscheck_keys_reduce_to_the_unsharded_result(ctx, as_f3
             kt.masked_fill_(kt == -1, torch.iinfo(torch.int64).max)
             acc = kt if acc is None else torch.minimum(acc, kt)
         acc.masked_fill_(acc == torch.iinfo(torch.int64).max, -1)
-        t, d = sharding.decode_keys(sharding.reduce_keys_device(acc), float32_route=as_f32)
+        t, d = sharding.decode_keys(sharding.reduce_keys_device(acc))
         assert _eq(t, full_t) and _eq(d, full_d)
     t, d = sharding.xcheck1_sharded(ctx, qb, ctx.bank(T), 0, device=dev)
     assert _eq(t, full_t) and _eq(d, full_d)

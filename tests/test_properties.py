@@ -81,6 +81,40 @@ def test_hip_equals_oracle_on_random_tie_heavy_inputs(ctx, s):
         assert np.array_equal(bt, et) and np.array_equal(bd.view(np.uint32), ed.view(np.uint32))
 
 
+@pytest.mark.gpu
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(st.tuples(st.integers(1, 300), st.integers(2, 300), st.integers(1, 12), st.integers(1, 3),
+                 st.integers(4197200, 6400000), st.booleans(), st.integers(0, 2**31 - 1)))
+def test_hip_equals_oracle_in_the_sqrt_tie_range(ctx, s):
+    """d2 >= 4 197 200: OpenCV orders by the float32 root, then index.  Banks whose every distance lies
+    in that range (a handful of d2 values, again and again), plus a planted pair of train rows at
+    d2 = n and n + 1 from a zero query row, larger d2 first or second."""
+    from kat import far_banks, row_with_sumsq
+    nq, nt, small_dims, small_max, n, larger_first, seed = s
+    rng = np.random.default_rng(seed)
+    Q, T = far_banks(nq, nt, rng, small_dims, small_max)
+    Q[0] = 0
+    i, j = sorted(rng.choice(nt, 2, replace=False))
+    T[i], T[j] = (row_with_sumsq(n + 1), row_with_sumsq(n)) if larger_first else (row_with_sumsq(n), row_with_sumsq(n + 1))
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    idx, dist = ctx.knn2(qb, tb)
+    oidx, odist = oracle.bf_knn(Q, T, 2)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    if np.sqrt(np.float32(n)) == np.sqrt(np.float32(n + 1)):
+        assert idx[0].tolist() == [i, j]                          # index order inside the tie, whichever d2 is larger
+    tidx, xd = ctx.xcheck1(qb, tb)
+    otidx, oxd = oracle.bf_xcheck1(Q, T)
+    assert np.array_equal(tidx, otidx) and np.array_equal(xd.view(np.uint32), oxd.view(np.uint32))
+    tidx, xd = ctx.xcheck1(tb, qb)                                # roles swapped: the election sees the planted pair
+    otidx, oxd = oracle.bf_xcheck1(T, Q)
+    assert np.array_equal(tidx, otidx) and np.array_equal(xd.view(np.uint32), oxd.view(np.uint32))
+    rows = rng.integers(0, nq, size=min(nq, 40)).astype(np.int32)
+    lo = int(rng.integers(0, nt))
+    bt, bd, _ = ctx.xcheck1_batched(qb, rows, [0, len(rows)], tb, [lo, nt])
+    et, ed = oracle.bf_xcheck1(Q[rows], T[lo:nt])
+    assert np.array_equal(bt, et) and np.array_equal(bd.view(np.uint32), ed.view(np.uint32))
+
+
 @pytest.fixture(scope="module")
 def filter_ctx_module():
     import os

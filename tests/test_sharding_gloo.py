@@ -82,8 +82,8 @@ Q = rng.integers(0, 4, (90, 128)).astype(np.uint8) * 60          # few levels: p
 T = rng.integers(0, 4, (150, 128)).astype(np.uint8) * 60
 lo, hi = sharding.shard_rows(150, rank, world)
 tl, dl = oracle.bf_xcheck1(Q, T[lo:hi])
-d2 = np.rint(dl.astype(np.float64) ** 2).astype(np.uint64)
-keys = np.where(tl >= 0, (d2 << np.uint64(32)) | (tl.astype(np.int64) + lo).astype(np.uint64), np.uint64(0xFFFFFFFFFFFFFFFF))
+db = dl.view(np.uint32).astype(np.uint64)                           # key = float32 distance bits << 32 | global train row
+keys = np.where(tl >= 0, (db << np.uint64(32)) | (tl.astype(np.int64) + lo).astype(np.uint64), np.uint64(0xFFFFFFFFFFFFFFFF))
 tidx, dd = sharding.decode_keys(sharding.reduce_keys(keys))
 ft, fd = oracle.bf_xcheck1(Q, T)
 assert np.array_equal(tidx, ft) and np.array_equal(dd.view(np.uint32), fd.view(np.uint32)), rank
@@ -117,11 +117,12 @@ def test_shard_rows_partition():
 
 def test_decode_keys():
     none = np.uint64(0xFFFFFFFFFFFFFFFF)
-    keys = np.array([(np.uint64(25) << np.uint64(32)) | np.uint64(7), none, np.uint64(0)], dtype=np.uint64)
+    five = np.uint64(np.array([5.0], np.float32).view(np.uint32)[0])
+    keys = np.array([(five << np.uint64(32)) | np.uint64(7), none, np.uint64(0)], dtype=np.uint64)
     t, d = sharding.decode_keys(keys)
     assert t.tolist() == [7, -1, 0] and d[0] == 5.0 and np.isinf(d[1]) and d[2] == 0.0
     f = np.array([1.25], np.float32).view(np.uint32)[0]
-    t, d = sharding.decode_keys(np.array([(np.uint64(f) << np.uint64(32)) | np.uint64(3)], dtype=np.uint64), float32_route=True)
+    t, d = sharding.decode_keys(np.array([(np.uint64(f) << np.uint64(32)) | np.uint64(3)], dtype=np.uint64))
     assert t.tolist() == [3] and d[0] == np.float32(1.25)
     assert np.array_equal(sharding.reduce_keys(keys), keys)          # single process: identity
 
