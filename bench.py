@@ -54,9 +54,10 @@ def k1_source_hash():
     return h.hexdigest()
 
 
-def cpu_baseline(Q, T, budget_s=12.0):
+def cpu_baseline(Q, T, budget_s=12.0, keep=None):
     """Oracle (kind 'port': the reference's .so cannot run here) on a bounded row sample of
-    the same workload, all host cores."""
+    the same workload, all host cores.  keep (a dict): receives the sample size and the oracle's
+    (tidx, dist) of the sample, for the self-check of the timed batch."""
     import oracle
     threads = oracle.max_threads()
     s0 = 256
@@ -66,11 +67,36 @@ def cpu_baseline(Q, T, budget_s=12.0):
     rate = s0 * len(T) / dt
     s = int(min(len(Q), max(s0, budget_s * rate / len(T))))
     t0 = time.perf_counter()
-    oracle.bf_xcheck1(Q[:s], T, threads=threads)
+    res = oracle.bf_xcheck1(Q[:s], T, threads=threads)
     dt = time.perf_counter() - t0
+    if keep is not None:
+        keep["rows"], keep["tidx"], keep["dist"] = s, res[0], res[1]
     return {"value": s * len(T) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": "oracle bf_xcheck1 (C, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s"
                       % (s, len(Q), len(T), dt)}
+
+
+def verify_against_oracle(ctx, Q, T, selfdist, keep, timed_rows, pair0):
+    """The oracle result cpu_baseline computed anyway, against the device: if the sample covered every query
+    row, against pair 0's accepted rows AS THE TIMED BATCH LEFT THEM (timed_rows = qidx, tidx, dist, ratio);
+    otherwise (few host cores) against a fresh device call on the same sub-problem (the election is over all
+    query rows, so a row sample of the full problem is a different problem)."""
+    import oracle
+    s, otidx, odist = keep["rows"], keep["tidx"], keep["dist"]
+    m = otidx >= 0
+    rows = np.nonzero(m)[0].astype(np.int32)
+    oratio, opass = oracle.ratio_filter(odist[m], selfdist[:s] if s < len(Q) else selfdist, TAU, qrows=rows)
+    want = (rows[opass], otidx[m][opass], odist[m][opass], oratio[opass])
+    if s == len(Q) and timed_rows is not None:
+        got, scope = timed_rows, "pair 0 of the timed batch, all %d query rows" % s
+    elif s == len(Q):
+        got, scope = ctx.match_accepted(pair0[0], pair0[1], TAU), "fresh call on pair 0, all %d query rows" % s
+    else:
+        qb, tb = ctx.bank(Q[:s]), ctx.bank(T)
+        qb.set_selfdist(selfdist[:s])
+        got, scope = ctx.match_accepted(qb, tb, TAU), "fresh call on the first %d query rows of pair 0 x all target rows" % s
+    ok = all(len(a) == len(b) and np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8)) for a, b in zip(got, want))
+    return bool(ok), scope, int(len(want[0]))
 
 
 def derived_pair(Q, T, j, rng):
@@ -228,12 +254,14 @@ def main():
     # can share ONE distance-kernel launch -- its small kernels run beside the next step's launch.  Without
     # the pipeline the library ends a run of pairs with a short launch instead (8 + 2).
     pipelined = os.environ.get("FM_BENCH_PIPELINE", "1") != "0" and os.environ.get("FM_BENCH_SYNC") != "1"
-    if pipelined:
-        os.environ.setdefault("FM_BATCH_GROUP", "16")
-        os.environ.setdefault("FM_BATCH_TAIL", "0")
     import fastmatch_amd
     from fastmatch_amd import synth, sharding
     ctx = fastmatch_amd.Context(local_rank)
+    if pipelined:                                           # the whole step in one launch (fm_ctx_set_option)
+        if "FM_BATCH_GROUP" not in os.environ:
+            ctx.set_option("batch_group", 16)
+        if "FM_BATCH_TAIL" not in os.environ:
+            ctx.set_option("batch_tail", 0)
 
     # the batch of independent pairs of this rank, resident in HBM before the timed region
     Q, T, planted = synth.planted_pair(NQ, NT, seed=SEED + rank)
@@ -244,6 +272,8 @@ def main():
         Qj, Tj = derived_pair(Q, T, j, rng)
         qb, tb = ctx.bank(Qj), ctx.bank(Tj)
         selfdist = ctx.self_dist(qb)                    # Metric_Cache build (once per query image)
+        if j == 0:
+            selfdist0 = selfdist
         if j == 1 or (j == 0 and PAIRS_PER_STEP == 1):  # timed on a later run (the first pays module load)
             ctx.reset_stats()
             t0 = time.perf_counter()
@@ -417,6 +447,11 @@ def main():
         npass_all = npass
     st = ctx.stats()
     qb, tb = banks[0]
+    # pair 0's accepted rows as the timed batch left them (output set 0), kept for the self-check below
+    timed_rows0 = None
+    if world == 1 and use_async:
+        m0 = int(counts_sets[0][0][0])
+        timed_rows0 = tuple(a[:m0].copy() for a in outbufs[0])
 
     # Classic Ratio-Match (2-NN + d1/d2 < 0.7, the literal "2-NN + ratio" of configs[1]), reported
     # beside the headline; not part of the timed region above.
@@ -433,6 +468,24 @@ def main():
                "ms_per_call": 1e3 * dt, "kernel_ms": ctx.stats()["kernel_ms"] / reps,
                "frac_int8_mfma_peak": float(NQ) * NT * OPS_PER_PAIR / (ctx.stats()["kernel_ms"] / reps * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
                "note": "fm_knn2_ratio: K2 top-2 + Lowe ratio + compaction, same banks"}
+
+    # ONE configs[1] call, the way a caller without a batch makes it: fm_match_accepted (K1 + election +
+    # ratio test + compaction into page-locked buffers) and its synchronisation, 20 repetitions.
+    single = None
+    if rank == 0 and legs:
+        ctx.match_accepted(qb, tb, TAU, out=outbuf)
+        ctx.reset_stats()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sq, _, _, _ = ctx.match_accepted(qb, tb, TAU, out=outbuf)
+        dt = (time.perf_counter() - t0) / reps
+        sst = ctx.stats()
+        skms = sst["kernel_ms"] / max(sst["kernel_launches"], 1)
+        single = {"ms_per_call": 1e3 * dt, "kernel_ms": skms, "pairs_per_s": float(NQ) * NT / dt, "accepted": int(len(sq)),
+                  "frac_int8_mfma_peak": float(NQ) * NT * OPS_PER_PAIR / (skms * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
+                  "frac_int8_mfma_peak_whole_call": float(NQ) * NT * OPS_PER_PAIR / dt / (INT8_DENSE_PEAK_TOPS * 1e12),
+                  "note": "fm_match_accepted, one 100k x 100k pair per call, synchronous (rowreduce_kernel<4,1,true,8,3,1>)"}
 
     # Float32 route (BASELINE.json configs[4]: 1M-row float32 target bank vs 10k-row query
     # batches): fm_knn2 on non-integer descriptors = K8 (fp16-MFMA filter + exact float32
@@ -545,7 +598,7 @@ def main():
             "matches_per_s": npass_all * args.steps / elapsed,
             "accepted_matches_per_step": npass_all,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
+                         "unit": "TOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_tag": traffic_tag, "traffic_note": traffic_note,
                          "kernel": ("fm::rowreduce_batch_kernel<4,1,8,3,1>" if (use_batch or step_gather) else "fm::rowreduce_kernel<4,1,true,8,3,1>")
                                    + " (v_mfma_i32_16x16x64_i8)",
@@ -563,16 +616,27 @@ def main():
             "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
                          "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},
             "classic_ratio_match": crm,
+            "single_pair": single,
             "expand_c3": c3,
             "expand_c4": c4,
             "float32_route": f32,
             "call_ms": call_ms,
             "device": ctx.device_name(),
         }
+        verified = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Q, T)
+            keep = {}
+            out["cpu_baseline"] = cpu_baseline(Q, T, keep=keep)
+            # self-check: the oracle result just computed against what the timed batch left for pair 0
+            verified, scope, n_want = verify_against_oracle(ctx, Q, T, selfdist0, keep, timed_rows0, banks[0])
+            out["verified_vs_oracle"] = verified
+            out["verified_scope"] = scope + " (%d accepted rows: query index, train index, distance bits, ratio bits)" % n_want
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if verified is False:
+            sys.stderr.write("bench.py: the device result differs from the oracle\n")
+            if world == 1:
+                sys.exit(1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

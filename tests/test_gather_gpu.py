@@ -582,3 +582,61 @@ def test_batch_outputs_shorter_than_the_accepted_lists_are_truncated_not_overrun
         assert int(cnts[i].item()) == len(qa)
         assert np.array_equal(got[i * cap:(i + 1) * cap], sharding.pack_matches(qa, ta, da)[:cap])
     assert (got[len(pairs) * cap:] == -7).all()
+
+
+def test_benchmarked_launch_shape_against_the_oracle():
+    """The launch bench.py times: twelve DISTINCT pairs in ONE rowreduce_batch_kernel launch (options
+    batch_group = 16, batch_tail = 0), steps pipelined two deep with fm_mark / fm_wait on two output
+    sets -- every pair's accepted rows (query index, train index, distance bits, ratio bits) against
+    oracle.bf_xcheck1 + ratio_filter, not against another call of the library."""
+    import fastmatch_amd
+    import oracle
+    c = fastmatch_amd.Context(0)
+    c.set_option("batch_group", 16)
+    c.set_option("batch_tail", 0)
+    nq, nt, tau = 8000, 33000, 0.7
+    pairs, want = [], []
+    for k in range(12):
+        Q, T, _ = synth.planted_pair(nq, nt, seed=700 + k)
+        qb, tb = c.bank(Q), c.bank(T)
+        sd = oracle.self_dist(Q)
+        qb.set_selfdist(sd)
+        ot, od = oracle.bf_xcheck1(Q, T)
+        m = ot >= 0
+        orat, opass = oracle.ratio_filter(od[m], sd, tau, qrows=np.nonzero(m)[0].astype(np.int32))
+        acc = np.nonzero(m)[0][opass]
+        want.append((acc.astype(np.int32), ot[acc], od[acc], orat[opass]))
+        pairs.append((qb, tb))
+    assert sum(len(w[0]) for w in want) > 5000
+    sets = []
+    for s in range(2):
+        outs = [(c.pinned_empty(nq, np.int32), c.pinned_empty(nq, np.int32), c.pinned_empty(nq, np.float32),
+                 c.pinned_empty(nq, np.float64)) for _ in pairs]
+        counts = [c.pinned_empty(1, np.int64) for _ in pairs]
+        sets.append((c.prepare_batch(pairs, outs, counts), outs, counts))
+
+    def check(s):
+        _, outs, counts = sets[s]
+        for j, (w, out, cnt) in enumerate(zip(want, outs, counts)):
+            m = int(cnt[0])
+            assert m == len(w[0]), j
+            for a, b in zip(out, w):
+                assert np.array_equal(a[:m].view(np.uint8), b.view(np.uint8)), j
+            cnt[0] = -1
+
+    c.reset_stats()
+    prev = None
+    for step in range(5):
+        s = step % 2
+        c.match_accepted_batch(sets[s][0], tau)
+        ticket = c.mark()
+        if prev is not None:
+            c.wait(prev[1])
+            check(prev[0])
+        prev = (s, ticket)
+    c.wait(prev[1])
+    check(prev[0])
+    c.sync()
+    st = c.stats()
+    assert st["kernel_launches"] == 5 and st["pairs"] == 5 * 12 * nq * nt      # one launch per step, twelve pairs each
+    c.close()
