@@ -127,7 +127,10 @@ def leg_expand_c3(ctx, reps=3):
     setup_s = time.perf_counter() - t0
     stats = {}
     get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats, "return_arrays": True})
-    get(TAU)                                            # builds the expander, warms the module
+    t0 = time.perf_counter()
+    get.expander()                                      # cell packing, position index, upload, first run state
+    build_s = time.perf_counter() - t0
+    get(TAU)                                            # warms the module
     best = None
     for _ in range(reps):
         stats.clear()
@@ -143,9 +146,49 @@ def leg_expand_c3(ctx, reps=3):
             "wall_s": wall, "rounds": rounds, "descriptor_pairs": pairs, "matches": nm,
             "rounds_per_s": rounds / wall, "pairs_per_s": pairs / wall, "matches_per_s": nm / wall,
             "kernel_ms": k_ms, "frac_wall_in_kernels": k_ms * 1e-3 / wall, "device_loop": rounds > 0,
-            "setup_s": setup_s,
+            "setup_s": setup_s, "expander_build_s": build_s,
             "note": "fm_expand_run (K7): exact depth-first replay of do_iter on the device, results fetched to the host; "
-                    "pairs = sum over rounds of nq_i x nt_i"}
+                    "pairs = sum over rounds of nq_i x nt_i; setup_s = synthetic pair + Metric_Cache (self 2-NN of 300k rows), "
+                    "expander_build_s = cell packing + position index + upload (once per pair, reused by every threshold)"}, get
+
+
+def leg_expand_c3_taus(ctx, get, single_wall):
+    """The reference's driver asks a pair for 15 thresholds (turntable.py:59-60; Evaluate Turntable.ipynb uses
+    numpy.linspace(0.5, 1.2, 15)): 15 runs of the configs[2] pair in ONE launch (one workgroup and one run
+    state each) against the same 15 runs one launch after the other.  Thresholds 0.5 .. 1.0 here: above 1.0
+    this synthetic pair accepts every cross-checked pair and the expansion heads for all 9801^2 (cell, query
+    cell) combinations -- minutes of rounds in the reference's own semantics, not a measurement of anything."""
+    from fastmatch_amd import fastmatch
+    taus = [float(t) for t in np.linspace(0.5, 1.0, 15)]
+    ex = get.expander()
+    seeds = [get.seeds_for(t) for t in taus]
+    res = fastmatch.run_device_loops(ctx, [ex] * len(taus), seeds, taus, as_arrays=True)      # warm: allocates the run states
+    best = None
+    for _ in range(2):
+        stats = {}
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        res = fastmatch.run_device_loops(ctx, [ex] * len(taus), seeds, taus, stats=stats, as_arrays=True)
+        wall = time.perf_counter() - t0
+        k_ms = ctx.stats()["kernel_ms"]
+        if best is None or wall < best[0]:
+            best = (wall, k_ms, stats.get("rounds", 0), stats.get("pairs", 0), stats.get("device_fallbacks", 0))
+    wall, k_ms, rounds, pairs, failed = best
+    t0 = time.perf_counter()
+    seq_rounds = []
+    for t, sd in zip(taus, seeds):
+        st1 = {}
+        fastmatch.run_device_loops(ctx, [ex], [sd], [t], stats=st1, as_arrays=True)
+        seq_rounds.append(st1.get("rounds", 0))
+    seq_wall = time.perf_counter() - t0
+    return {"workload": "BASELINE configs[2] pair at 15 thresholds linspace(0.5, 1.0, 15), one launch",
+            "thresholds": taus, "wall_s": wall, "kernel_ms": k_ms, "rounds": rounds, "descriptor_pairs": pairs,
+            "matches": int(sum(len(r[0]) for r in res if r is not None)), "runs_given_up_by_the_device": failed,
+            "rounds_per_s": rounds / wall, "pairs_per_s": pairs / wall,
+            "rounds_per_run": seq_rounds, "sequential_wall_s": seq_wall, "speedup_vs_sequential": seq_wall / wall,
+            "wall_vs_single_tau_0.7": wall / single_wall,
+            "note": "each run is a sequential chain of rounds on one workgroup, so the launch lasts as long as its LONGEST run "
+                    "(the largest threshold); the other 14 run beside it"}
 
 
 def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=64, reps=3):
@@ -160,7 +203,9 @@ def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=64, reps=3):
     pairs = [build_image_pair(ctx, (1000, 1000), 12500, 20250100 + i, 600) for i in mine]
     setup_s = time.perf_counter() - t0
     prepared, stats = [], {}
+    t0 = time.perf_counter()
     fastmatch.match_many(pairs, TAU, {"context": ctx, "prepared_out": prepared, "return_arrays": True})
+    build_s = time.perf_counter() - t0                      # grids + seeding + expanders + the first (warming) launch
     tdev = dev if backend == "nccl" else "cpu"
     best = None
     for _ in range(reps):
@@ -196,7 +241,7 @@ def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=64, reps=3):
             "n_gpus": world, "scaling": "strong", "wall_s": wall, "rounds": rounds, "descriptor_pairs": npairs,
             "matches": nm, "rounds_per_s": rounds / wall, "pairs_per_s": npairs / wall, "matches_per_s": nm / wall,
             "image_pairs_per_s": n_pairs / wall, "kernel_ms": k_ms, "frac_wall_in_kernels": k_ms * 1e-3 / wall,
-            "setup_s": setup_s,
+            "setup_s": setup_s, "expander_build_s": build_s,
             "note": "fastmatch.match_many: one fm_expand_run launch per rank (one workgroup per image pair) + "
                     "all-gather of (pair, query index, ratio) rows; wall = max over ranks, best of %d" % reps}
 
@@ -540,9 +585,11 @@ def main():
         qall.close()
         tbf.close()
 
-    c3 = None
+    c3 = c3t = None
     if rank == 0 and world == 1 and legs and os.environ.get("FM_BENCH_C3", "1") != "0":
-        c3 = leg_expand_c3(ctx)
+        c3, c3_get = leg_expand_c3(ctx)
+        c3t = leg_expand_c3_taus(ctx, c3_get, c3["wall_s"])
+        del c3_get
     c4 = None
     if legs and os.environ.get("FM_BENCH_C4", "1") != "0":
         c4 = leg_expand_c4(ctx, rank, world, dev, backend)
@@ -618,6 +665,7 @@ def main():
             "classic_ratio_match": crm,
             "single_pair": single,
             "expand_c3": c3,
+            "expand_c3_taus": c3t,
             "expand_c4": c4,
             "float32_route": f32,
             "call_ms": call_ms,

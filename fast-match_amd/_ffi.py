@@ -81,7 +81,7 @@ SYMBOLS = {
     "fm_match_accepted_async": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_mark": (_INT, [_P, ctypes.POINTER(_I64)]),
     "fm_wait": (_INT, [_P, _I64]),
-    "fm_expand_fetch_many": (_INT, [_P, ctypes.c_int32, _P, ctypes.POINTER(_I64), _P, _P, _P]),
+    "fm_expand_fetch_many": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.POINTER(_I64), _P, _P, _P]),
     "fm_match_accepted_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, _P]),
     "fm_match_accepted_dev_batch": (_INT, [_P, ctypes.c_int32, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P]),
     "fm_match_accepted_dev": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, ctypes.POINTER(_I64)]),
@@ -284,7 +284,7 @@ class Context(object):
     def set_option(self, name, value):
         """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
         "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
-        "async_time_every", "expand_big", "expand_prof".  Results never depend on them."""
+        "async_time_every", "expand_big", "expand_grow", "expand_prof".  Results never depend on them."""
         self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def get_option(self, name):
@@ -536,9 +536,21 @@ class Context(object):
                                                 _ptr(t_off), nb, _ptr(tidx), _ptr(dist), _ptr(ratio)))
         return tidx, dist, ratio
 
+    @staticmethod
+    def expand_slots(expanders):
+        """Run slot of every entry of a launch: the k-th entry that names an Expander uses its slot k
+        (fm_expand_run's rule; several thresholds of one pair run side by side, each in a state of its own)."""
+        seen, slots = {}, []
+        for e in expanders:
+            k = seen.get(id(e), 0)
+            slots.append(k)
+            seen[id(e)] = k + 1
+        return slots
+
     def expand_run(self, expanders, seeds, taus):
-        """Run the device-resident expansion loop for several pairs in one launch.
-        Returns per pair (n_matches, n_rounds, n_pairs, status)."""
+        """Run the device-resident expansion loop for several runs in one launch (one workgroup each); an
+        Expander may appear several times (e.g. once per threshold).  Returns per run
+        (n_matches, n_rounds, n_pairs, status)."""
         n = len(expanders)
         seeds = [np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 2, 2) for s in seeds]
         hs = (_P * n)(*[e.handle for e in expanders])
@@ -589,14 +601,17 @@ class Context(object):
     def sync(self):
         self._check(self.lib.fm_sync(self.handle))
 
-    def expand_fetch_many(self, expanders, counts):
-        """(index, positions, ratio) arrays of several Expanders after one ``expand_run``: every copy
-        enqueued, one synchronisation (``Expander.fetch`` costs one per pair)."""
+    def expand_fetch_many(self, expanders, counts, slots=None):
+        """(index, positions, ratio) arrays of several runs after one ``expand_run``: every copy
+        enqueued, one synchronisation (``Expander.fetch`` costs one per pair).  ``slots[i]`` = run slot of
+        ``expanders[i]`` (``expand_slots`` of the launch's list); None = slots by appearance in THIS list."""
         n = len(expanders)
         out = [(np.empty(c, dtype=np.int32), np.empty((c, 2, 2), dtype=np.float64), np.empty(c, dtype=np.float64)) for c in counts]
         if n:
             arr = lambda vals: (_P * n)(*[_P(int(v)) if v is not None else None for v in vals])
-            self._check(self.lib.fm_expand_fetch_many(self.handle, n, arr([e.handle.value for e in expanders]),
+            slots = self.expand_slots(expanders) if slots is None else slots
+            sl = np.ascontiguousarray(slots, dtype=np.int32)
+            self._check(self.lib.fm_expand_fetch_many(self.handle, n, arr([e.handle.value for e in expanders]), _ptr(sl),
                                                       (_I64 * n)(*[int(c) for c in counts]), arr([_ptr(o[0]) for o in out]),
                                                       arr([_ptr(o[1]) for o in out]), arr([_ptr(o[2]) for o in out])))
         return out

@@ -610,7 +610,7 @@ static const OptionDef kOptions[] = {
     {"f32_lpc", &Tuning::f32_lpc, 0, 64, "FM_F32_LPC"},
     {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
-    {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
+    {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
 };
 
 extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value)
@@ -2055,16 +2055,89 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
 // ---------------------------------------------------------------------------------------
 // K7 entry points
 // ---------------------------------------------------------------------------------------
-struct fm_expand {
-    ExpandPair dev{};              // device pointers + parameters (seeds/tau filled per run)
-    void* blob = nullptr;          // one allocation holding every static + work array
+// An fm_expand holds what an image pair's runs SHARE and never change (banks, position index, cell
+// offsets, target positions) plus a pool of run states (pending stack, seen / found tables, result
+// arrays, seed buffer).  One launch may hold several runs of one pair -- the reference is driven as
+// pairs x thresholds (turntable.py:59-60) -- each run in a state of its own, one workgroup each.
+struct ExpandRun {
+    void* blob = nullptr;          // stack | seen | found | m_index | m_pos | m_ratio | result
+    double* stack = nullptr;
+    unsigned long long* seen = nullptr;
+    unsigned long long* found = nullptr;
+    int32_t* m_index = nullptr;
+    double* m_pos = nullptr;
+    double* m_ratio = nullptr;
+    long long* result = nullptr;
     double* d_seeds = nullptr;     // grown on demand
     int64_t seeds_cap = 0;
+    // capacities of THIS run state: they start at the pair's defaults and are multiplied by four when a run
+    // ends with the matching FM_EXPAND_*_FULL status (fm_expand_run then repeats the run)
+    int64_t match_cap = 0, stack_cap = 0, seen_cap = 0, found_cap = 0;
+};
+
+struct fm_expand {
+    ExpandPair dev{};              // device pointers + parameters (run state, seeds and tau filled per run)
+    void* blob = nullptr;          // the shared arrays
     int64_t nq = 0;
+    int64_t match_cap = 0, stack_cap = 0, seen_cap = 0;       // defaults of a new run state
+    std::vector<ExpandRun> runs;   // run slot k = the k-th run of this pair inside one launch
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int64_t pow2_at_least(int64_t x) { int64_t p = 1; while (p < x) p <<= 1; return p; }
+
+static void expand_run_free(ExpandRun& r)
+{
+    if (r.blob) (void)hipFree(r.blob);
+    if (r.d_seeds) (void)hipFree(r.d_seeds);
+    r = ExpandRun{};
+}
+
+// (Re)allocate the arrays of a run state for its current capacities.
+static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
+{
+    if (r.blob) { (void)hipFree(r.blob); r.blob = nullptr; }
+    r.found_cap = pow2_at_least(4 * r.match_cap);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
+    // (seen and found are neighbours: one fill resets both)
+    const size_t o_stack = carve((size_t)r.stack_cap * 32), o_seen = carve((size_t)r.seen_cap * 8), o_found = carve((size_t)r.found_cap * 16);
+    const size_t o_mi = carve((size_t)r.match_cap * 4), o_mp = carve((size_t)r.match_cap * 32), o_mr = carve((size_t)r.match_cap * 8);
+    const size_t o_res = carve(256);
+    hipError_t e = hipMalloc(&r.blob, off);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        r.blob = nullptr;
+        return fail(ctx, FM_ENOMEM, std::string("fm_expand: run state (") + std::to_string(off >> 20) + " MiB): " + hipGetErrorString(e));
+    }
+    char* b = (char*)r.blob;
+    r.stack = (double*)(b + o_stack); r.seen = (unsigned long long*)(b + o_seen); r.found = (unsigned long long*)(b + o_found);
+    r.m_index = (int32_t*)(b + o_mi); r.m_pos = (double*)(b + o_mp); r.m_ratio = (double*)(b + o_mr);
+    r.result = (long long*)(b + o_res);
+    return FM_OK;
+}
+
+// Run slot `slot` of the pair exists after this call (slots are created in order).
+static int expand_ensure_run(fm_ctx* ctx, fm_expand* ex, size_t slot)
+{
+    while (ex->runs.size() <= slot) {
+        ExpandRun r;
+        r.match_cap = ex->match_cap; r.stack_cap = ex->stack_cap; r.seen_cap = ex->seen_cap;
+        int rc = expand_run_alloc(ctx, r);
+        if (rc != FM_OK) return rc;
+        ex->runs.push_back(r);
+    }
+    return FM_OK;
+}
+
+static void expand_bind_run(ExpandPair& P, const ExpandRun& r)
+{
+    P.stack = r.stack; P.stack_cap = r.stack_cap;
+    P.seen = r.seen; P.seen_cap = r.seen_cap;
+    P.found = r.found; P.found_cap = r.found_cap;
+    P.m_index = r.m_index; P.m_pos = r.m_pos; P.m_ratio = r.m_ratio; P.match_cap = r.match_cap;
+    P.result = r.result;
+}
 
 extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
 {
@@ -2103,22 +2176,18 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     fm_expand* ex = new (std::nothrow) fm_expand();
     if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
     ex->nq = nq;
-    const int64_t match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
-    const int64_t stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
-    const int64_t seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
-    const int64_t found_cap = pow2_at_least(4 * match_cap);
-    // carve one allocation
+    ex->match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
+    ex->stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
+    ex->seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
+    // the shared arrays in one allocation
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
     const size_t o_qpos = carve((size_t)nq * 16), o_order = carve((size_t)nq * 4), o_start = carve((size_t)(nb + 1) * 4);
     const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16);
-    const size_t o_stack = carve((size_t)stack_cap * 32), o_seen = carve((size_t)seen_cap * 8), o_found = carve((size_t)found_cap * 16);
-    const size_t o_mi = carve((size_t)match_cap * 4), o_mp = carve((size_t)match_cap * 32), o_mr = carve((size_t)match_cap * 8);
-    const size_t o_res = carve(256);
     hipError_t e = hipMalloc(&ex->blob, off);
     if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
     char* b = (char*)ex->blob;
-    auto bail = [&](int code) { (void)hipFree(ex->blob); delete ex; return code; };
+    auto bail = [&](int code) { for (auto& r : ex->runs) expand_run_free(r); (void)hipFree(ex->blob); delete ex; return code; };
 #define ETRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); \
         return bail(fail(ctx, FM_EDEVICE, std::string(#expr " failed: ") + hipGetErrorString(_e))); } } while (0)
     if (nq) ETRY(hipMemcpyAsync(b + o_qpos, d->query_pos, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -2143,13 +2212,11 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.width = d->width; P.height = d->height; P.cell_w = d->cell_w; P.cell_h = d->cell_h;
     P.rows = d->rows; P.cols = d->cols; P.margin = d->margin; P.radius = d->radius;
     P.seeds = nullptr; P.n_seeds = 0; P.tau = 0.0;
-    P.stack = (double*)(b + o_stack); P.stack_cap = stack_cap;
-    P.seen = (unsigned long long*)(b + o_seen); P.seen_cap = seen_cap;
-    P.found = (unsigned long long*)(b + o_found); P.found_cap = found_cap;
-    P.m_index = (int32_t*)(b + o_mi); P.m_pos = (double*)(b + o_mp); P.m_ratio = (double*)(b + o_mr);
-    P.match_cap = match_cap;
-    P.result = (long long*)(b + o_res);
     P.prof = 0;                        // (set per run from the context's expand_prof option)
+    // the first run state exists from the start (a pair that cannot get one fails here, not at its first run)
+    int rc = expand_ensure_run(ctx, ex, 0);
+    if (rc != FM_OK) return bail(rc);
+    expand_bind_run(P, ex->runs[0]);
     *out = ex;
     return FM_OK;
 }
@@ -2158,10 +2225,18 @@ extern "C" int fm_expand_destroy(fm_ctx* ctx, fm_expand* ex)
 {
     if (!ex) return FM_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    for (auto& r : ex->runs) expand_run_free(r);
     if (ex->blob) (void)hipFree(ex->blob);
-    if (ex->d_seeds) (void)hipFree(ex->d_seeds);
     delete ex;
     return FM_OK;
+}
+
+// Run slot of entry i of a launch: how many earlier entries name the same pair.
+static int expand_slot_of(fm_expand* const* pairs, int i)
+{
+    int k = 0;
+    for (int j = 0; j < i; ++j) k += pairs[j] == pairs[i] ? 1 : 0;
+    return k;
 }
 
 extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
@@ -2174,28 +2249,43 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     if (!pairs || !seeds || !n_seeds || !tau) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<ExpandPair> host((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        fm_expand* ex = pairs[i];
-        if (!ex) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL pair");
-        for (int j = 0; j < i; ++j) if (pairs[j] == ex) return fail(ctx, FM_EINVAL, "fm_expand_run: a pair appears twice in one launch");
-        if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
-        if (n_seeds[i] > ex->seeds_cap) {
-            if (ex->d_seeds) { HIP_TRY(ctx, hipFree(ex->d_seeds)); ex->d_seeds = nullptr; ex->seeds_cap = 0; }
-            const int64_t cap = n_seeds[i] + n_seeds[i] / 2 + 64;
-            HIP_TRY(ctx, hipMalloc((void**)&ex->d_seeds, (size_t)cap * 32));
-            ex->seeds_cap = cap;
+    std::vector<ExpandRun*> run((size_t)n);
+    int rc;
+    {
+        // slots by occurrence (a map instead of expand_slot_of's quadratic scan: a launch may hold thousands of runs)
+        std::map<fm_expand*, int> seen_pairs;
+        for (int i = 0; i < n; ++i) {
+            fm_expand* ex = pairs[i];
+            if (!ex) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL pair");
+            if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
+            const int slot = seen_pairs[ex]++;
+            if ((rc = expand_ensure_run(ctx, ex, (size_t)slot)) != FM_OK) return rc;
+        }
+        seen_pairs.clear();
+        for (int i = 0; i < n; ++i) {                      // (pointers into runs[] are taken once the vectors stopped growing)
+            fm_expand* ex = pairs[i];
+            ExpandRun* r = &ex->runs[(size_t)seen_pairs[ex]++];
+            run[(size_t)i] = r;
+            if (n_seeds[i] > r->seeds_cap) {
+                if (r->d_seeds) { HIP_TRY(ctx, hipFree(r->d_seeds)); r->d_seeds = nullptr; r->seeds_cap = 0; }
+                const int64_t cap = n_seeds[i] + n_seeds[i] / 2 + 64;
+                HIP_TRY(ctx, hipMalloc((void**)&r->d_seeds, (size_t)cap * 32));
+                r->seeds_cap = cap;
+            }
         }
     }
-    int rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, (size_t)n * sizeof(ExpandPair) + 64);
+    rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, (size_t)n * sizeof(ExpandPair) + 64);
     if (rc != FM_OK) return rc;
     CallScope cs(ctx);
     for (int i = 0; i < n; ++i) {
         fm_expand* ex = pairs[i];
-        if (n_seeds[i]) HIP_TRY(ctx, hipMemcpyAsync(ex->d_seeds, seeds[i], (size_t)n_seeds[i] * 32, hipMemcpyHostToDevice, ctx->stream));
-        // (the two tables are neighbours in the pair's allocation: one fill)
-        HIP_TRY(ctx, hipMemsetAsync(ex->dev.seen, 0xff, (size_t)((char*)ex->dev.found - (char*)ex->dev.seen) + (size_t)ex->dev.found_cap * 16, ctx->stream));
+        ExpandRun* r = run[(size_t)i];
+        if (n_seeds[i]) HIP_TRY(ctx, hipMemcpyAsync(r->d_seeds, seeds[i], (size_t)n_seeds[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+        // (the two tables are neighbours in the run's allocation: one fill)
+        HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
         host[i] = ex->dev;
-        host[i].seeds = ex->d_seeds;
+        expand_bind_run(host[i], *r);
+        host[i].seeds = r->d_seeds;
         host[i].n_seeds = n_seeds[i];
         host[i].tau = tau[i];
         host[i].prof = ctx->tune.expand_prof;
@@ -2214,35 +2304,62 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     ctx->kernel_timed = true;
     std::vector<long long> res((size_t)n * 4);
     for (int i = 0; i < n; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], pairs[i]->dev.result, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // Pairs in which a round's radius subset exceeded the kernel's capacity (status 2) run again, from
-    // the start, in the larger-capacity variant of the kernel (int8 banks); the rest keep their results.
-    {
+    // Runs that ended on a capacity run again, from the start: a radius subset beyond the kernel's 2048 rows
+    // (status 2, int8 banks) in the 4096-row variant of the kernel; a full pending stack, result list or
+    // hash table (status 1, 4, 5: thresholds above 1 accept nearly every cross-checked pair and the
+    // expansion heads for every (cell, query cell) combination) in a run state four times as large, at most
+    // `expand_grow` times over (default 2; the status stands after that).  The other runs keep their results.
+    std::vector<char> big((size_t)n, 0);
+    for (int pass = 0; pass <= ctx->tune.expand_grow + 1; ++pass) {
         std::vector<int> redo;
-        for (int i = 0; i < n; ++i) if (res[(size_t)i * 4 + 3] == 2 && !host[i].f32 && ctx->tune.expand_big) redo.push_back(i);
-        if (!redo.empty()) {
-            grouped.clear();
-            for (int i : redo) {
-                HIP_TRY(ctx, hipMemsetAsync(pairs[i]->dev.seen, 0xff, (size_t)pairs[i]->dev.seen_cap * 8, ctx->stream));
-                HIP_TRY(ctx, hipMemsetAsync(pairs[i]->dev.found, 0xff, (size_t)pairs[i]->dev.found_cap * 16, ctx->stream));
-                grouped.push_back(host[i]);
+        for (int i = 0; i < n; ++i) {
+            const long long st = res[(size_t)i * 4 + 3];
+            ExpandRun* r = run[(size_t)i];
+            if (st == 2 && !host[i].f32 && ctx->tune.expand_big && !big[(size_t)i]) { big[(size_t)i] = 1; redo.push_back(i); continue; }
+            if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (big[(size_t)i] ? 1 : 0)) {
+                const int64_t limit = (int64_t)1 << 28;
+                if (st == 1) { if (r->stack_cap >= limit) continue; r->stack_cap *= 4; }
+                if (st == 4) { if (r->match_cap >= limit) continue; r->match_cap *= 4; }
+                if (st == 5) { if (r->seen_cap >= limit) continue; r->seen_cap *= 4; }
+                if (expand_run_alloc(ctx, *r) != FM_OK) {                 // no memory for the larger state: the status stands
+                    r->match_cap = pairs[i]->match_cap; r->stack_cap = pairs[i]->stack_cap; r->seen_cap = pairs[i]->seen_cap;
+                    if ((rc = expand_run_alloc(ctx, *r)) != FM_OK) return rc;
+                    continue;
+                }
+                expand_bind_run(host[i], *r);
+                redo.push_back(i);
             }
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), redo.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, launch_expand(ctx->ws_in, (int)redo.size(), false, true, ctx->stream));
+        }
+        if (redo.empty()) break;
+        for (int v = 0; v < 2; ++v) {                   // the two int8 capacity variants (float32 pairs: the small one)
+            grouped.clear();
+            std::vector<int> idx;
+            for (int i : redo) if ((big[(size_t)i] ? 1 : 0) == v && !host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
+            const int n8 = (int)idx.size();
+            if (v == 0) for (int i : redo) if (host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
+            if (idx.empty()) continue;
+            for (int i : idx)
+                HIP_TRY(ctx, hipMemsetAsync(run[(size_t)i]->seen, 0xff, (size_t)((char*)run[(size_t)i]->found - (char*)run[(size_t)i]->seen) +
+                                            (size_t)run[(size_t)i]->found_cap * 16, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), grouped.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+            if (n8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n8, false, v == 1, ctx->stream));
+            if ((int)idx.size() > n8)
+                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n8 * sizeof(ExpandPair), (int)idx.size() - n8, true, false, ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-            for (int i : redo)
-                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], pairs[i]->dev.result, 32, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i : idx)
+                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (ws_in is reused by the next variant)
         }
     }
     for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
     if (ctx->tune.expand_prof) {
         long long pr[16];
-        (void)hipMemcpy(pr, pairs[0]->dev.result, sizeof(pr), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
         static const char* names[12] = {"pop:barrier", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "pop:thread0",
                                         "x1:bfrag+barrier", "x1:gather", "x1:mfma", "x1:merge"};
-        fprintf(stderr, "[fm_expand prof, pair 0, %lld rounds] ", pr[1]);
+        fprintf(stderr, "[fm_expand prof, run 0, %lld rounds] ", pr[1]);
         for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
         fprintf(stderr, "\n");
     }
@@ -2260,26 +2377,15 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
 extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index, double* positions, double* ratio)
 {
     if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_fetch: NULL argument");
-    if (n < 0 || n > ex->dev.match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch: n out of range");
-    if (n == 0) return FM_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    struct StageGuard {      // drop the staged copies on every exit path (their targets die with the call)
-        fm_ctx* c;
-        ~StageGuard() { c->staged.clear(); c->h_stage_used = 0; }
-    } guard{ctx};
-    ctx->staged.clear();
-    ctx->h_stage_used = 0;
-    if (index) HIP_TRY(ctx, d2h(ctx, index, ex->dev.m_index, (size_t)n * 4));
-    if (positions) HIP_TRY(ctx, d2h(ctx, positions, ex->dev.m_pos, (size_t)n * 32));
-    if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ex->dev.m_ratio, (size_t)n * 8));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
-    return FM_OK;
+    const int32_t slot = 0;
+    const fm_expand* one = ex;
+    int32_t* ip = index; double* pp = positions; double* rp = ratio;
+    return fm_expand_fetch_many(ctx, 1, &one, &slot, &n, index ? &ip : nullptr, positions ? &pp : nullptr, ratio ? &rp : nullptr);
 }
 
-// The results of several pairs of one fm_expand_run in ONE pass: every copy is enqueued, then a single
-// synchronisation (fm_expand_fetch per pair costs a synchronisation each: 64 pairs = 2 ms of a 32 ms call).
-extern "C" int fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int64_t* n,
+// The results of several runs of one fm_expand_run in ONE pass: every copy is enqueued, then a single
+// synchronisation (a synchronisation per run: 64 runs = 2 ms of a 32 ms call).
+extern "C" int fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int32_t* slot, const int64_t* n,
                                     int32_t* const* index, double* const* positions, double* const* ratio)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_fetch_many: ctx is NULL");
@@ -2287,13 +2393,17 @@ extern "C" int fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* 
     if (n_ex == 0) return FM_OK;
     if (!ex || !n) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: NULL argument");
     size_t total = 0;
+    std::vector<const ExpandRun*> run((size_t)n_ex);
     for (int i = 0; i < n_ex; ++i) {
         if (!ex[i]) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: NULL pair");
-        if (n[i] < 0 || n[i] > ex[i]->dev.match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: n out of range");
+        const int s = slot ? slot[i] : expand_slot_of((fm_expand* const*)ex, i);
+        if (s < 0 || (size_t)s >= ex[i]->runs.size()) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: the pair has no such run slot");
+        run[(size_t)i] = &ex[i]->runs[(size_t)s];
+        if (n[i] < 0 || n[i] > run[(size_t)i]->match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: n out of range");
         total += (size_t)n[i] * 44 + 192;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    struct StageGuard {
+    struct StageGuard {      // drop the staged copies on every exit path (their targets die with the call)
         fm_ctx* c;
         ~StageGuard() { c->staged.clear(); c->h_stage_used = 0; }
     } guard{ctx};
@@ -2309,9 +2419,9 @@ extern "C" int fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* 
     }
     for (int i = 0; i < n_ex; ++i) {
         if (n[i] == 0) continue;
-        if (index && index[i]) HIP_TRY(ctx, d2h(ctx, index[i], ex[i]->dev.m_index, (size_t)n[i] * 4));
-        if (positions && positions[i]) HIP_TRY(ctx, d2h(ctx, positions[i], ex[i]->dev.m_pos, (size_t)n[i] * 32));
-        if (ratio && ratio[i]) HIP_TRY(ctx, d2h(ctx, ratio[i], ex[i]->dev.m_ratio, (size_t)n[i] * 8));
+        if (index && index[i]) HIP_TRY(ctx, d2h(ctx, index[i], run[(size_t)i]->m_index, (size_t)n[i] * 4));
+        if (positions && positions[i]) HIP_TRY(ctx, d2h(ctx, positions[i], run[(size_t)i]->m_pos, (size_t)n[i] * 32));
+        if (ratio && ratio[i]) HIP_TRY(ctx, d2h(ctx, ratio[i], run[(size_t)i]->m_ratio, (size_t)n[i] * 8));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);

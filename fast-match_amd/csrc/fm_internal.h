@@ -71,6 +71,8 @@ struct Tuning {
     int batch_tail = 2;               // ... pairs of the short launch a run ends with (0 = none)
     int async_time_every = 4;         // async calls: every n-th call carries kernel timing events (0 = none)
     int expand_big = 1;               // K7: re-run pairs that overflow the 2048-row round in the 4096-row variant
+    int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a
+                                      // state four times as large (0 = never: the status goes to the caller)
     int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
 };
 

@@ -65,11 +65,13 @@ def evaluate(pairs, thresholds, scorers, options={}, match_fun=None):
     match_fun = match_fun or fastmatch.match
     opts = dict(options, return_arrays=True)
     getters = [match_fun(q, t, opts) for q, t in pairs]            # seeding once per pair
+    thresholds = [float(t) for t in thresholds]
+    results = matches_for_thresholds(getters, thresholds)
     rows = []
-    for tau in thresholds:
+    for ti, tau in enumerate(thresholds):
         correct = total = 0
-        for get, score in zip(getters, scorers):
-            res = get(tau)
+        for pi, score in enumerate(scorers):
+            res = results[pi][ti]
             if isinstance(res, tuple):
                 index, positions, ratio = res
             else:                                                  # host loop: list of (index, dict)
@@ -82,3 +84,32 @@ def evaluate(pairs, thresholds, scorers, options={}, match_fun=None):
         rows.append({"tau": float(tau), "correct": correct, "total": total,
                      "precision": (correct / total) if total else float("nan")})
     return rows
+
+
+def matches_for_thresholds(getters, thresholds, as_arrays=True):
+    """results[pair][threshold] for closures returned by ``fastmatch.match``: every (pair, threshold)
+    run whose pair has device-resident expansion state goes into ONE launch of the device loop (one
+    workgroup per run) and one fetch; the rest -- and runs the device gave up on -- take the closure's
+    own path.  The reference evaluates them one after the other: ``{ tau : f(tau) for tau in thresholds }``
+    per pair (turntable.py:59-60)."""
+    results = [[None] * len(thresholds) for _ in getters]
+    runs = []                                                      # (pair, threshold index, expander)
+    for pi, get in enumerate(getters):
+        ex = get.expander() if hasattr(get, "expander") else None
+        if ex is not None:
+            runs.extend((pi, ti, ex) for ti in range(len(thresholds)))
+    by_ctx = {}
+    for r in runs:
+        by_ctx.setdefault(id(getters[r[0]].context), []).append(r)
+    for group in by_ctx.values():
+        ctx = getters[group[0][0]].context
+        got = fastmatch.run_device_loops(ctx, [ex for _, _, ex in group],
+                                         [getters[pi].seeds_for(thresholds[ti]) for pi, ti, _ in group],
+                                         [thresholds[ti] for _, ti, _ in group], as_arrays=as_arrays)
+        for (pi, ti, _), res in zip(group, got):
+            results[pi][ti] = res
+    for pi, get in enumerate(getters):
+        for ti, tau in enumerate(thresholds):
+            if results[pi][ti] is None:
+                results[pi][ti] = get(tau)
+    return results

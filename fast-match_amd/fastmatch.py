@@ -60,25 +60,50 @@ def match(query_cache, target_img, options={}):
                        and options.get("device_loop", True))
     state = {"expander": None}
 
-    # A function where tau can be varied to get different results
-    def get_matches(tau):
-        thumb_tau = thumb_strategy(tau)
-        seeds = thumb_positions[thumb_ratios < thumb_tau]
-        if use_device_loop:
-            if state["expander"] is None:
-                state["expander"] = make_expander(query_cache, target_cache, radius, context)
-            if state["expander"] is not False:
-                res = run_device_loops(context, [state["expander"]], [seeds], [tau], stats=stats,
-                                       as_arrays=options.get("return_arrays", False))[0]
-                if res is not None:
-                    return res
-        return do_iter(iter(seeds), query_cache, target_cache, tau=tau, thumb_tau=thumb_tau,
+    def seeds_for(tau):
+        return thumb_positions[thumb_ratios < thumb_strategy(tau)]
+
+    def expander():
+        """The pair's device-resident expansion state (built on first use), or None."""
+        if not use_device_loop:
+            return None
+        if state["expander"] is None:
+            state["expander"] = make_expander(query_cache, target_cache, radius, context)
+        return state["expander"] or None
+
+    def host_loop(tau):
+        return do_iter(iter(seeds_for(tau)), query_cache, target_cache, tau=tau, thumb_tau=thumb_strategy(tau),
                        radius=radius, log=log, context=context, stats=stats)
 
+    # A function where tau can be varied to get different results.  Addition: a LIST of thresholds
+    # (the reference's driver asks one pair for many, turntable.py:59-60) returns the list of their
+    # results from ONE launch of the device loop -- the runs are independent, one workgroup each.
+    def get_matches(tau):
+        if np.ndim(tau) > 0:
+            taus = [float(t) for t in tau]
+            res = [None] * len(taus)
+            ex = expander()
+            if ex is not None and taus:
+                res = run_device_loops(context, [ex] * len(taus), [seeds_for(t) for t in taus], taus, stats=stats,
+                                       as_arrays=options.get("return_arrays", False))
+            return [r if r is not None else host_loop(t) for r, t in zip(res, taus)]
+        ex = expander()
+        if ex is not None:
+            res = run_device_loops(context, [ex], [seeds_for(tau)], [tau], stats=stats,
+                                   as_arrays=options.get("return_arrays", False))[0]
+            if res is not None:
+                return res
+        return host_loop(tau)
+
+    # (for drivers that put the runs of SEVERAL pairs into one launch: evaluate.evaluate)
+    get_matches.expander = expander
+    get_matches.seeds_for = seeds_for
+    get_matches.host_loop = host_loop
+    get_matches.context = context
     return get_matches
 
 
-def make_expander(query_cache, target_grid, radius, context):
+def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_cap=0):
     """Device-resident expansion state for (query_cache, target_grid), or False when the
     pair cannot use the device loop (oversize geometry, float32 banks the fp16 filter cannot
     take).  Integer-valued descriptors run the int8 round, others (RootSIFT-style float32)
@@ -97,19 +122,23 @@ def make_expander(query_cache, target_grid, radius, context):
             "margin": target_grid.margin}
     try:
         return _ffi.Expander(context, q_bank, query_cache.original["positions"],
-                             query_cache.original["position_tree"], t_bank, cell_off, t_pos, grid, radius)
+                             query_cache.original["position_tree"], t_bank, cell_off, t_pos, grid, radius,
+                             match_cap=match_cap, stack_cap=stack_cap)
     except _ffi.FastMatchHipError:
         return False
 
 
 def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):
-    """One launch of the device-resident loop for several independent pairs.  Returns, per
-    pair, the match list in do_iter's format (or (index, positions, ratio) arrays), or None
+    """One launch of the device-resident loop for several independent runs: (expander, seeds, tau)
+    triples, an expander may appear several times (several thresholds of one pair).  Returns, per
+    run, the match list in do_iter's format (or (index, positions, ratio) arrays), or None
     where the device gave up (caller falls back to the host loop)."""
     out = []
     results = context.expand_run(expanders, seeds, taus)
+    slots = context.expand_slots(expanders)
     ok = [i for i, r in enumerate(results) if r[3] == 0]
-    fetched = dict(zip(ok, context.expand_fetch_many([expanders[i] for i in ok], [results[i][0] for i in ok])))
+    fetched = dict(zip(ok, context.expand_fetch_many([expanders[i] for i in ok], [results[i][0] for i in ok],
+                                                     slots=[slots[i] for i in ok])))
     for i, (ex, (n_matches, n_rounds, n_pairs, status)) in enumerate(zip(expanders, results)):
         if status != 0:
             if stats is not None:

@@ -65,6 +65,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "f32_nw" "f32_nsplit" "f32_fused" "f32_lpc"   K8 launch shape (0 / -1 = rule)
  *   "async_time_every"    every n-th async call carries kernel-timing events (4; 0 = none)
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
+ *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
+ *                         repeated in a run state four times as large (2)
  *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
  * Unknown names and out-of-range values return FM_EINVAL.                                          */
 int  fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value);
@@ -287,8 +289,9 @@ typedef struct fm_expand_desc {
     int32_t        cell_w, cell_h; /* Grid_Cache cell size                                  */
     int32_t        rows, cols;     /* Grid_Cache.rows (cells along x), .cols (along y)      */
     int32_t        margin, radius;
-    int64_t        match_cap;      /* capacity of the result list (0 = 4 * nq)              */
-    int64_t        stack_cap;      /* capacity of the pending stack (0 = default)           */
+    int64_t        match_cap;      /* first capacity of the result list (0 = 4 * nq) and    */
+    int64_t        stack_cap;      /* of the pending stack (0 = default); fm_expand_run     */
+                                   /* repeats a run that fills one in a state 4x as large   */
 } fm_expand_desc;
 
 #define FM_EXPAND_OK            0
@@ -296,27 +299,32 @@ typedef struct fm_expand_desc {
 #define FM_EXPAND_SUBSET_FULL   2  /* a radius subset exceeded 4096 query rows (2048 for float32 banks):
                                       * pairs that exceed 2048 are re-run by fm_expand_run in a larger-capacity kernel */
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
-#define FM_EXPAND_MATCH_FULL    4
+#define FM_EXPAND_MATCH_FULL    4  /* 1, 4, 5: reported only when the run state could not grow any further */
 #define FM_EXPAND_TABLE_FULL    5
 #define FM_EXPAND_LIST_FULL     6  /* float32 round: more candidates inside the fp16 margin than fit  */
 
 int  fm_expand_create(fm_ctx* ctx, const fm_expand_desc* desc, fm_expand** out);
 int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
-/* Run n pairs in one launch.  seeds[i] = [n_seeds[i]][2][2] float64 (query_pos, target_pos)
- * in visiting order (fastmatch.pyx:50), tau[i] the ratio threshold.  Per pair outputs:
- * number of matches, rounds, descriptor pairs evaluated, and a FM_EXPAND_* status (non-zero
- * = the device gave up; the caller falls back to the host loop).                          */
+/* Run n expansions in one launch, one workgroup each.  Run i = (pairs[i], seeds[i], tau[i]): seeds[i] =
+ * [n_seeds[i]][2][2] float64 (query_pos, target_pos) in visiting order (fastmatch.pyx:50), tau[i] the
+ * ratio threshold.  A pair may appear SEVERAL times -- the reference is driven as pairs x thresholds
+ * (turntable.py:59-60: { tau : f(tau) for tau in thresholds } per pair) and the runs of one pair are
+ * independent of each other: each gets a run state of its own (pending stack, seen / found tables,
+ * result list; created on first use, kept), the k-th appearance of a pair in a launch uses its run
+ * slot k.  Per run outputs: number of matches, rounds, descriptor pairs evaluated, and a FM_EXPAND_*
+ * status (non-zero = the device gave up; the caller falls back to the host loop).                */
 int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
                    const int64_t* n_seeds, const double* tau, int64_t* n_matches,
                    int64_t* n_rounds, int64_t* n_pairs, int32_t* status);
-/* Copy the first n results of the last run of `ex`: query row index, positions [n][2][2]
+/* Copy the first n results of the last run in slot 0 of `ex`: query row index, positions [n][2][2]
  * (query x,y then target x,y) and ratio -- the tuples do_iter appends (fastmatch.pyx:86). */
 int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index,
                      double* positions, double* ratio);
-/* fm_expand_fetch for several pairs of one fm_expand_run with a single synchronisation: n[i] results of
- * ex[i] into index[i] / positions[i] / ratio[i] (any of the three arrays of pointers, or single
- * entries, may be NULL).                                                                          */
-int  fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int64_t* n,
+/* fm_expand_fetch for several runs of one fm_expand_run with a single synchronisation: n[i] results of
+ * run slot slot[i] of ex[i] into index[i] / positions[i] / ratio[i] (any of the three arrays of
+ * pointers, or single entries, may be NULL).  slot == NULL: slots by appearance, as fm_expand_run
+ * assigns them (the k-th entry naming a pair reads its slot k).                                    */
+int  fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int32_t* slot, const int64_t* n,
                           int32_t* const* index, double* const* positions, double* const* ratio);
 
 /* ---- result gather across the GPUs of a node (RCCL over xGMI) --------------------------------

@@ -81,6 +81,20 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
         assert oget.rounds == ds["rounds"]
         _same_matches(dev, exp)
 
+    # Eight thresholds of the pair in ONE launch (eight workgroups, a run state each) == the calls one by
+    # one; the oracle replays a second threshold in full (0.7 above is the first).
+    taus = [0.5, 0.55, 0.6, 0.65, 0.7, 0.8, 0.9, 1.0]
+    ms = {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": ms})
+    many = get(taus)
+    assert ms["device_loops"] == len(taus) and ms.get("device_fallbacks", 0) == 0
+    _same_matches(many[4], dev)
+    for k in (0, 7):
+        _same_matches(many[k], get(taus[k]))
+    assert [len(m) for m in many] == sorted(len(m) for m in many)
+    if not cap:
+        _same_matches(many[1], fo.o_match(oq, ot, {})(0.55))
+
 
 def test_config4_batch_of_64_pairs_one_launch(ctx):
     n_pairs = 64

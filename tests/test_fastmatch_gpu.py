@@ -232,6 +232,100 @@ def test_evaluate_many_thresholds_reuses_state(ctx):
     assert dev[2]["precision"] > 0.7
 
 
+def test_many_thresholds_of_one_pair_in_one_launch(ctx, monkeypatch):
+    """get_matches([taus]) runs every threshold of the pair in ONE launch of the device loop (one
+    workgroup and one run state each): each list equals the single-threshold call and the oracle, in
+    any order of the thresholds, repeated (run states are reused), with a threshold twice."""
+    mc, fi, oq, ot = _build((800, 640), 3000, seed=4242, ctx=ctx)
+    calls = []
+    orig = fastmatch.run_device_loops
+
+    def spy(context, expanders, seeds, taus, **k):
+        calls.append(len(expanders))
+        return orig(context, expanders, seeds, taus, **k)
+    monkeypatch.setattr(fastmatch, "run_device_loops", spy)
+    stats = {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})
+    taus = [0.9, 0.5, 0.7, 1.0, 0.7, 0.6, 0.8, 0.95]
+    oget = fo.o_match(oq, ot, {})
+    exp = {t: oget(t) for t in set(taus)}
+    for rep in range(2):
+        del calls[:]
+        stats.clear()
+        many = get(taus)
+        assert calls == [len(taus)], "the thresholds did not share one launch"
+        assert stats["device_loops"] == len(taus)
+        for t, got in zip(taus, many):
+            _same_matches(got, exp[t])
+    for t in (0.7, 1.0):
+        _same_matches(get(t), exp[t])                      # the single-threshold call (run slot 0) still works
+    assert len(exp[1.0]) > len(exp[0.7]) >= len(exp[0.5]) > 0
+    # numpy array of thresholds, empty list
+    _same_matches(get(np.array([0.7]))[0], exp[0.7])
+    assert get([]) == []
+
+
+def test_run_states_grow_when_a_run_fills_them(ctx):
+    """A run that fills its result list or pending stack is repeated by fm_expand_run in a state four
+    times as large (option expand_grow, default twice): tiny first capacities give the results of the
+    default ones; with growth switched off the status reaches the caller."""
+    import fastmatch_amd
+    from fastmatch_amd.cache import Grid_Cache
+    mc, fi, oq, ot = _build((640, 480), 2000, seed=77, ctx=ctx)
+    pos, ratios = fastmatch.match_thumbs(fi, mc, context=ctx)
+    seeds = pos[ratios < 0.7]
+    grid = Grid_Cache(fi, (50, 50), fi, margin=25)
+    ref = fastmatch.run_device_loops(ctx, [fastmatch.make_expander(mc, grid, 100, ctx)], [seeds], [0.7])[0]
+    assert ref is not None and len(ref) > 300
+    c = fastmatch_amd.Context(0)
+    c.set_option("expand_grow", 4)                          # four steps in all: 64 -> 1024 results, 2048 -> 8192+ stack entries
+    mc2 = cache.Metric_Cache.from_arrays(mc.original["descriptors"], mc.original["positions"], mc.original["size"],
+                                         mc.thumb["descriptors"], mc.thumb["positions"], mc.thumb["size"], options={"context": c})
+    small = fastmatch.make_expander(mc2, grid, 100, c, match_cap=64, stack_cap=2048)
+    got = fastmatch.run_device_loops(c, [small, small], [seeds, seeds], [0.7, 0.7])
+    _same_matches(got[0], ref)
+    _same_matches(got[1], ref)
+    _same_matches(fastmatch.run_device_loops(c, [small], [seeds], [0.7])[0], ref)      # (the grown state is kept)
+    c.set_option("expand_grow", 0)
+    tiny = fastmatch.make_expander(mc2, grid, 100, c, match_cap=64, stack_cap=65536)
+    res = c.expand_run([tiny], [seeds], [0.7])
+    assert res[0][3] == 4                                   # FM_EXPAND_MATCH_FULL
+    c.close()
+
+
+def test_evaluate_puts_all_pairs_and_thresholds_into_one_launch(ctx, monkeypatch):
+    from fastmatch_amd import evaluate
+    pairs, scorers = [], []
+    for k in range(3):
+        q, t = synth.image_pair((640, 480), 2500, seed=300 + k)
+        mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                            q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+        fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                                 t["thumb_descriptors"], t["thumb_size"])
+        pairs.append((mc, fi))
+        scorers.append(evaluate.planted_scorer(q["planted"], t["positions"]))
+    calls = []
+    orig = fastmatch.run_device_loops
+
+    def spy(context, expanders, seeds, taus, **k):
+        calls.append((len(expanders), len(set(id(e) for e in expanders))))
+        return orig(context, expanders, seeds, taus, **k)
+    monkeypatch.setattr(fastmatch, "run_device_loops", spy)
+    taus = list(np.linspace(0.5, 1.0, 15))                  # 15 thresholds, the reference's count (Evaluate Turntable.ipynb)
+    dev = evaluate.evaluate(pairs, taus, scorers, {"context": ctx})
+    assert calls == [(45, 3)]                               # 3 pairs x 15 thresholds, one launch
+    # the sequential driver (one launch per pair and threshold) gives the same table
+    getters = [fastmatch.match(q, t, {"context": ctx, "return_arrays": True}) for q, t in pairs]
+    for row, tau in zip(dev, taus):
+        correct = total = 0
+        for get, score in zip(getters, scorers):
+            index, positions, ratio = get(float(tau))
+            correct += int(score(index, positions, ratio).sum())
+            total += len(index)
+        assert (row["correct"], row["total"]) == (correct, total)
+    assert dev[4]["precision"] > 0.7
+
+
 def test_match_on_non_integer_descriptors_takes_the_float_route(ctx, monkeypatch):
     """RootSIFT-style (non-integer float32) descriptors: fastmatch.match() runs the
     device-resident loop with the float32 round, the host loop runs one float32 round launch
