@@ -29,7 +29,7 @@
 #include <stdlib.h>
 
 #ifdef FM_COUNT_VISITS
-__device__ unsigned long long g_visits[256];     // [split]: exact-path visits (wave, block), [128 + split]: units x blocks
+__device__ unsigned long long g_visits[256];     // [split]: exact-path visits (wave, block), [64 + split]: lanes that want them, [128 + split]: units x blocks
 extern "C" int fm_debug_visits(unsigned long long* out, int reset)
 {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_visits), sizeof(g_visits));
@@ -274,7 +274,10 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
                 for (int j = 0; j < NC; ++j) {
                     if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
 #ifdef FM_COUNT_VISITS
-                        if (lane == 0) atomicAdd(&g_visits[split & 127], 1ull);
+                        {   // [split]: visits, [64 + split]: lanes of those visits whose own candidates reach their threshold
+                            const unsigned long long wm = __builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]);
+                            if (lane == 0) { atomicAdd(&g_visits[split & 63], 1ull); atomicAdd(&g_visits[64 + (split & 63)], (unsigned long long)__popcll(wm)); }
+                        }
 #endif
                         const int best_before = top[j].key[0];
                         const bool improved = top[j].update(acc[0][j], acc[1][j], low0, low1,

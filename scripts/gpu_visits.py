@@ -17,7 +17,9 @@ for name, fn in (("k1", lambda: ctx.xcheck1(qb, tb)), ("k2", lambda: ctx.knn2(qb
     raw.fm_debug_visits(None, 1)
     fn()
     raw.fm_debug_visits(buf, 1)
-    v = np.array(buf[:128], dtype=np.float64); u = np.array(buf[128:], dtype=np.float64)
+    v = np.array(buf[:64], dtype=np.float64); w = np.array(buf[64:128], dtype=np.float64); u = np.array(buf[128:], dtype=np.float64)
     n = int((u > 0).sum())
-    print(name, "splits", n, "overall visit rate %.4f" % (v.sum() / u.sum()))
+    print(name, "splits", n, "overall visit rate %.4f" % (v.sum() / u.sum()), "visits %.3g" % v.sum(),
+          "lanes wanting %.3g (%.2f per visit)" % (w.sum(), w.sum() / max(v.sum(), 1)))
     print("  per split:", " ".join("%.3f" % (v[i] / u[i]) for i in range(n)))
+    print("  lanes per visit, per split:", " ".join("%.1f" % (w[i] / max(v[i], 1)) for i in range(n)))
