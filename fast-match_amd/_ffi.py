@@ -39,7 +39,7 @@ class fm_expand_desc(ctypes.Structure):
                 ("cell_w", ctypes.c_int32), ("cell_h", ctypes.c_int32),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
                 ("margin", ctypes.c_int32), ("radius", ctypes.c_int32),
-                ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64)]
+                ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64), ("metric", ctypes.c_int32)]
 
 
 EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 4096 rows (2048 for float32 banks)",
@@ -95,6 +95,7 @@ SYMBOLS = {
     "fm_comm_init": (_INT, [_P, _INT, _INT, _P]),
     "fm_comm_destroy": (_INT, [_P]),
     "fm_gather_matches": (_INT, [_P, _P, _P, _I64, _P, _P, _INT]),
+    "fm_gather_matches_counted": (_INT, [_P, _P, _P, _I64, _P, _P, ctypes.POINTER(_I64)]),
 }
 
 _lib = None
@@ -223,6 +224,7 @@ class Expander(object):
         d.cell_w, d.cell_h = grid["cell_w"], grid["cell_h"]
         d.rows, d.cols, d.margin, d.radius = grid["rows"], grid["cols"], grid["margin"], int(radius)
         d.match_cap, d.stack_cap = int(match_cap), int(stack_cap)
+        d.metric = int(getattr(index, "metric", 0))         # Position_Index.metric = FM_METRIC_*
         h = _P()
         ctx._check(ctx.lib.fm_expand_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
         self.handle = h
@@ -587,6 +589,14 @@ class Context(object):
         [nranks, cap, 3] int32 and [nranks] int64 (addresses, e.g. ``tensor.data_ptr()``)."""
         self._check(self.lib.fm_gather_matches(self.handle, _P(int(rows_ptr)), _P(int(count_ptr)), int(cap),
                                                _P(int(all_rows_ptr)), _P(int(all_counts_ptr)), 1 if wait else 0))
+
+    def gather_matches_counted(self, rows_ptr, count_ptr, cap, all_rows_ptr, all_counts_ptr):
+        """Two-phase form of ``gather_matches``: counts first, then only ``m`` = the fullest rank's rows per
+        rank; the rows arrive as [nranks, m, 3] at ``all_rows_ptr``.  Returns m.  Synchronous."""
+        m = _I64(0)
+        self._check(self.lib.fm_gather_matches_counted(self.handle, _P(int(rows_ptr)), _P(int(count_ptr)), int(cap),
+                                                       _P(int(all_rows_ptr)), _P(int(all_counts_ptr)), ctypes.byref(m)))
+        return int(m.value)
 
     # -- bookkeeping ---------------------------------------------------------------------
     def stats(self):

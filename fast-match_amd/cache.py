@@ -33,17 +33,47 @@ from . import matchutil
 # ---------------------------------------------------------------------------------------
 # Position index (replaces sklearn BallTree.query_radius, cache.pyx:180-186,276)
 # ---------------------------------------------------------------------------------------
+METRIC_L2, METRIC_L1, METRIC_LINF = 0, 1, 2
+_METRICS = {"minkowski": METRIC_L2, "euclidean": METRIC_L2, "l2": METRIC_L2,
+            "manhattan": METRIC_L1, "cityblock": METRIC_L1, "l1": METRIC_L1,
+            "chebyshev": METRIC_LINF, "infinity": METRIC_LINF}
+
+
+def metric_code(metric, p=None):
+    """The reference hands ``options["metric"]`` to ``BallTree(positions, metric=metric)``
+    (cache.pyx:160, 276; default "minkowski", i.e. p = 2).  Served here: the Minkowski family a 2-D
+    keypoint index has a use for -- p = 2 ("minkowski", "euclidean", "l2"), p = 1 ("manhattan",
+    "cityblock", "l1"), p = inf ("chebyshev", "infinity"); "minkowski" with ``p`` in {1, 2, inf}
+    likewise.  Anything else raises instead of silently answering in another metric."""
+    name = str(metric).lower()
+    if name not in _METRICS:
+        raise ValueError("metric %r is not supported by the position index (euclidean / manhattan / chebyshev)" % (metric,))
+    code = _METRICS[name]
+    if name == "minkowski" and p is not None:
+        if p == 1:
+            code = METRIC_L1
+        elif p == 2:
+            code = METRIC_L2
+        elif p == float("inf"):
+            code = METRIC_LINF
+        else:
+            raise ValueError("minkowski p = %r is not supported by the position index (1, 2 or inf)" % (p,))
+    return code
+
+
 class Position_Index(object):
     """Uniform-grid radius query over 2-D keypoint positions.
 
-    Result order is ascending ``(dx*dx + dy*dy, index)`` in float64 and a point at
-    distance exactly r is included -- sklearn's BallTree also includes it but leaves the
-    order among equal distances unspecified, so this order is OUR definition
-    (SURVEY.md 7.2 item 4)."""
+    Result order is ascending ``(distance, index)`` in float64 and a point at distance exactly
+    r is included -- sklearn's BallTree also includes it but leaves the order among equal
+    distances unspecified, so this order is OUR definition.
+    ``metric``: see ``metric_code``; distances are computed the way sklearn's DistanceMetric
+    classes do (p = 2: dx*dx + dy*dy then sqrt; p = 1: |dx| + |dy|; p = inf: max(|dx|, |dy|))."""
 
-    def __init__(self, positions, bucket=64.0):
+    def __init__(self, positions, bucket=64.0, metric="minkowski", p=None):
         self.positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
         self.bucket = float(bucket)
+        self.metric = metric_code(metric, p)
         n = self.positions.shape[0]
         if n:
             self.x0 = float(np.floor(self.positions[:, 0].min()))
@@ -61,8 +91,13 @@ class Position_Index(object):
             self.order = np.zeros(0, dtype=np.int64)
             self.start = np.zeros(1, dtype=np.int64)
 
+    def key_to_distance(self, key):
+        """Distances from the sort keys ``radius`` returns (p = 2: the key is the SQUARED distance)."""
+        return np.sqrt(key) if self.metric == METRIC_L2 else key
+
     def radius(self, x, y, r):
-        """(idx int64[m], d2 float64[m]) of the points with d2 <= r*r, sorted by (d2, idx)."""
+        """(idx int64[m], key float64[m]) of the points within r, sorted by (key, idx); key = squared
+        distance for p = 2 (d2 <= r*r), the distance itself for p = 1 / inf (d <= r)."""
         if self.positions.shape[0] == 0 or r < 0:
             return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float64)
         b = self.bucket
@@ -83,8 +118,12 @@ class Position_Index(object):
         cand = np.concatenate(parts) if len(parts) > 1 else parts[0]
         dx = self.positions[cand, 0] - float(x)
         dy = self.positions[cand, 1] - float(y)
-        d2 = dx * dx + dy * dy
-        keep = d2 <= float(r) * float(r)
+        if self.metric == METRIC_L2:
+            d2 = dx * dx + dy * dy
+            keep = d2 <= float(r) * float(r)
+        else:
+            d2 = np.abs(dx) + np.abs(dy) if self.metric == METRIC_L1 else np.maximum(np.abs(dx), np.abs(dy))
+            keep = d2 <= float(r)
         cand = cand[keep]
         d2 = d2[keep]
         o = np.lexsort((cand, d2))
@@ -102,7 +141,7 @@ class Position_Index(object):
                 o = np.argsort(idx, kind="stable")
                 idx, d2 = idx[o], d2[o]
             inds[i] = idx
-            dists[i] = np.sqrt(d2)
+            dists[i] = self.key_to_distance(d2)
         if return_distance:
             return inds, dists
         return inds
@@ -426,6 +465,8 @@ class Metric_Cache(object):
         self.thumb = {}
         self.original = {}
         self._options = options
+        self._metric = (metric, options.get("p"))
+        metric_code(*self._metric)                      # an unsupported metric fails here, not at the first query
         self._bank = None
         self._thumb_bank = None
         if path is None:
@@ -459,7 +500,7 @@ class Metric_Cache(object):
             "descriptors": desc,
             "positions": pos,
             "distances": distances,
-            "position_tree": Position_Index(pos),
+            "position_tree": Position_Index(pos, metric=self._metric[0], p=self._metric[1]),
             "size": (int(size[0]), int(size[1])),
         }
         if thumb_descriptors is not None:
@@ -547,8 +588,9 @@ class Metric_Cache(object):
         self.thumb["size"] = tuple(int(v) for v in data_thumb["size"])
         self.original = {k: data[k] for k in ("descriptors", "positions", "distances")}
         self.original["size"] = tuple(int(v) for v in data["size"])
-        # the reference pickles its sklearn BallTree; ours is rebuilt from the positions
-        self.original["position_tree"] = Position_Index(self.original["positions"])
+        # the reference pickles its sklearn BallTree (which carries the metric it was built with); ours is
+        # rebuilt from the positions in the metric of THIS cache's options
+        self.original["position_tree"] = Position_Index(self.original["positions"], metric=self._metric[0], p=self._metric[1])
         self._bank = None
         self._thumb_bank = None
         return True
@@ -584,6 +626,6 @@ class Metric_Cache(object):
             "descriptors": descriptors,
             "positions": positions,
             "distances": distances,
-            "position_tree": Position_Index(positions),
+            "position_tree": Position_Index(positions, metric=metric, p=self._metric[1]),
             "size": (img_data.shape[1], img_data.shape[0]),
         }

@@ -523,8 +523,10 @@ __global__ void compact_rows_kernel(const int32_t* __restrict__ tidx, const floa
     int wb = 0;
     for (int w = 0; w < wave; ++w) wb += wave_base[w];
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        // the device word counts the rows that are THERE (what a consumer of o_rows may index: the gather ships
+        // it next to the rows); the host word keeps the full number of accepted matches
         const long long tot = (long long)(base + wave_base[0] + wave_base[1] + wave_base[2] + wave_base[3]);
-        *o_count = tot;
+        *o_count = tot < (long long)cap ? tot : (long long)cap;
         if (h_count) *h_count = (unsigned long long)tot;
     }
     if (p) {
@@ -723,8 +725,8 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     for (auto& sl : ctx->bslot) free_slot(sl);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
     for (hipEvent_t ev : ctx->ev_tail_end) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }      // (before the streams it was used on)
     for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamDestroy(ts);
-    if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }
     for (auto* v : {&ctx->pending, &ctx->timer_pool})
         for (auto& t : *v) { (void)hipEventDestroy(t.c0); (void)hipEventDestroy(t.c1); (void)hipEventDestroy(t.k0); (void)hipEventDestroy(t.k1); }
     if (ctx->ws_partial) (void)hipFree(ctx->ws_partial);
@@ -1115,10 +1117,18 @@ extern "C" int fm_bank_create_f32_route(fm_ctx* ctx, const float* rows, int64_t 
     return bank_create(ctx, rows, n, dim, true, bank, true);
 }
 
+// Everything enqueued on the context -- its own stream and the tail streams the async entry points use.
+static void sync_all_streams(fm_ctx* ctx)
+{
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamSynchronize(ts);
+}
+
 extern "C" int fm_bank_destroy(fm_ctx* ctx, fm_bank* bank)
 {
     if (!bank) return FM_OK;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) sync_all_streams(ctx);          // (tail kernels of async calls read the bank's self distances)
     bank_free(bank);
     delete bank;
     return FM_OK;
@@ -1778,8 +1788,19 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
     if (n == 0) return FM_OK;
     if (!q || !t) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: NULL argument");
     int rc;
-    for (int i = 0; i < n; ++i)
+    // every pair is checked BEFORE anything is enqueued: a bad pair in the middle must not leave earlier pairs
+    // in flight and outputs half written
+    for (int i = 0; i < n; ++i) {
         if ((rc = check_pair(ctx, q[i], t[i], "fm_match_accepted_batch")) != FM_OK) return rc;
+        if (q[i]->n > 0 && !q[i]->selfdist)
+            return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: a query bank has no self distances (fm_bank_set_selfdist)");
+        if (!to_dev && q[i]->n > 0) {
+            if (!qidx[i] || !tidx[i] || !dist[i] || !ratio[i]) return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: output pointer is NULL");
+            if (!pinned_device_alias(qidx[i]) || !pinned_device_alias(tidx[i]) || !pinned_device_alias(dist[i]) ||
+                !pinned_device_alias(ratio[i]) || !pinned_device_alias(n_accepted[i]))
+                return fail(ctx, FM_EINVAL, "fm_match_accepted_batch: host outputs must be page-locked (fm_host_alloc)");
+        }
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (to_dev && consumer != kNoStream) {
         // the compactions write buffers the consumer stream reads (the previous step's collective): they wait
@@ -1813,7 +1834,10 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->tune);
             if (pl.nb != 4 || pl.nw != 8 || !(ctx->tune.glds != 0) || pl.nbuf == 2) g = 1;     // shapes the batched kernel is not built for
         }
-        if (g == 1) {                  // an odd pair: the single-pair async call (which also reports its errors)
+        if (g == 1) {                  // an odd pair: the single-pair call (which also reports its errors)
+            // float32-route pairs have no enqueue-only form: they run synchronously, in place (their outputs
+            // are complete when the batch call returns; the pairs around them stay asynchronous)
+            const bool in_place = q[i]->kind == FM_BANK_F32 && q[i]->n > 0;
             if (to_dev) {
                 int64_t* hc = h_counts ? h_counts + i : nullptr;
                 if (q[i]->n == 0) {
@@ -1821,13 +1845,13 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
                     if (hc) *hc = 0;
                 } else {
                     rc = xcheck_common(ctx, q[i], t[i], true, tau, nullptr, nullptr, nullptr, nullptr, hc, "fm_match_accepted_dev_batch",
-                                       cap, nullptr, d_rows + (size_t)i * cap * 3, (long long*)(d_counts + i), true, kNoStream);
+                                       cap, nullptr, d_rows + (size_t)i * cap * 3, (long long*)(d_counts + i), !in_place, kNoStream);
                     if (rc != FM_OK) return rc;
                 }
             } else {
                 if (q[i]->n == 0) *n_accepted[i] = 0;
                 rc = xcheck_common(ctx, q[i], t[i], true, tau, tidx[i], dist[i], ratio[i], nullptr, n_accepted[i],
-                                   "fm_match_accepted_batch", cap, qidx[i], nullptr, nullptr, true);
+                                   "fm_match_accepted_batch", cap, qidx[i], nullptr, nullptr, !in_place);
                 if (rc != FM_OK) return rc;
             }
             ++i;
@@ -2156,6 +2180,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     const int64_t ncells = (int64_t)d->rows * d->cols;
     if (d->width < 1 || d->height < 1 || d->cell_w < 1 || d->cell_h < 1 || d->rows < 1 || d->cols < 1 || d->radius < 0)
         return fail(ctx, FM_EINVAL, "fm_expand_create: bad grid parameters");
+    if (d->metric < FM_METRIC_EUCLIDEAN || d->metric > FM_METRIC_CHEBYSHEV) return fail(ctx, FM_EINVAL, "fm_expand_create: unknown metric");
     if (d->rows > 65535 || d->cols > 65535 || d->width > 65535 || d->height > 65535)
         return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: image or grid too large for 16-bit cell keys");
     if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || !d->cell_off || (nt > 0 && !d->target_pos))
@@ -2203,6 +2228,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.idx_order = (const int32_t*)(b + o_order); P.idx_start = (const int32_t*)(b + o_start);
     P.idx_bucket = d->index_bucket; P.idx_x0 = d->index_x0; P.idx_y0 = d->index_y0;
     P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;
+    P.metric = d->metric;
     P.t_rows8 = d->target->rows8; P.t_norm = d->target->norm;
     P.f32 = f32 ? 1 : 0;
     P.tie_guard = (!f32 && sqrt_tie_possible(*d->query, *d->target)) ? 1 : 0;
@@ -2457,11 +2483,39 @@ extern "C" int fm_comm_destroy(fm_ctx* ctx)
 {
     if (!ctx) return FM_OK;
     if (ctx->comm) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
+        sync_all_streams(ctx);               // (a gather behind an async fill runs on a tail stream)
         comm_destroy(ctx->comm);
         ctx->comm = nullptr;
         ctx->comm_ranks = 0;
+    }
+    return FM_OK;
+}
+
+// Two-phase form: the counts first, then only as many rows per rank as the fullest rank holds (the padded
+// form ships cap rows per rank whatever they hold).  Costs a host synchronisation between the phases.
+extern "C" int fm_gather_matches_counted(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                                         int32_t* d_all_rows, int64_t* d_all_counts, int64_t* rows_per_rank)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_gather_matches_counted: ctx is NULL");
+    if (!ctx->comm) return fail(ctx, FM_EINVAL, "fm_gather_matches_counted: no communicator (fm_comm_init)");
+    if (cap < 0 || !d_count || !d_all_counts || !rows_per_rank || (cap > 0 && (!d_rows || !d_all_rows)))
+        return fail(ctx, FM_EINVAL, "fm_gather_matches_counted: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    hipStream_t gs = ctx->rows_stream ? ctx->rows_stream : ctx->stream;
+    int rc = comm_gather(ctx->comm, nullptr, d_count, 0, nullptr, d_all_counts, gs, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches_counted: " + err);
+    std::vector<int64_t> counts((size_t)ctx->comm_ranks);
+    HIP_TRY(ctx, hipMemcpyAsync(counts.data(), d_all_counts, counts.size() * 8, hipMemcpyDeviceToHost, gs));
+    HIP_TRY(ctx, hipStreamSynchronize(gs));
+    int64_t m = 0;
+    for (int64_t c : counts) m = c > m ? c : m;
+    if (m > cap) m = cap;
+    *rows_per_rank = m;
+    if (m > 0) {
+        rc = comm_gather(ctx->comm, d_rows, nullptr, m, d_all_rows, nullptr, gs, &err);
+        if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches_counted: " + err);
+        HIP_TRY(ctx, hipStreamSynchronize(gs));
     }
     return FM_OK;
 }

@@ -85,14 +85,15 @@ int comm_destroy(void* comm)
     return FM_OK;
 }
 
-// One grouped pair of all-gathers on `stream`: counts (1 x int64 per rank) and rows (cap x 3 x int32 per rank).
+// One grouped pair of all-gathers on `stream`: counts (1 x int64 per rank; skipped when d_count is null) and
+// rows (cap x 3 x int32 per rank; skipped when cap == 0).
 int comm_gather(void* comm, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
                 int32_t* d_all_rows, int64_t* d_all_counts, hipStream_t stream, std::string* err)
 {
     RcclApi* a = rccl_api();
     if (!a->error.empty()) { *err = a->error; return FM_EUNSUPPORTED; }
     ncclResult_t r = a->GroupStart();
-    if (r == ncclSuccess) r = a->AllGather(d_count, d_all_counts, 1, ncclInt64, (ncclComm_t)comm, stream);
+    if (r == ncclSuccess && d_count) r = a->AllGather(d_count, d_all_counts, 1, ncclInt64, (ncclComm_t)comm, stream);
     if (r == ncclSuccess && cap > 0) r = a->AllGather(d_rows, d_all_rows, (size_t)cap * 3, ncclInt32, (ncclComm_t)comm, stream);
     const ncclResult_t e = a->GroupEnd();
     if (r == ncclSuccess) r = e;

@@ -346,7 +346,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     struct View {
         gptr<const int8_t> q_rows8; gptr<const int32_t> q_norm; gptr<const double> q_selfdist, q_pos;
         gptr<const int32_t> idx_order, idx_start;
-        double idx_bucket, idx_x0, idx_y0; int idx_nbx, idx_nby;
+        double idx_bucket, idx_x0, idx_y0; int idx_nbx, idx_nby, metric;
         gptr<const int8_t> t_rows8; gptr<const int32_t> t_norm; gptr<const int64_t> cell_off; gptr<const double> t_pos;
         int width, height, cell_w, cell_h, rows, cols, margin, radius, f32, tie_guard;
         gptr<const double> seeds; int64_t n_seeds; double tau;
@@ -359,7 +359,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
     P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos;
     P.idx_order = (gptr<const int32_t>)M.idx_order; P.idx_start = (gptr<const int32_t>)M.idx_start;
-    P.idx_bucket = M.idx_bucket; P.idx_x0 = M.idx_x0; P.idx_y0 = M.idx_y0; P.idx_nbx = M.idx_nbx; P.idx_nby = M.idx_nby;
+    P.idx_bucket = M.idx_bucket; P.idx_x0 = M.idx_x0; P.idx_y0 = M.idx_y0; P.idx_nbx = M.idx_nbx; P.idx_nby = M.idx_nby; P.metric = M.metric;
     P.t_rows8 = (gptr<const int8_t>)M.t_rows8; P.t_norm = (gptr<const int32_t>)M.t_norm;
     P.cell_off = (gptr<const int64_t>)M.cell_off; P.t_pos = (gptr<const double>)M.t_pos;
     P.width = M.width; P.height = M.height; P.cell_w = M.cell_w; P.cell_h = M.cell_h;
@@ -512,8 +512,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         for (int q = 1; q < 8; ++q) { base = (j == q) ? rs[q] : base; off = (j == q) ? pre[q] : off; }
                         const int qi = P.idx_order[base + f - off];
                         const double dx = P.q_pos[2 * qi] - (double)qx, dy = P.q_pos[2 * qi + 1] - (double)qy;
-                        const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));   // no fma: NumPy order
-                        if (d2 <= r2) {
+                        // sort key and inclusion test of the pair's metric (BallTree(positions, metric), cache.pyx:276):
+                        // squared Euclidean distance against r^2 (no fma: NumPy order), or |dx| + |dy| /
+                        // max(|dx|, |dy|) against r
+                        const double d2 = P.metric == 0 ? __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))
+                                        : (P.metric == 1 ? __dadd_rn(fabs(dx), fabs(dy)) : fmax(fabs(dx), fabs(dy)));
+                        if (d2 <= (P.metric == 0 ? r2 : r)) {
                             const int slot = atomicAdd(&sh_i[4], 1);
                             if (slot < CAND) { keys[slot] = (unsigned long long)__double_as_longlong(d2); cand[slot] = qi; }
                         }
@@ -525,8 +529,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         const int nq = sh_i[4];
         if (nq > CAND) { status = kExpCandFull; break; }
         EXP_STAMP(1);
-        // sort by (d2 bits, index): non-negative doubles order like their bit patterns
-        block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq, (double)P.radius * (double)P.radius);
+        // sort by (key bits, index): non-negative doubles order like their bit patterns
+        block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq,
+                               P.metric == 0 ? (double)P.radius * (double)P.radius : (double)P.radius);
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------

@@ -15,6 +15,7 @@ struct ExpandPair {
     const int32_t* idx_start;      // [nbx*nby + 1]
     double idx_bucket, idx_x0, idx_y0;
     int    idx_nbx, idx_nby;
+    int    metric;                 // radius query: 0 = Euclidean (d2 <= r2), 1 = Manhattan, 2 = Chebyshev (d <= r)
     // target side: every grid cell's descriptors packed back to back
     const int8_t*  t_rows8;
     const int32_t* t_norm;

@@ -64,9 +64,11 @@ def get_size(path):
 
 def open_img(path, size=None):
     """ Image as uint8 [H, W, 3] in cv2.imread's BGR channel order; ``size`` None or -1 keeps
-    the resolution, a (width, height) box rescales by the rule above (reference imaging.py:80-85). """
+    the resolution, a (width, height) box -- or one number for a square box -- rescales by the rule above (reference imaging.py:80-85). """
     Image = _pil()
     img = _open_pil(path).convert("RGB")
-    if not (size is None or (np.isscalar(size) and size == -1)):
+    if not (size is None or (np.isscalar(size) and size <= 0)):
+        if np.isscalar(size):                      # Metric_Cache passes options["max_size"], an int (cache.pyx:158, 266)
+            size = (size, size)
         img = img.resize(resize_rule(img.size[0], img.size[1], size), Image.BOX)
     return np.asarray(img, dtype=np.uint8)[:, :, ::-1].copy()

@@ -203,14 +203,16 @@ int  fm_wait(fm_ctx* ctx, int64_t ticket);
 /* n independent image pairs in one call, enqueued like n fm_match_accepted_async calls (same output
  * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
  * fm_sync).  Consecutive pairs whose banks have the same padded sizes go through the distance kernel
- * TOGETHER, up to eight (FM_BATCH_GROUP: sixteen) pairs per launch: inside one launch the workgroups of the next pair fill the
- * CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
+ * TOGETHER, up to eight pairs per launch (option "batch_group": up to sixteen): inside one launch the
+ * workgroups of the next pair fill the CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
  * a 100k x 100k pair).  The reference maps its matcher over the pairs of a dataset one after the
- * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (float32
- * route, empty banks, a different shape) are enqueued one by one.  A run of pairs ends with a short
- * launch (2 pairs) because only the LAST launch's small kernels are exposed to a caller that
- * synchronises after the call; a caller that enqueues the next batch first (fm_mark / fm_wait) sets
- * the environment variables FM_BATCH_TAIL=0 and FM_BATCH_GROUP=16 (read once) for one launch per run. */
+ * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (empty banks, a
+ * different shape) are enqueued one by one; pairs on the float32 route, which has no enqueue-only form,
+ * run synchronously in their place (their outputs are complete when the call returns, the pairs around
+ * them stay asynchronous).  Every pair is validated before anything is enqueued.  A run of pairs ends with
+ * a short launch (2 pairs) because only the LAST launch's small kernels are exposed to a caller that
+ * synchronises after the call; a caller that enqueues the next batch first (fm_mark / fm_wait) sets the
+ * options batch_tail = 0 and batch_group = 16 (fm_ctx_set_option) for one launch per run.              */
 int  fm_match_accepted_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const fm_bank* const* t, double tau,
                              int64_t cap, int32_t* const* qidx, int32_t* const* tidx, float* const* dist,
                              double* const* ratio, int64_t* const* n_accepted /*page-locked words*/);
@@ -226,7 +228,8 @@ int  fm_match_accepted_dev_batch(fm_ctx* ctx, int32_t n, const fm_bank* const* q
 
 /* As fm_match_accepted, but the accepted matches stay on the device: d_rows[i] = {query index,
  * train index, float32 distance bits} (12-byte rows, ascending query index, at most cap of
- * them) and *d_count = total accepted, both in caller-supplied DEVICE memory -- the send
+ * them) and *d_count = the number of rows written = min(accepted, cap), both in caller-supplied DEVICE
+ * memory (n_accepted / h_count on the host receive the full number of accepted matches) -- the send
  * buffer of the multi-GPU result gather (fm_gather_matches / an RCCL all-gather), so nothing
  * bounces through the host.  The reference has no counterpart (single process); the rows are
  * the (queryIdx, trainIdx, distance) of the DMatch list fastmatch.pyx:161-165 consumes.
@@ -292,7 +295,13 @@ typedef struct fm_expand_desc {
     int64_t        match_cap;      /* first capacity of the result list (0 = 4 * nq) and    */
     int64_t        stack_cap;      /* of the pending stack (0 = default); fm_expand_run     */
                                    /* repeats a run that fills one in a state 4x as large   */
+    int32_t        metric;         /* radius query metric: the reference builds its BallTree with
+                                    * options["metric"] (cache.pyx:160, 276): FM_METRIC_*    */
 } fm_expand_desc;
+
+#define FM_METRIC_EUCLIDEAN 0      /* "minkowski" (p = 2), "euclidean": dx^2 + dy^2 <= r^2     */
+#define FM_METRIC_MANHATTAN 1      /* |dx| + |dy| <= r                                          */
+#define FM_METRIC_CHEBYSHEV 2      /* max(|dx|, |dy|) <= r                                      */
 
 #define FM_EXPAND_OK            0
 #define FM_EXPAND_STACK_FULL    1
@@ -344,6 +353,12 @@ int  fm_comm_init(fm_ctx* ctx, int nranks, int rank, const void* id128);
 int  fm_comm_destroy(fm_ctx* ctx);
 int  fm_gather_matches(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
                        int32_t* d_all_rows, int64_t* d_all_counts, int wait);
+/* Counts first, then only *rows_per_rank = min(cap, max over the ranks of their counts) rows per rank:
+ * d_all_rows is laid out [nranks][*rows_per_rank][3].  Ships what is there instead of the padded capacity
+ * (xGMI traffic / 3 on the bench's workload) for one host synchronisation between the two collectives;
+ * returns when both are done.                                                                          */
+int  fm_gather_matches_counted(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                               int32_t* d_all_rows, int64_t* d_all_counts, int64_t* rows_per_rank);
 
 #ifdef __cplusplus
 }

@@ -102,7 +102,11 @@ class OGrid(object):
 class OQuery(object):
     """Query bank: descriptors, positions, self distances (+ thumbnail bank)."""
 
-    def __init__(self, descriptors, positions, size, distances=None, thumb=None):
+    def __init__(self, descriptors, positions, size, distances=None, thumb=None, metric="minkowski"):
+        # BallTree(positions, metric = metric), cache.pyx:276: "minkowski" (p = 2) / "euclidean",
+        # "manhattan", "chebyshev"
+        self.metric = {"minkowski": 2, "euclidean": 2, "l2": 2, "manhattan": 1, "cityblock": 1, "l1": 1,
+                       "chebyshev": 0, "infinity": 0}[metric]
         self.descriptors = descriptors
         self.positions = np.asarray(positions, dtype=np.float64).reshape(-1, 2)
         self.size = size
@@ -116,8 +120,12 @@ class OQuery(object):
         x, y, radius = int(x), int(y), int(radius)
         dx = self.positions[:, 0] - float(x)
         dy = self.positions[:, 1] - float(y)
-        d2 = dx * dx + dy * dy
-        idx = np.nonzero(d2 <= float(radius) * float(radius))[0]
+        if self.metric == 2:
+            d2 = dx * dx + dy * dy
+            idx = np.nonzero(d2 <= float(radius) * float(radius))[0]
+        else:
+            d2 = np.abs(dx) + np.abs(dy) if self.metric == 1 else np.maximum(np.abs(dx), np.abs(dy))
+            idx = np.nonzero(d2 <= float(radius))[0]
         idx = idx[np.lexsort((idx, d2[idx]))]
         return self.descriptors[idx], self.positions[idx], self.distances[idx], idx
 

@@ -15,6 +15,7 @@ copied -- sklearn is a third-party package):
     python tests/golden/make_radius_golden.py
 
 Writes  tests/golden/radius_golden.json   query -> (indices, distances) in sklearn's order
+        tests/golden/radius_metric_golden.json   the same for metric = chebyshev / manhattan / euclidean
         tests/golden/metric_cache_npz/<ripemd160(path)>.npz, ..._thumb.npz
                                           a Metric_Cache file pair in the reference's layout
                                           (pickled BallTree bytes in `position_tree`).
@@ -84,6 +85,22 @@ def main():
         golden["sets"][name] = {"positions": [[float(a), float(b)] for a, b in pos], "queries": qs}
     with open(os.path.join(HERE, "radius_golden.json"), "w") as f:
         json.dump(golden, f, separators=(",", ":"))
+
+    # ---- the other metrics options["metric"] can name (cache.pyx:160 -> BallTree(positions, metric = metric)) ----
+    rng = np.random.default_rng(20260004)
+    mg = {"sklearn_version": sklearn.__version__, "sets": {}}
+    sets = position_sets()
+    for metric in ("chebyshev", "manhattan", "euclidean"):
+        for name in ("subpixel_800x640", "lattice_60x40", "float32_pts"):
+            pos = sets[name][:900]
+            tree = BallTree(pos, metric=metric)
+            qs = []
+            for (x, y, r) in queries(name, pos, rng)[:24]:
+                ind, dist = tree.query_radius(np.array((x, y)).reshape(1, -1), r=r, return_distance=True, sort_results=True)
+                qs.append({"x": x, "y": y, "r": r, "indices": [int(v) for v in ind[0]], "distances": [float(v) for v in dist[0]]})
+            mg["sets"]["%s/%s" % (metric, name)] = {"metric": metric, "positions": [[float(a), float(b)] for a, b in pos], "queries": qs}
+    with open(os.path.join(HERE, "radius_metric_golden.json"), "w") as f:
+        json.dump(mg, f, separators=(",", ":"))
 
     # ---- a Metric_Cache file pair written the way cache.pyx:199-210 writes it -------------
     from fastmatch_amd import synth

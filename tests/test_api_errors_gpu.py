@@ -140,8 +140,11 @@ def test_batch_calls_reject_bad_arguments_and_the_context_survives(ctx):
         ctx.match_accepted_batch([(qb, tb)], 0.7, outs, [])
     qf = ctx.bank((Q.astype(np.float32) + 0.25))
     qf.set_selfdist(ctx.self_dist(qf))
-    with pytest.raises(_ffi.FastMatchHipError):                         # float32 route: not an async path
-        ctx.match_accepted_batch([(qf, ctx.bank(T.astype(np.float32) + 0.25))], 0.7, outs, cnt)
+    tf = ctx.bank(T.astype(np.float32) + 0.25)                          # float32 route: runs synchronously in place
+    ctx.match_accepted_batch([(qf, tf)], 0.7, outs, cnt)
+    fq, ft, fd, fr = ctx.match_accepted(qf, tf, 0.7)
+    m = int(cnt[0][0])
+    assert m == len(fq) and np.array_equal(outs[0][0][:m], fq) and np.array_equal(outs[0][3][:m], fr)
     ctx.sync()
     ctx.match_accepted_batch([(qb, tb)], 0.7, outs, cnt)                # and it still works
     ctx.sync()

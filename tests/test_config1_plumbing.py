@@ -50,6 +50,7 @@ def test_open_img_and_get_size_on_files(tmp_path):
     assert np.array_equal(imaging.open_img(path), img)
     assert np.array_equal(imaging.open_img(path, -1), img)
     assert imaging.open_img(path, (160, 160)).shape == (100, 160, 3)
+    assert imaging.open_img(path, 160).shape == (100, 160, 3)        # Metric_Cache's max_size is one number (cache.pyx:158)
     th = imaging.get_thumbnail(path, (100, 100))         # target (100, 62); PIL's own aspect rounding may give 99
     assert th.shape[0] == 62 and th.shape[1] in (99, 100) and th.shape[2] == 3
 
@@ -154,3 +155,57 @@ def test_readme_flow_on_pixels_equals_oracle(ctx, tmp_path, monkeypatch):
     good = evaluate.homography_scorer(mild, 4.0, query_is_source=False)(
         np.array([m[0] for m in matches]), np.array([m[1]["positions"] for m in matches]), None)
     assert good.mean() > 0.8
+
+
+@pytest.mark.gpu
+def test_readme_flow_on_the_graf_pixels(ctx, tmp_path, monkeypatch, capsys):
+    """BASELINE.json configs[0] on the reference's OWN pixels (tests/golden/graf: images/graf/img1 and img4,
+    re-encoded as PNG; H1to4p): README.md:41-50 with the stand-in extractor in place of cv2 SIFT (absent on
+    both boxes; standin.py says what it is).  Pins the plumbing on real image content -- file -> thumbnail ->
+    Metric_Cache -> lazy Grid_Cache cells -> rounds on the device -- against the oracle on the same features,
+    and prints the homography precision as a STAND-IN number (it says nothing about SIFT matching quality)."""
+    from PIL import Image
+    from fastmatch_amd import cache, fastmatch
+    from oracle import fastmatch_oracle as fo
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graf")
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("images/graf")
+    for n in ("img1", "img4"):                                             # the README's paths, as .ppm files
+        Image.open(os.path.join(here, n + ".png")).save("images/graf/%s.ppm" % n)
+    H = evaluate.load_homography(os.path.join(here, "H1to4p"))
+    feat = standin.standin_features
+    target_path, query_path = "images/graf/img1.ppm", "images/graf/img4.ppm"
+    opts = {"context": ctx, "feature_function": feat}
+    query_cache = cache.Metric_Cache(query_path, opts)
+    target_img = imaging.open_img(target_path)
+    assert target_img.shape == (640, 800, 3) and query_cache.original["size"] == (800, 640)
+    log, stats = [], {}
+    match_fun = fastmatch.match(query_cache, target_img, dict(opts, log=log, stats=stats))
+    results = {tau: list(match_fun(tau)) for tau in (0.7, 0.9)}
+
+    kq, dq = feat(imaging.open_img(query_path))
+    thumb_q = imaging.get_thumbnail(query_path, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    oq = fo.OQuery(dq, pos(kq), (800, 640),
+                   thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    assert np.array_equal(query_cache.original["distances"], oq.distances)
+    thumb_t = imaging.get_thumbnail(target_img, (400, 400))
+    ktt, dtt = feat(thumb_t)
+    ot = {"size": (800, 640), "image": target_img, "feature_function": feat,
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    oget = fo.o_match(oq, ot, {})
+    for tau, matches in results.items():
+        exp = oget(tau)
+        assert len(matches) == len(exp)
+        for (ia, da), (ib, db) in zip(matches, exp):
+            assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    # query = img4, target = img1; H1to4p maps img1 -> img4 coordinates, i.e. target -> query
+    score = evaluate.homography_scorer(H, 5.0, query_is_source=False)
+    with capsys.disabled():
+        for tau, matches in results.items():
+            idx = np.array([m[0] for m in matches])
+            p = np.array([m[1]["positions"] for m in matches]).reshape(-1, 2, 2)
+            good = score(idx, p, None)
+            print("\n[graf img1-img4, stand-in features (NOT SIFT), tau %.1f] %d keypoints/query image, %d matches, %d within 5 px of H1to4p"
+                  % (tau, len(dq), len(matches), int(good.sum())))

@@ -142,6 +142,38 @@ def test_device_and_host_loop_in_the_sqrt_tie_range(ctx):
             assert stats.get("device_loops", 0) == 1
 
 
+@pytest.mark.parametrize("metric", ["chebyshev", "manhattan"])
+def test_metric_option_reaches_the_radius_query_on_host_and_device(ctx, metric):
+    """options["metric"] of the query cache (cache.pyx:160 -> BallTree(positions, metric), cache.pyx:276):
+    the device loop's radius query, the host loop's and the oracle's select the same keypoints in the
+    same order, and not the Euclidean ones."""
+    q, t = synth.image_pair((800, 640), 3000, seed=31)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx, "metric": metric})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"], metric=metric,
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    stats, hstats = {}, {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats})
+    hget = fastmatch.match(mc, fi, {"context": ctx, "stats": hstats, "device_loop": False})
+    oget = fo.o_match(oq, ot, {})
+    exp = oget(0.7)
+    _same_matches(get(0.7), exp)
+    _same_matches(hget(0.7), exp)
+    assert stats.get("device_loops", 0) == 1 and stats["rounds"] == hstats["rounds"] == oget.rounds
+    assert stats["pairs"] == hstats["pairs"]
+    # Euclidean discs hold other keypoints: the number of descriptor pairs differs
+    mc2 = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                         q["thumb_positions"], q["thumb_size"], distances=mc.original["distances"],
+                                         thumb_distances=mc.thumb["distances"], options={"context": ctx})
+    s2 = {}
+    fastmatch.match(mc2, fi, {"context": ctx, "stats": s2})(0.7)
+    assert s2["pairs"] != stats["pairs"]
+
+
 def test_device_loop_return_arrays_and_many_pairs(ctx):
     pairs, oracles = [], []
     for k in range(5):

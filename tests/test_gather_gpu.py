@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from fastmatch_amd import synth, sharding
+from fastmatch_amd import synth, sharding, _ffi
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +56,7 @@ def test_device_rows_capacity_and_errors(ctx):
     rows = torch.full((cap + 5, 3), -7, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     n = ctx.match_accepted_dev(qb, tb, 0.9, rows.data_ptr(), count.data_ptr(), cap)
-    assert n == len(q_acc) == int(count.item())        # the total, although only cap rows fit
+    assert n == len(q_acc) and int(count.item()) == cap     # host: the total; device word: the rows that are there
     got = rows.cpu().numpy()
     assert np.array_equal(got[:cap], sharding.pack_matches(q_acc, t_acc, d_acc)[:cap]) and (got[cap:] == -7).all()
     host = np.zeros((cap, 3), np.int32)
@@ -137,7 +137,12 @@ def test_rccl_gather_through_the_c_abi_one_rank():
             qa, ta, da, _ = c.match_accepted(qb, tb, tau)
             assert int(all_counts[0].item()) == n == len(qa) > 100
             assert np.array_equal(all_rows[0, :n].cpu().numpy(), sharding.pack_matches(qa, ta, da))
-        from fastmatch_amd import _ffi
+            # counts first, then only the rows that are there: [nranks, m, 3] with m = the fullest rank's count
+            all_rows.fill_(-9)
+            m = c.gather_matches_counted(rows.data_ptr(), count.data_ptr(), cap, all_rows.data_ptr(), all_counts.data_ptr())
+            assert m == n and int(all_counts[0].item()) == n
+            flat = all_rows.view(-1, 3)
+            assert np.array_equal(flat[:m].cpu().numpy(), sharding.pack_matches(qa, ta, da)) and bool((flat[m:] == -9).all())
         with pytest.raises(_ffi.FastMatchHipError):   # a second communicator on the same context
             c.comm_init(1, 0, uid)
     finally:
@@ -152,7 +157,7 @@ import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
 import fastmatch_amd
-from fastmatch_amd import synth, sharding
+from fastmatch_amd import synth, sharding, _ffi
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 backend = os.environ["FM_TEST_BACKEND"]
 torch.cuda.set_device(0)
@@ -579,9 +584,62 @@ def test_batch_outputs_shorter_than_the_accepted_lists_are_truncated_not_overrun
     ctx.sync()
     got = flat.cpu().numpy()
     for i, (qa, ta, da, ra) in enumerate(want):
-        assert int(cnts[i].item()) == len(qa)
+        assert int(cnts[i].item()) == cap                       # the device word counts the rows that are there ...
         assert np.array_equal(got[i * cap:(i + 1) * cap], sharding.pack_matches(qa, ta, da)[:cap])
     assert (got[len(pairs) * cap:] == -7).all()
+    hc = ctx.pinned_empty(len(pairs), np.int64)                 # ... the host word the full number of accepted matches
+    ctx.match_accepted_dev_batch(pairs, 0.9, flat.data_ptr(), cnts.data_ptr(), cap, h_counts=hc)
+    ctx.sync()
+    assert hc.tolist() == [len(w[0]) for w in want] and cnts.cpu().tolist() == [cap] * len(pairs)
+
+
+def test_float32_route_pairs_inside_a_batch(ctx):
+    """A batch that mixes integer-valued pairs with float32-route pairs (RootSIFT-style descriptors): the
+    float32 pairs run synchronously in place, every pair's outputs equal its single call; a bad pair anywhere
+    in the batch is refused before anything is enqueued."""
+    rng = np.random.default_rng(11)
+    ints = [_banks(ctx, 3000, 33000, seed=900 + k) for k in range(3)]
+    fl = []
+    for k in range(2):
+        Qf = (synth.synth_sift(700, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (700, 128)).astype(np.float32))
+        Tf = (synth.synth_sift(900, rng).astype(np.float32) + rng.uniform(-0.5, 0.5, (900, 128)).astype(np.float32))
+        Tf[:200] = Qf[:200] + rng.normal(0, 2, (200, 128)).astype(np.float32)
+        qb, tb = ctx.bank(Qf), ctx.bank(Tf)
+        assert qb.kind == _ffi.FM_BANK_F32
+        qb.set_selfdist(ctx.self_dist(qb))
+        fl.append((qb, tb))
+    pairs = [(ints[0][2], ints[0][3]), fl[0], (ints[1][2], ints[1][3]), (ints[2][2], ints[2][3]), fl[1]]
+    want = [ctx.match_accepted(q, t, 0.8) for q, t in pairs]
+    assert all(len(w[0]) > 20 for w in want)
+    outs = [tuple(ctx.pinned_empty(3000, dt) for dt in (np.int32, np.int32, np.float32, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    for rep in range(2):
+        for c in counts:
+            c[0] = -1
+        ctx.match_accepted_batch(pairs, 0.8, outs, counts)
+        ctx.sync()
+        for w, o, c in zip(want, outs, counts):
+            m = int(c[0])
+            assert m == len(w[0]) and all(np.array_equal(a[:m].view(np.uint8), b.view(np.uint8)) for a, b in zip(o, w))
+    # device outputs
+    import torch
+    dev = torch.device("cuda", 0)
+    rows = torch.full((len(pairs) * 3000, 3), -7, dtype=torch.int32, device=dev)
+    cnts = torch.zeros(len(pairs), dtype=torch.int64, device=dev)
+    ctx.match_accepted_dev_batch(pairs, 0.8, rows.data_ptr(), cnts.data_ptr(), 3000)
+    ctx.sync()
+    got = rows.cpu().numpy().reshape(len(pairs), 3000, 3)
+    for i, w in enumerate(want):
+        m = int(cnts[i].item())
+        assert m == len(w[0]) and np.array_equal(got[i, :m], sharding.pack_matches(w[0], w[1], w[2]))
+    # a pair without self distances in the MIDDLE: refused up front, nothing written
+    bad_q = ctx.bank(synth.planted_pair(3000, 33000, 1)[0])
+    for c in counts:
+        c[0] = -5
+    with pytest.raises(_ffi.FastMatchHipError):
+        ctx.match_accepted_batch(pairs[:2] + [(bad_q, ints[0][3])] + pairs[2:4], 0.8, outs, counts)
+    ctx.sync()
+    assert all(int(c[0]) == -5 for c in counts)
 
 
 def test_benchmarked_launch_shape_against_the_oracle():

@@ -20,6 +20,7 @@ from oracle import fastmatch_oracle as fo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "radius_golden.json")))
+METRIC_GOLDEN = json.load(open(os.path.join(HERE, "golden", "radius_metric_golden.json")))
 NPZ_DIR = os.path.join(HERE, "golden", "metric_cache_npz")
 NPZ_PATH = "images/graf/img4.ppm"
 
@@ -79,6 +80,49 @@ def test_metric_cache_get_and_oracle_get_equal_balltree(name):
         assert sorted(idx.tolist()) == sorted(q["indices"])
         assert np.array_equal(d, desc[idx]) and np.array_equal(dis, sd[idx])
         assert np.allclose(dist, np.array(q["distances"]), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", sorted(METRIC_GOLDEN["sets"]))
+def test_other_metrics_equal_balltree(name):
+    """options["metric"] (cache.pyx:160 -> BallTree(positions, metric = metric), cache.pyx:276): chebyshev,
+    manhattan and euclidean against sklearn's BallTree built with that metric -- Position_Index,
+    Metric_Cache.get and the oracle's OQuery.get: same set, same distances, same order outside ties."""
+    s = METRIC_GOLDEN["sets"][name]
+    metric = s["metric"]
+    pos = np.array(s["positions"], dtype=np.float64).reshape(-1, 2)
+    index = cache.Position_Index(pos, metric=metric)
+    n = len(pos)
+    desc = (np.arange(n * 4, dtype=np.int64).reshape(n, 4) % 251).astype(np.uint8)
+    sd = np.arange(n, dtype=np.float64) + 1.0
+    mc = cache.Metric_Cache.from_arrays(desc, pos, (1000, 1000), distances=sd, options={"metric": metric})
+    oq = fo.OQuery(desc, pos, (1000, 1000), distances=sd, metric=metric)
+    differs = 0
+    l2 = cache.Position_Index(pos)
+    for q in s["queries"]:
+        idx, key = index.radius(q["x"], q["y"], q["r"])
+        _check(idx, index.key_to_distance(key), q)
+        inds, dists = index.query_radius(np.array((q["x"], q["y"])), r=q["r"], return_distance=True, sort_results=True)
+        assert np.array_equal(inds[0], idx) and np.array_equal(dists[0], index.key_to_distance(key))
+        _, _, _, midx = mc.get(q["x"], q["y"], q["r"])
+        _, _, _, oidx = oq.get(q["x"], q["y"], q["r"])
+        assert np.array_equal(midx, idx) and np.array_equal(oidx, idx)
+        differs += int(len(l2.radius(q["x"], q["y"], q["r"])[0]) != len(idx))
+    if metric != "euclidean" and "single" not in name:
+        assert differs > 3                                  # the metric does change the selected sets
+
+
+def test_unsupported_metric_is_rejected_not_ignored():
+    pos = np.zeros((3, 2))
+    for bad in ("haversine", "mahalanobis", "seuclidean"):
+        with pytest.raises(ValueError):
+            cache.Position_Index(pos, metric=bad)
+        with pytest.raises(ValueError):
+            cache.Metric_Cache.from_arrays(np.zeros((3, 4), np.uint8), pos, (10, 10), distances=np.ones(3), options={"metric": bad})
+    with pytest.raises(ValueError):
+        cache.Position_Index(pos, metric="minkowski", p=3)
+    assert cache.Position_Index(pos, metric="minkowski", p=1).metric == cache.METRIC_L1
+    assert cache.Position_Index(pos, metric="minkowski", p=float("inf")).metric == cache.METRIC_LINF
+    assert cache.Position_Index(pos).metric == cache.METRIC_L2
 
 
 def _install_fixture(tmp_path, monkeypatch):

@@ -73,6 +73,32 @@ for r in range(world):
         assert int(counts_s[r, i]) == m, (rank, r, i)
         exp = torch.arange(m * 3, dtype=torch.int32).view(m, 3) + 1000 * r + 100 * i + 3
         assert torch.equal(rows_s[r, i, :m], exp), (rank, r, i)
+# the same steps through the counts-first form: only max(count) rows per pair travel, same contents
+g2 = sharding.MatchGatherer("cpu", capacity=CAP, pairs_per_step=PPS, two_phase=True)
+for step in range(4):
+    rows_t, cnts_t = g2.send_buffers()
+    for i in range(PPS):
+        m = (step + 2 * i + 3 * rank) %% (CAP + 1)
+        cnts_t[i] = m
+        rows_t[i * CAP:i * CAP + m] = torch.arange(m * 3, dtype=torch.int32).view(m, 3) + 1000 * rank + 100 * i + step
+    g2.submit_device()
+counts_2, rows_2 = g2.finish()
+mmax = int(counts_s.max())
+assert torch.equal(counts_2, counts_s) and rows_2.shape == (world, PPS, mmax, 3) and mmax < CAP
+assert g2.rows_shipped == PPS * mmax and gs.rows_shipped == PPS * CAP
+for r in range(world):
+    for i in range(PPS):
+        m = int(counts_s[r, i])
+        assert torch.equal(rows_2[r, i, :m], rows_s[r, i, :m]), (rank, r, i)
+g1 = sharding.MatchGatherer("cpu", capacity=64, two_phase=True)          # one pair per step, host path
+for step in range(3):
+    g1.submit(mine[: max(0, len(mine) - step)])
+c1, r1 = g1.finish()
+for r in range(world):
+    n_r = sum(3 + 2 * p for p in sharding.shard_items(7, r, world)) - 2
+    assert int(c1[r]) == n_r and r1.shape[1] == int(c1.max())
+    if r == rank:
+        assert np.array_equal(r1[r, :n_r].numpy(), mine[:n_r])
 # ONE large problem, train rows sharded: election keys per shard (here from the CPU oracle, on
 # the GPU from fm_xcheck1_keys), one all-reduce(min), decode == the unsharded cross-check
 sys.path.insert(0, %r)
