@@ -60,6 +60,21 @@ def config3():
          wall_s=w, rounds_per_s=rounds / w, pairs_per_s=pairs / w, matches_per_s=len(m[0]) / w)
 
 
+def config3_thresholds():
+    """configs[2] at 15 thresholds in ONE launch (key "3t"): the reference's driver asks a pair for a list of
+    thresholds (turntable.py:59-60); the runs are independent, one workgroup and one run state each."""
+    mc, fi = build_pair((6000, 4000), 300000, 20250003, 2000)
+    stats = {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats, "return_arrays": True})
+    taus = [float(t) for t in np.linspace(0.5, 1.0, 15)]
+    get(taus)
+    stats.clear()
+    m, w, k = best_of(lambda: get(taus), 2)
+    rounds, pairs = stats["rounds"] // 2, stats["pairs"] // 2
+    emit(config=3, op="15 thresholds linspace(0.5, 1.0, 15) of the 24 MP pair in one launch", runs=len(taus),
+         matches=int(sum(len(r[0]) for r in m)), rounds=rounds, wall_s=w, kernel_ms=k, rounds_per_s=rounds / w, pairs_per_s=pairs / w)
+
+
 def config4():
     pairs = [build_pair((1000, 1000), 12500, 20250100 + i, 600) for i in range(64)]
     for n in (8, 64):
@@ -92,6 +107,6 @@ def config5():
              frac_int8_mfma_peak=1e10 * 256 / (k * 1e-3) / 5e15)
 
 
-for name, fn in (("2", config2), ("3", config3), ("4", config4), ("5", config5)):
-    if not only or name in only:
+for name, fn in (("2", config2), ("3", config3), ("3t", config3_thresholds), ("4", config4), ("5", config5)):
+    if (not only and name != "3t") or name in only:
         fn()
