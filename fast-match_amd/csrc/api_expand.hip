@@ -1,0 +1,383 @@
+// C-ABI of libfastmatch_hip.so (include/fastmatch_hip.h), part 3: host glue of K7, the device-resident
+// expansion loop (expand.hip) -- pairs, run states, launches, result fetch.
+#include "ctx_internal.h"
+
+using namespace fm;
+
+// ---------------------------------------------------------------------------------------
+// K7 entry points
+// ---------------------------------------------------------------------------------------
+// An fm_expand holds what an image pair's runs SHARE and never change (banks, position index, cell
+// offsets, target positions) plus a pool of run states (pending stack, seen / found tables, result
+// arrays, seed buffer).  One launch may hold several runs of one pair -- the reference is driven as
+// pairs x thresholds (turntable.py:59-60) -- each run in a state of its own, one workgroup each.
+struct ExpandRun {
+    void* blob = nullptr;          // stack | seen | found | m_index | m_pos | m_ratio | result
+    double* stack = nullptr;
+    unsigned long long* seen = nullptr;
+    unsigned long long* found = nullptr;
+    int32_t* m_index = nullptr;
+    double* m_pos = nullptr;
+    double* m_ratio = nullptr;
+    long long* result = nullptr;
+    double* d_seeds = nullptr;     // grown on demand
+    int64_t seeds_cap = 0;
+    // capacities of THIS run state: they start at the pair's defaults and are multiplied by four when a run
+    // ends with the matching FM_EXPAND_*_FULL status (fm_expand_run then repeats the run)
+    int64_t match_cap = 0, stack_cap = 0, seen_cap = 0, found_cap = 0;
+};
+
+struct fm_expand {
+    ExpandPair dev{};              // device pointers + parameters (run state, seeds and tau filled per run)
+    void* blob = nullptr;          // the shared arrays
+    int64_t nq = 0;
+    int64_t match_cap = 0, stack_cap = 0, seen_cap = 0;       // defaults of a new run state
+    std::vector<ExpandRun> runs;   // run slot k = the k-th run of this pair inside one launch
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline int64_t pow2_at_least(int64_t x) { int64_t p = 1; while (p < x) p <<= 1; return p; }
+
+static void expand_run_free(ExpandRun& r)
+{
+    if (r.blob) (void)hipFree(r.blob);
+    if (r.d_seeds) (void)hipFree(r.d_seeds);
+    r = ExpandRun{};
+}
+
+// (Re)allocate the arrays of a run state for its current capacities.
+static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
+{
+    if (r.blob) { (void)hipFree(r.blob); r.blob = nullptr; }
+    r.found_cap = pow2_at_least(4 * r.match_cap);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
+    // (seen and found are neighbours: one fill resets both)
+    const size_t o_stack = carve((size_t)r.stack_cap * 32), o_seen = carve((size_t)r.seen_cap * 8), o_found = carve((size_t)r.found_cap * 16);
+    const size_t o_mi = carve((size_t)r.match_cap * 4), o_mp = carve((size_t)r.match_cap * 32), o_mr = carve((size_t)r.match_cap * 8);
+    const size_t o_res = carve(256);
+    hipError_t e = hipMalloc(&r.blob, off);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        r.blob = nullptr;
+        return fail(ctx, FM_ENOMEM, std::string("fm_expand: run state (") + std::to_string(off >> 20) + " MiB): " + hipGetErrorString(e));
+    }
+    char* b = (char*)r.blob;
+    r.stack = (double*)(b + o_stack); r.seen = (unsigned long long*)(b + o_seen); r.found = (unsigned long long*)(b + o_found);
+    r.m_index = (int32_t*)(b + o_mi); r.m_pos = (double*)(b + o_mp); r.m_ratio = (double*)(b + o_mr);
+    r.result = (long long*)(b + o_res);
+    return FM_OK;
+}
+
+// Run slot `slot` of the pair exists after this call (slots are created in order).
+static int expand_ensure_run(fm_ctx* ctx, fm_expand* ex, size_t slot)
+{
+    while (ex->runs.size() <= slot) {
+        ExpandRun r;
+        r.match_cap = ex->match_cap; r.stack_cap = ex->stack_cap; r.seen_cap = ex->seen_cap;
+        int rc = expand_run_alloc(ctx, r);
+        if (rc != FM_OK) return rc;
+        ex->runs.push_back(r);
+    }
+    return FM_OK;
+}
+
+static void expand_bind_run(ExpandPair& P, const ExpandRun& r)
+{
+    P.stack = r.stack; P.stack_cap = r.stack_cap;
+    P.seen = r.seen; P.seen_cap = r.seen_cap;
+    P.found = r.found; P.found_cap = r.found_cap;
+    P.m_index = r.m_index; P.m_pos = r.m_pos; P.m_ratio = r.m_ratio; P.match_cap = r.match_cap;
+    P.result = r.result;
+}
+
+extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_create: ctx is NULL");
+    if (!d || !out) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL argument");
+    *out = nullptr;
+    if (!d->query || !d->target) return fail(ctx, FM_EINVAL, "fm_expand_create: NULL bank");
+    if (d->query->kind != d->target->kind)
+        return fail(ctx, FM_EINVAL, "fm_expand_create: query/target kind mismatch");
+    const bool f32 = d->query->kind == FM_BANK_F32;
+    if (f32 && !filter_usable(*d->target, *d->query))
+        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: float32 banks without usable fp16 filter planes (non-finite values or scales more than 2^40 apart)");
+    if (d->query->dim != d->target->dim) return fail(ctx, FM_EINVAL, "fm_expand_create: dim mismatch");
+    if (!d->query->selfdist) return fail(ctx, FM_EINVAL, "fm_expand_create: query bank has no self distances");
+    const int64_t nq = d->query->n, nt = d->target->n;
+    const int64_t ncells = (int64_t)d->rows * d->cols;
+    if (d->width < 1 || d->height < 1 || d->cell_w < 1 || d->cell_h < 1 || d->rows < 1 || d->cols < 1 || d->radius < 0)
+        return fail(ctx, FM_EINVAL, "fm_expand_create: bad grid parameters");
+    if (d->metric < FM_METRIC_EUCLIDEAN || d->metric > FM_METRIC_CHEBYSHEV) return fail(ctx, FM_EINVAL, "fm_expand_create: unknown metric");
+    if (d->rows > 65535 || d->cols > 65535 || d->width > 65535 || d->height > 65535)
+        return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: image or grid too large for 16-bit cell keys");
+    if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || !d->cell_off || (nt > 0 && !d->target_pos))
+        return fail(ctx, FM_EINVAL, "fm_expand_create: NULL array");
+    const int64_t nb = (int64_t)d->index_nbx * d->index_nby;
+    if (d->index_nbx < 0 || d->index_nby < 0 || d->index_start[nb] != nq || !(d->index_bucket > 0.0))
+        return fail(ctx, FM_EINVAL, "fm_expand_create: inconsistent position index");
+    if (d->cell_off[0] != 0 || d->cell_off[ncells] != nt) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off must cover the target bank");
+    for (int64_t c = 0; c < ncells; ++c)
+        if (d->cell_off[c + 1] < d->cell_off[c]) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off not monotonic");
+    for (int64_t i = 0; i < nq; ++i) {
+        if (d->index_order[i] < 0 || d->index_order[i] >= nq) return fail(ctx, FM_EINVAL, "fm_expand_create: index_order out of range");
+        const double x = d->query_pos[2 * i], y = d->query_pos[2 * i + 1];
+        if (!(x >= 0.0) || !(y >= 0.0) || x / d->cell_w >= 65535.0 || y / d->cell_h >= 65535.0)
+            return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: query position outside the 16-bit cell-key range");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_expand* ex = new (std::nothrow) fm_expand();
+    if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
+    ex->nq = nq;
+    ex->match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
+    ex->stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
+    ex->seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
+    // the shared arrays in one allocation
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
+    const size_t o_qpos = carve((size_t)nq * 16), o_order = carve((size_t)nq * 4), o_start = carve((size_t)(nb + 1) * 4);
+    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16);
+    hipError_t e = hipMalloc(&ex->blob, off);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
+    char* b = (char*)ex->blob;
+    auto bail = [&](int code) { for (auto& r : ex->runs) expand_run_free(r); (void)hipFree(ex->blob); delete ex; return code; };
+#define ETRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)hipGetLastError(); \
+        return bail(fail(ctx, FM_EDEVICE, std::string(#expr " failed: ") + hipGetErrorString(_e))); } } while (0)
+    if (nq) ETRY(hipMemcpyAsync(b + o_qpos, d->query_pos, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (nq) ETRY(hipMemcpyAsync(b + o_order, d->index_order, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipMemcpyAsync(b + o_start, d->index_start, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipMemcpyAsync(b + o_coff, d->cell_off, (size_t)(ncells + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) ETRY(hipMemcpyAsync(b + o_tpos, d->target_pos, (size_t)nt * 16, hipMemcpyHostToDevice, ctx->stream));
+    ETRY(hipStreamSynchronize(ctx->stream));
+#undef ETRY
+    ExpandPair& P = ex->dev;
+    P.q_rows8 = d->query->rows8; P.q_norm = d->query->norm; P.q_selfdist = d->query->selfdist;
+    P.q_pos = (const double*)(b + o_qpos);
+    P.idx_order = (const int32_t*)(b + o_order); P.idx_start = (const int32_t*)(b + o_start);
+    P.idx_bucket = d->index_bucket; P.idx_x0 = d->index_x0; P.idx_y0 = d->index_y0;
+    P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;
+    P.metric = d->metric;
+    P.t_rows8 = d->target->rows8; P.t_norm = d->target->norm;
+    P.f32 = f32 ? 1 : 0;
+    P.tie_guard = (!f32 && sqrt_tie_possible(*d->query, *d->target)) ? 1 : 0;
+    P.rf = RoundF32{};
+    if (f32) fill_round_f32(&P.rf, *d->query, *d->target);
+    P.cell_off = (const int64_t*)(b + o_coff); P.t_pos = (const double*)(b + o_tpos);
+    P.width = d->width; P.height = d->height; P.cell_w = d->cell_w; P.cell_h = d->cell_h;
+    P.rows = d->rows; P.cols = d->cols; P.margin = d->margin; P.radius = d->radius;
+    P.seeds = nullptr; P.n_seeds = 0; P.tau = 0.0;
+    P.prof = 0;                        // (set per run from the context's expand_prof option)
+    // the first run state exists from the start (a pair that cannot get one fails here, not at its first run)
+    int rc = expand_ensure_run(ctx, ex, 0);
+    if (rc != FM_OK) return bail(rc);
+    expand_bind_run(P, ex->runs[0]);
+    *out = ex;
+    return FM_OK;
+}
+
+extern "C" int fm_expand_destroy(fm_ctx* ctx, fm_expand* ex)
+{
+    if (!ex) return FM_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    for (auto& r : ex->runs) expand_run_free(r);
+    if (ex->blob) (void)hipFree(ex->blob);
+    delete ex;
+    return FM_OK;
+}
+
+// Run slot of entry i of a launch: how many earlier entries name the same pair.
+static int expand_slot_of(fm_expand* const* pairs, int i)
+{
+    int k = 0;
+    for (int j = 0; j < i; ++j) k += pairs[j] == pairs[i] ? 1 : 0;
+    return k;
+}
+
+extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
+                             const int64_t* n_seeds, const double* tau, int64_t* n_matches,
+                             int64_t* n_rounds, int64_t* n_pairs, int32_t* status)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_run: ctx is NULL");
+    if (n < 0) return fail(ctx, FM_EINVAL, "fm_expand_run: n < 0");
+    if (n == 0) return FM_OK;
+    if (!pairs || !seeds || !n_seeds || !tau) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<ExpandPair> host((size_t)n);
+    std::vector<ExpandRun*> run((size_t)n);
+    int rc;
+    {
+        // slots by occurrence (a map instead of expand_slot_of's quadratic scan: a launch may hold thousands of runs)
+        std::map<fm_expand*, int> seen_pairs;
+        for (int i = 0; i < n; ++i) {
+            fm_expand* ex = pairs[i];
+            if (!ex) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL pair");
+            if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
+            const int slot = seen_pairs[ex]++;
+            if ((rc = expand_ensure_run(ctx, ex, (size_t)slot)) != FM_OK) return rc;
+        }
+        seen_pairs.clear();
+        for (int i = 0; i < n; ++i) {                      // (pointers into runs[] are taken once the vectors stopped growing)
+            fm_expand* ex = pairs[i];
+            ExpandRun* r = &ex->runs[(size_t)seen_pairs[ex]++];
+            run[(size_t)i] = r;
+            if (n_seeds[i] > r->seeds_cap) {
+                if (r->d_seeds) { HIP_TRY(ctx, hipFree(r->d_seeds)); r->d_seeds = nullptr; r->seeds_cap = 0; }
+                const int64_t cap = n_seeds[i] + n_seeds[i] / 2 + 64;
+                HIP_TRY(ctx, hipMalloc((void**)&r->d_seeds, (size_t)cap * 32));
+                r->seeds_cap = cap;
+            }
+        }
+    }
+    rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, (size_t)n * sizeof(ExpandPair) + 64);
+    if (rc != FM_OK) return rc;
+    CallScope cs(ctx);
+    for (int i = 0; i < n; ++i) {
+        fm_expand* ex = pairs[i];
+        ExpandRun* r = run[(size_t)i];
+        if (n_seeds[i]) HIP_TRY(ctx, hipMemcpyAsync(r->d_seeds, seeds[i], (size_t)n_seeds[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+        // (the two tables are neighbours in the run's allocation: one fill)
+        HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
+        host[i] = ex->dev;
+        expand_bind_run(host[i], *r);
+        host[i].seeds = r->d_seeds;
+        host[i].n_seeds = n_seeds[i];
+        host[i].tau = tau[i];
+        host[i].prof = ctx->tune.expand_prof;
+    }
+    // the int8 and the float32 pairs are two kernels: descriptors grouped by kind, one launch each
+    std::vector<ExpandPair> grouped;
+    grouped.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) if (!host[i].f32) grouped.push_back(host[i]);
+    const int n_i8 = (int)grouped.size();
+    for (int i = 0; i < n; ++i) if (host[i].f32) grouped.push_back(host[i]);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    if (n_i8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n_i8, false, false, ctx->stream));
+    if (n - n_i8 > 0) HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n_i8 * sizeof(ExpandPair), n - n_i8, true, false, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    std::vector<long long> res((size_t)n * 4);
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // Runs that ended on a capacity run again, from the start: a radius subset beyond the kernel's 2048 rows
+    // (status 2, int8 banks) in the 4096-row variant of the kernel; a full pending stack, result list or
+    // hash table (status 1, 4, 5: thresholds above 1 accept nearly every cross-checked pair and the
+    // expansion heads for every (cell, query cell) combination) in a run state four times as large, at most
+    // `expand_grow` times over (default 2; the status stands after that).  The other runs keep their results.
+    std::vector<char> big((size_t)n, 0);
+    for (int pass = 0; pass <= ctx->tune.expand_grow + 1; ++pass) {
+        std::vector<int> redo;
+        for (int i = 0; i < n; ++i) {
+            const long long st = res[(size_t)i * 4 + 3];
+            ExpandRun* r = run[(size_t)i];
+            if (st == 2 && !host[i].f32 && ctx->tune.expand_big && !big[(size_t)i]) { big[(size_t)i] = 1; redo.push_back(i); continue; }
+            if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (big[(size_t)i] ? 1 : 0)) {
+                const int64_t limit = (int64_t)1 << 28;
+                if (st == 1) { if (r->stack_cap >= limit) continue; r->stack_cap *= 4; }
+                if (st == 4) { if (r->match_cap >= limit) continue; r->match_cap *= 4; }
+                if (st == 5) { if (r->seen_cap >= limit) continue; r->seen_cap *= 4; }
+                if (expand_run_alloc(ctx, *r) != FM_OK) {                 // no memory for the larger state: the status stands
+                    r->match_cap = pairs[i]->match_cap; r->stack_cap = pairs[i]->stack_cap; r->seen_cap = pairs[i]->seen_cap;
+                    if ((rc = expand_run_alloc(ctx, *r)) != FM_OK) return rc;
+                    continue;
+                }
+                expand_bind_run(host[i], *r);
+                redo.push_back(i);
+            }
+        }
+        if (redo.empty()) break;
+        for (int v = 0; v < 2; ++v) {                   // the two int8 capacity variants (float32 pairs: the small one)
+            grouped.clear();
+            std::vector<int> idx;
+            for (int i : redo) if ((big[(size_t)i] ? 1 : 0) == v && !host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
+            const int n8 = (int)idx.size();
+            if (v == 0) for (int i : redo) if (host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
+            if (idx.empty()) continue;
+            for (int i : idx)
+                HIP_TRY(ctx, hipMemsetAsync(run[(size_t)i]->seen, 0xff, (size_t)((char*)run[(size_t)i]->found - (char*)run[(size_t)i]->seen) +
+                                            (size_t)run[(size_t)i]->found_cap * 16, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), grouped.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+            if (n8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n8, false, v == 1, ctx->stream));
+            if ((int)idx.size() > n8)
+                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n8 * sizeof(ExpandPair), (int)idx.size() - n8, true, false, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+            for (int i : idx)
+                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (ws_in is reused by the next variant)
+        }
+    }
+    for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
+    if (ctx->tune.expand_prof) {
+        long long pr[16];
+        (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
+        static const char* names[12] = {"pop:barrier", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "pop:thread0",
+                                        "x1:bfrag+barrier", "x1:gather", "x1:mfma", "x1:merge"};
+        fprintf(stderr, "[fm_expand prof, run 0, %lld rounds] ", pr[1]);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
+        fprintf(stderr, "\n");
+    }
+    rc = cs.finish();
+    if (rc != FM_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (n_matches) n_matches[i] = res[(size_t)i * 4 + 0];
+        if (n_rounds) n_rounds[i] = res[(size_t)i * 4 + 1];
+        if (n_pairs) n_pairs[i] = res[(size_t)i * 4 + 2];
+        if (status) status[i] = (int32_t)res[(size_t)i * 4 + 3];
+    }
+    return FM_OK;
+}
+
+extern "C" int fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index, double* positions, double* ratio)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_fetch: NULL argument");
+    const int32_t slot = 0;
+    const fm_expand* one = ex;
+    int32_t* ip = index; double* pp = positions; double* rp = ratio;
+    return fm_expand_fetch_many(ctx, 1, &one, &slot, &n, index ? &ip : nullptr, positions ? &pp : nullptr, ratio ? &rp : nullptr);
+}
+
+// The results of several runs of one fm_expand_run in ONE pass: every copy is enqueued, then a single
+// synchronisation (a synchronisation per run: 64 runs = 2 ms of a 32 ms call).
+extern "C" int fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int32_t* slot, const int64_t* n,
+                                    int32_t* const* index, double* const* positions, double* const* ratio)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_expand_fetch_many: ctx is NULL");
+    if (n_ex < 0) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: n_ex < 0");
+    if (n_ex == 0) return FM_OK;
+    if (!ex || !n) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: NULL argument");
+    size_t total = 0;
+    std::vector<const ExpandRun*> run((size_t)n_ex);
+    for (int i = 0; i < n_ex; ++i) {
+        if (!ex[i]) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: NULL pair");
+        const int s = slot ? slot[i] : expand_slot_of((fm_expand* const*)ex, i);
+        if (s < 0 || (size_t)s >= ex[i]->runs.size()) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: the pair has no such run slot");
+        run[(size_t)i] = &ex[i]->runs[(size_t)s];
+        if (n[i] < 0 || n[i] > run[(size_t)i]->match_cap) return fail(ctx, FM_EINVAL, "fm_expand_fetch_many: n out of range");
+        total += (size_t)n[i] * 44 + 192;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    struct StageGuard {      // drop the staged copies on every exit path (their targets die with the call)
+        fm_ctx* c;
+        ~StageGuard() { c->staged.clear(); c->h_stage_used = 0; }
+    } guard{ctx};
+    ctx->staged.clear();
+    ctx->h_stage_used = 0;
+    if (total > ctx->h_stage_bytes) {          // one staging area for all of it (d2h grows it only while nothing is staged)
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr;
+        ctx->h_stage_bytes = 0;
+        const size_t want = total + total / 4 + (1 << 20);
+        if (hipHostMalloc((void**)&ctx->h_stage, want, hipHostMallocDefault) == hipSuccess) ctx->h_stage_bytes = want;
+        else { (void)hipGetLastError(); ctx->h_stage = nullptr; }
+    }
+    for (int i = 0; i < n_ex; ++i) {
+        if (n[i] == 0) continue;
+        if (index && index[i]) HIP_TRY(ctx, d2h(ctx, index[i], run[(size_t)i]->m_index, (size_t)n[i] * 4));
+        if (positions && positions[i]) HIP_TRY(ctx, d2h(ctx, positions[i], run[(size_t)i]->m_pos, (size_t)n[i] * 32));
+        if (ratio && ratio[i]) HIP_TRY(ctx, d2h(ctx, ratio[i], run[(size_t)i]->m_ratio, (size_t)n[i] * 8));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (const auto& c : ctx->staged) memcpy(c.dst, ctx->h_stage + c.off, c.bytes);
+    return FM_OK;
+}

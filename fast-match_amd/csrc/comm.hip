@@ -7,7 +7,7 @@
 // RCCL is bound at run time (dlopen "librccl.so.1"): a process that already carries an RCCL --
 // PyTorch-ROCm bundles one under the same SONAME -- shares it instead of loading a second copy,
 // and a process that never gathers needs no RCCL at all.
-#include "fm_internal.h"
+#include "ctx_internal.h"
 #include <dlfcn.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -102,3 +102,90 @@ int comm_gather(void* comm, const int32_t* d_rows, const int64_t* d_count, int64
 }
 
 }  // namespace fm
+
+using namespace fm;
+
+// ---------------------------------------------------------------------------------------
+// result gather over RCCL (comm.hip)
+// ---------------------------------------------------------------------------------------
+extern "C" int fm_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(nullptr, FM_EINVAL, "fm_comm_unique_id: NULL buffer");
+    std::string err;
+    const int rc = comm_unique_id(id128, &err);
+    return rc == FM_OK ? FM_OK : fail(nullptr, rc, "fm_comm_unique_id: " + err);
+}
+
+extern "C" int fm_comm_init(fm_ctx* ctx, int nranks, int rank, const void* id128)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_comm_init: ctx is NULL");
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, FM_EINVAL, "fm_comm_init: bad argument");
+    if (ctx->comm) return fail(ctx, FM_EINVAL, "fm_comm_init: the context already has a communicator (fm_comm_destroy first)");
+    std::string err;
+    void* comm = nullptr;
+    const int rc = comm_init(ctx->device, nranks, rank, id128, &comm, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_comm_init: " + err);
+    ctx->comm = comm;
+    ctx->comm_ranks = nranks;
+    return FM_OK;
+}
+
+extern "C" int fm_comm_destroy(fm_ctx* ctx)
+{
+    if (!ctx) return FM_OK;
+    if (ctx->comm) {
+        sync_all_streams(ctx);               // (a gather behind an async fill runs on a tail stream)
+        comm_destroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_ranks = 0;
+    }
+    return FM_OK;
+}
+
+// Two-phase form: the counts first, then only as many rows per rank as the fullest rank holds (the padded
+// form ships cap rows per rank whatever they hold).  Costs a host synchronisation between the phases.
+extern "C" int fm_gather_matches_counted(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                                         int32_t* d_all_rows, int64_t* d_all_counts, int64_t* rows_per_rank)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_gather_matches_counted: ctx is NULL");
+    if (!ctx->comm) return fail(ctx, FM_EINVAL, "fm_gather_matches_counted: no communicator (fm_comm_init)");
+    if (cap < 0 || !d_count || !d_all_counts || !rows_per_rank || (cap > 0 && (!d_rows || !d_all_rows)))
+        return fail(ctx, FM_EINVAL, "fm_gather_matches_counted: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    hipStream_t gs = ctx->rows_stream ? ctx->rows_stream : ctx->stream;
+    int rc = comm_gather(ctx->comm, nullptr, d_count, 0, nullptr, d_all_counts, gs, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches_counted: " + err);
+    std::vector<int64_t> counts((size_t)ctx->comm_ranks);
+    HIP_TRY(ctx, hipMemcpyAsync(counts.data(), d_all_counts, counts.size() * 8, hipMemcpyDeviceToHost, gs));
+    HIP_TRY(ctx, hipStreamSynchronize(gs));
+    int64_t m = 0;
+    for (int64_t c : counts) m = c > m ? c : m;
+    if (m > cap) m = cap;
+    *rows_per_rank = m;
+    if (m > 0) {
+        rc = comm_gather(ctx->comm, d_rows, nullptr, m, d_all_rows, nullptr, gs, &err);
+        if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches_counted: " + err);
+        HIP_TRY(ctx, hipStreamSynchronize(gs));
+    }
+    return FM_OK;
+}
+
+extern "C" int fm_gather_matches(fm_ctx* ctx, const int32_t* d_rows, const int64_t* d_count, int64_t cap,
+                                 int32_t* d_all_rows, int64_t* d_all_counts, int wait)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_gather_matches: ctx is NULL");
+    if (!ctx->comm) return fail(ctx, FM_EINVAL, "fm_gather_matches: no communicator (fm_comm_init)");
+    if (cap < 0 || !d_count || !d_all_counts || (cap > 0 && (!d_rows || !d_all_rows)))
+        return fail(ctx, FM_EINVAL, "fm_gather_matches: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    // on the stream that filled d_rows: behind fm_match_accepted_dev_async that is the tail stream, so
+    // the collective does not sit in front of the next pair's K1
+    hipStream_t gs = ctx->rows_stream ? ctx->rows_stream : ctx->stream;
+    const int rc = comm_gather(ctx->comm, d_rows, d_count, cap, d_all_rows, d_all_counts, gs, &err);
+    if (rc != FM_OK) return fail(ctx, rc, "fm_gather_matches: " + err);
+    if (wait) HIP_TRY(ctx, hipStreamSynchronize(gs));
+    return FM_OK;
+}
+

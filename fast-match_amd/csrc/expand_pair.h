@@ -1,4 +1,4 @@
-// Device-side descriptor of one image pair for expand_kernel (expand.hip); filled by api.hip.
+// Device-side descriptor of one image pair for expand_kernel (expand.hip); filled by api_expand.hip.
 #pragma once
 #include <stdint.h>
 #include "round_body_f32.h"

@@ -178,7 +178,7 @@ struct TopK8 {
 // square root: never below kSqrtTieMin (exhaustive check over [0, 128 * 255^2]), and above it only
 // as pairs {n, n + 1} (no three integers share a root).  The matrix-core kernels order by d2; the
 // callers repair the rows where that can matter -- the K-th best d2 reached kSqrtTieMin -- by an
-// exact rescan (sqrt_fix_* kernels in api.hip, the cold branch of x1_round_wsplit), and only for bank
+// exact rescan (sqrt_fix_kernel in api_match.hip, the cold branch of x1_round_wsplit), and only for bank
 // pairs whose row norms allow such a distance at all (Bank::usq_max): SIFT-range descriptors
 // (|d|^2 ~ 2.6e5) never take any of it.
 constexpr unsigned kSqrtTieMin = 4197200u;
