@@ -54,7 +54,7 @@ def k1_source_hash():
     return h.hexdigest()
 
 
-def cpu_baseline(Q, T, budget_s=12.0, keep=None):
+def cpu_baseline(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_BUDGET_S", "12")), keep=None):
     """Oracle (kind 'port': the reference's .so cannot run here) on a bounded row sample of
     the same workload, all host cores.  keep (a dict): receives the sample size and the oracle's
     (tidx, dist) of the sample, for the self-check of the timed batch."""

@@ -297,6 +297,33 @@ def test_many_thresholds_of_one_pair_in_one_launch(ctx, monkeypatch):
     assert get([]) == []
 
 
+def test_many_runs_of_several_pairs_in_one_launch_any_order(ctx):
+    """40 runs over three pairs in random order with random thresholds (some repeated) in ONE launch: every
+    run equals the single-run launch of the same (pair, threshold); run states are created on demand and
+    reused by the next launch."""
+    from fastmatch_amd.cache import Grid_Cache
+    rng = np.random.default_rng(3)
+    pairs = []
+    for k in range(3):
+        mc, fi, _, _ = _build((640, 480), 1500 + 400 * k, seed=50 + k, ctx=ctx)
+        pos, ratios = fastmatch.match_thumbs(fi, mc, context=ctx)
+        grid = Grid_Cache(fi, (50, 50), fi, margin=25)
+        pairs.append((fastmatch.make_expander(mc, grid, 100, ctx), pos, ratios))
+    taus = [0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+    single = {}
+    for pi, (ex, pos, ratios) in enumerate(pairs):
+        for t in taus:
+            single[(pi, t)] = fastmatch.run_device_loops(ctx, [ex], [pos[ratios < t]], [t])[0]
+            assert single[(pi, t)] is not None
+    for rep in range(2):
+        runs = [(int(rng.integers(0, 3)), float(rng.choice(taus))) for _ in range(40)]
+        got = fastmatch.run_device_loops(ctx, [pairs[pi][0] for pi, _ in runs],
+                                         [pairs[pi][1][pairs[pi][2] < t] for pi, t in runs], [t for _, t in runs])
+        for (pi, t), g in zip(runs, got):
+            _same_matches(g, single[(pi, t)])
+    assert ctx.expand_slots([pairs[0][0], pairs[1][0], pairs[0][0], pairs[0][0]]) == [0, 0, 1, 2]
+
+
 def test_run_states_grow_when_a_run_fills_them(ctx):
     """A run that fills its result list or pending stack is repeated by fm_expand_run in a state four
     times as large (option expand_grow, default twice): tiny first capacities give the results of the

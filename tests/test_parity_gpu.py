@@ -863,3 +863,33 @@ def test_full_size_float32_route_config5(monkeypatch):
     rows = rng.choice(NQ, 64, replace=False)
     oi, od = oracle.bf_knn(Q[rows], T, 2, order=1)
     assert _eq(i8[rows], oi) and _eq(d8[rows], od)
+
+
+def test_results_do_not_depend_on_the_options():
+    """fm_ctx_set_option: every launch-shape / tuning option, alone and in random combinations, leaves the
+    2-NN lists, the cross-check and the accepted matches bit-identical (the header promises it)."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    Q, T, _ = synth.planted_pair(3000, 33000, seed=91)
+    qb, tb = c.bank(Q), c.bank(T)
+    qb.set_selfdist(c.self_dist(qb))
+
+    def run():
+        return c.knn2(qb, tb) + c.xcheck1(qb, tb) + c.knn2(tb, qb) + c.match_accepted(qb, tb, 0.8)
+    ref = run()
+    oi, od = oracle.bf_knn(Q, T, 2)
+    assert _eq(ref[0], oi) and _eq(ref[1], od)
+    domains = {"nsplit": [0, 1, 2, 5, 12], "nb": [0, 4, 8], "nw": [0, 4, 8], "nbuf": [0, 2, 3], "prio": [0, 1],
+               "glds": [0, 1], "coop": [0, 1], "async_time_every": [0, 1, 4]}
+    defaults = {k: c.get_option(k) for k in domains}
+    rng = np.random.default_rng(7)
+    settings = [{k: v} for k, vs in domains.items() for v in vs]
+    settings += [{k: int(rng.choice(vs)) for k, vs in domains.items()} for _ in range(12)]
+    for s in settings:
+        for k, v in defaults.items():
+            c.set_option(k, v)
+        for k, v in s.items():
+            c.set_option(k, v)
+        got = run()
+        assert all(_eq(a, b) for a, b in zip(got, ref)), s
+    c.close()
