@@ -514,6 +514,20 @@ def main():
                "frac_int8_mfma_peak": float(NQ) * NT * OPS_PER_PAIR / (ctx.stats()["kernel_ms"] / reps * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
                "note": "fm_knn2_ratio: K2 top-2 + Lowe ratio + compaction, same banks"}
 
+    # Metric_Cache build (fm_self_dist = self 2-NN, K2): the single call timed during set-up (between bank uploads,
+    # clock still ramping) and, for the kernel's own rate, the mean of ten back-to-back calls
+    self2 = {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms, "wall_s": self_s,
+             "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region; kernel_ms = one call during set-up, "
+                     "kernel_ms_steady = mean of 10 back-to-back calls"}
+    if rank == 0 and legs:
+        ctx.self_dist(qb)
+        ctx.reset_stats()
+        for _ in range(10):
+            ctx.self_dist(qb)
+        s2 = ctx.stats()
+        self2["kernel_ms_steady"] = s2["kernel_ms"] / max(s2["kernel_launches"], 1)
+        self2["frac_int8_mfma_peak_steady"] = float(NQ) * NQ * OPS_PER_PAIR / (self2["kernel_ms_steady"] * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12)
+
     # ONE configs[1] call, the way a caller without a batch makes it: fm_match_accepted (K1 + election +
     # ratio test + compaction into page-locked buffers) and its synchronisation, 20 repetitions.
     single = None
@@ -660,8 +674,7 @@ def main():
                                  "library's own stream) per image pair, kernel_ms_per_launch = per launch; traffic / hbm_gbps = PMC HBM bytes "
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
                                  "cycles of the launch (profiles/)"},
-            "self_2nn": {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms,
-                         "wall_s": self_s, "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region"},
+            "self_2nn": self2,
             "classic_ratio_match": crm,
             "single_pair": single,
             "expand_c3": c3,
