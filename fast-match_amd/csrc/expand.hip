@@ -567,8 +567,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
-                    // high word: the float32 distance bits (both routes)
-                    const float d = __uint_as_float((unsigned)(qb >> 32));
+                    // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
+                    const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
                     // the positions step (b) needs ride on the same memory round trip as the self distance
                     const int qrow = cand[i];
                     t_local = (int)(unsigned)qb;

@@ -7,9 +7,12 @@
 namespace fm {
 
 // x1_round_wsplit: on return (after the caller's next __syncthreads) qbest[slot], slot in
-// [0, nq), holds (float32 bits of the distance << 32 | local train index) of the cross-checked match
-// of query slot `slot`, or ~0 (the distance itself, not d2: OpenCV compares the square roots, and
-// above kSqrtTieMin two d2 can share one; tile_ops.h).  q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
+// [0, nq), holds (distance key << 32 | local train index) of the cross-checked match of query slot
+// `slot`, or ~0.  Distance key: with tie_guard the float32 bits of the distance itself (OpenCV compares
+// the square roots, and above kSqrtTieMin two d2 can share one; tile_ops.h); without it -- the banks' norms
+// rule such distances out, e.g. every SIFT pair -- the integer d2, which then orders the same way and
+// spares the election a square root per train row (x1_key_distance decodes either).
+// q_rows[slot] = row of the query bank; train rows are [t0, t0 + nt) of the train bank.
 // qbest must be pre-filled with ~0 for slots [0, nq) (visible to all threads).  The bank pointers are
 // global-memory pointers (gptr, tile_ops.h): callers convert theirs once.
 // SR = query rows gathered per staging step (128 in round_kernel, 512 in expand_kernel so that a
@@ -23,6 +26,12 @@ namespace fm {
 // four waves' reverse-NN candidates meet in an LDS table tbest[128] through 64-bit
 // atomicMin on (d2 << 32 | slot) -- min d2, then lowest slot, exactly the order
 // cv::batchDistance keeps -- before the scatter-min into qbest.
+// float32 distance of a qbest key's high word (see x1_round_wsplit)
+__device__ __forceinline__ float x1_key_distance(unsigned hi, int tie_guard)
+{
+    return tie_guard ? __uint_as_float(hi) : sqrtf((float)hi);
+}
+
 constexpr int kTbestWords = 128 + 4;       // 128 train rows of a chunk + the tie repair's two masks and its accumulator
 
 template <int SR, int NT = 256>
@@ -164,7 +173,7 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                 const unsigned d2 = (unsigned)(tb >> 32);
                 tied = tie_guard && d2 >= kSqrtTieMin && sqrt_ties_up(d2);
                 if (!tied)
-                    atomicMin(&qbest[(unsigned)tb], ((unsigned long long)sqrt_bits(d2) << 32) | (unsigned)(cb0 + tid));
+                    atomicMin(&qbest[(unsigned)tb], ((unsigned long long)(tie_guard ? sqrt_bits(d2) : d2) << 32) | (unsigned)(cb0 + tid));
             }
         }
         if (tie_guard) {

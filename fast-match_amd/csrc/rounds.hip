@@ -66,7 +66,7 @@ void round_kernel(RoundParams p)
         double r = NAN;
         if (key != ~0ull) {
             ti = (int32_t)(unsigned)key;
-            d = __uint_as_float((unsigned)(key >> 32));
+            d = x1_key_distance((unsigned)(key >> 32), p.tie_guard);
             if (p.q_selfdist) r = (double)d / p.q_selfdist[p.q_rows[q0 + i]];
         }
         p.tidx[q0 + i] = ti;
