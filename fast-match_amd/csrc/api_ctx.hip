@@ -49,24 +49,59 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
     int sumsq = 0, usq = 0;
     bool bad = false;
     if (row < n) {
+        // the thread's 16 values; full-width rows (dim = 128: SIFT) come in as 16-byte loads -- byte / float loads
+        // one at a time ran the upload kernel at ~80 GB/s
+        int uv[16];
+        bool have[16];
+        if (dim == kDim) {
+            if constexpr (SRC_F32) {
+                const float4* sp = (const float4*)((const float*)src + row * kDim + 16 * c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = sp[q];
+                    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float fr = rintf(f[b]);
+                        const bool ok = (f[b] == fr) && f[b] >= 0.f && f[b] <= 255.f;
+                        bad |= !ok;
+                        uv[4 * q + b] = ok ? (int)fr : 128;
+                        have[4 * q + b] = true;
+                    }
+                }
+            } else {
+                const uint4 v = *(const uint4*)((const uint8_t*)src + row * kDim + 16 * c);
+                const unsigned ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { uv[4 * q + b] = (int)((ww[q] >> (8 * b)) & 0xffu); have[4 * q + b] = true; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = 16 * c + e;
+                uv[e] = 128;                         // padding beyond dim: 0 after the shift
+                have[e] = k < dim;
+                if (k < dim) {
+                    if constexpr (SRC_F32) {
+                        const float f = ((const float*)src)[row * dim + k];
+                        const float fr = rintf(f);
+                        if (!(f == fr) || f < 0.f || f > 255.f) bad = true;
+                        else uv[e] = (int)fr;
+                    } else {
+                        uv[e] = ((const uint8_t*)src)[row * dim + k];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned word = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int k = 16 * c + 4 * q + b;
-                int u = 128;                         // padding beyond dim: 0 after the shift
-                if (k < dim) {
-                    if constexpr (SRC_F32) {
-                        const float f = ((const float*)src)[row * dim + k];
-                        const float fr = rintf(f);
-                        if (!(f == fr) || f < 0.f || f > 255.f) { bad = true; u = 128; }
-                        else u = (int)fr;
-                    } else {
-                        u = ((const uint8_t*)src)[row * dim + k];
-                    }
-                    usq += u * u;
-                }
+                const int u = uv[4 * q + b];
+                if (have[4 * q + b]) usq += u * u;
                 const int s = u - 128;               // == (int8)(u ^ 0x80)
                 sumsq += s * s;
                 word |= (unsigned)(s & 0xff) << (8 * b);
