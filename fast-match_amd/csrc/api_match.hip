@@ -695,7 +695,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
         // Every event record is a packet the K1 launches of consecutive calls queue behind; the
         // start-of-kernel event is therefore taken for every async_time_every-th call only (those
-        // calls are the ones fm_get_stats accounts as timed K1 launches; FM_ASYNC_TIME_EVERY, default 4).
+        // calls are the ones fm_get_stats accounts as timed K1 launches; option async_time_every, default 4).
         const int time_every = ctx->tune.async_time_every;
         const bool timed_call = time_every > 0 && (ctx->async_calls++ % time_every) == 0;
         tm.timed = tm.timed && timed_call;
