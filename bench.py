@@ -355,8 +355,11 @@ def main():
     # (fm_match_accepted_dev_batch) and ONE all-gather ships the step's rows, overlapping the next step.
     step_gather = (world > 1 and os.environ.get("FM_BENCH_SYNC") != "1" and os.environ.get("FM_BENCH_BATCH", "1") != "0"
                    and os.environ.get("FM_BENCH_HOST_GATHER") != "1" and os.environ.get("FM_BENCH_GATHER") != "rccl")
+    # FM_BENCH_GATHER=counted: counts first, then only the rows that are there (a third of the bytes, one host wait
+    # per step; sharding.MatchGatherer two_phase) -- for the day the padded all-gather shows in the 8-GPU curve
     gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank),
-                                      pairs_per_step=PAIRS_PER_STEP if step_gather else 1) if world > 1 else None
+                                      pairs_per_step=PAIRS_PER_STEP if step_gather else 1,
+                                      two_phase=os.environ.get("FM_BENCH_GATHER") == "counted") if world > 1 else None
     device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
     pair_args = ctx.prepare_pairs(banks) if step_gather else None
     h_counts = ctx.pinned_empty(PAIRS_PER_STEP, np.int64)
