@@ -36,3 +36,10 @@ good = sum(1 for i, m in matches
 print("%d of them are planted correspondences" % good)
 fast = fastmatch.match(query_cache, target_img, {})(0.7)          # same result from the device-resident loop
 assert [m[0] for m in fast] == [m[0] for m in matches]
+
+# The reference's evaluation asks one pair for a whole list of thresholds (turntable.py:59-60): a list goes
+# through ONE launch of the device loop, one workgroup per threshold.
+taus = [0.5, 0.6, 0.7, 0.8, 0.9]
+per_tau = fastmatch.match(query_cache, target_img, {})(taus)
+print("matches per threshold:", dict(zip(taus, (len(m) for m in per_tau))))
+assert [m[0] for m in per_tau[2]] == [m[0] for m in matches]
