@@ -46,7 +46,15 @@ __global__ void knn2_merge_kernel(const unsigned long long* __restrict__ partial
     idx[2 * i + 1] = (b1 == ~0ull) ? -1 : (int32_t)(unsigned)b1;
     dist[2 * i]     = (b0 == ~0ull) ? INFINITY : key_dist(b0, f32);
     dist[2 * i + 1] = (b1 == ~0ull) ? INFINITY : key_dist(b1, f32);
-    if (fix && b1 != ~0ull && (unsigned)(b1 >> 32) >= kSqrtTieMin) fix[4 + atomicAdd(fix, 1u)] = (unsigned)i;
+    // The float32 order can differ from the d2 order only if the root class of the best or of the 2nd best d2
+    // has a second member (d2 - 1 or d2 + 1 shares its root): only then can a candidate outside this list, or
+    // the other list entry, tie with it and win on its index.
+    if (fix && b1 != ~0ull && (unsigned)(b1 >> 32) >= kSqrtTieMin) {
+        const unsigned e0 = (unsigned)(b0 >> 32), e1 = (unsigned)(b1 >> 32);
+        const bool paired1 = sqrt_ties_up(e1) || sqrt_ties_up(e1 - 1u);
+        const bool paired0 = e0 >= kSqrtTieMin && (sqrt_ties_up(e0) || sqrt_ties_up(e0 - 1u));
+        if (paired0 || paired1) fix[4 + atomicAdd(fix, 1u)] = (unsigned)i;
+    }
 }
 
 // Exact repair of the output rows listed in fix[] (see knn2_merge_kernel / xcheck_scatter_kernel): one
