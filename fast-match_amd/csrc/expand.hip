@@ -515,9 +515,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         // sort key and inclusion test of the pair's metric (BallTree(positions, metric), cache.pyx:276):
                         // squared Euclidean distance against r^2 (no fma: NumPy order), or |dx| + |dy| /
                         // max(|dx|, |dy|) against r
-                        const double d2 = P.metric == 0 ? __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy))
-                                        : (P.metric == 1 ? __dadd_rn(fabs(dx), fabs(dy)) : fmax(fabs(dx), fabs(dy)));
-                        if (d2 <= (P.metric == 0 ? r2 : r)) {
+                        double d2, lim;                              // (a uniform branch: one formula is executed)
+                        if (P.metric == 0) { d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)); lim = r2; }
+                        else if (P.metric == 1) { d2 = __dadd_rn(fabs(dx), fabs(dy)); lim = r; }
+                        else { d2 = fmax(fabs(dx), fabs(dy)); lim = r; }
+                        if (d2 <= lim) {
                             const int slot = atomicAdd(&sh_i[4], 1);
                             if (slot < CAND) { keys[slot] = (unsigned long long)__double_as_longlong(d2); cand[slot] = qi; }
                         }
