@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 NQ = NT = 100000
 TAU = 0.7
 SEED = 20250002
-PAIRS_PER_STEP = 12               # independent 100k x 100k pairs per GPU and step (timed region >= 0.2 s at 20 steps)
+PAIRS_PER_STEP = int(os.environ.get("FM_BENCH_PAIRS", "12"))   # independent 100k x 100k pairs per GPU and step (timed region >= 0.2 s at 20 steps; at most 16 share a launch)
 PROFILE_JSON = os.path.join(ROOT, "profiles", "latest_pmc.json")   # written by scripts/profile.sh
 K1_SOURCES = ("fast-match_amd/csrc/rowreduce.hip", "fast-match_amd/csrc/tile_ops.h")
 INT8_DENSE_PEAK_TOPS = 5000.0     # MI355X dense int8 MFMA (2x bf16's ~2.5 PF), MI355X_MICROARCH.md
