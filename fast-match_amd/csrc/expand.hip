@@ -673,13 +673,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             int po, eo;
             const int petot = block_rank_flags(push, emit, &po, &eo, wave_cnt, rank_toggle);
             const int ptot = petot & 0xffff, etot = petot >> 16;
-            if (tid == 0) {
-                sh_i[5] = (sh_top + ptot > P.stack_cap) ? 1 : 0;
-                sh_i[6] = (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) ? 1 : 0;
-            }
-            lds_barrier();
-            if (sh_i[5]) { status = kExpStackFull; break; }
-            if (sh_i[6]) { status = kExpMatchFull; break; }
+            // (every thread holds the same totals and counters and sh_top is stable here: no flag, no barrier)
+            if (sh_top + ptot > P.stack_cap) { status = kExpStackFull; break; }
+            if (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) { status = kExpMatchFull; break; }
             if (push) {
                 // The first accepted match must be popped first, i.e. sit on top.  One chunk
                 // (na <= kExpThreads, the usual case): write in reverse rank order.  More: chunks are
@@ -701,9 +697,15 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
             }
             n_emit += etot;
-            lds_barrier();
-            if (tid == 0) { sh_top += ptot; top += ptot; }
-            lds_barrier();
+            if (na <= kExpThreads) {
+                // the only chunk of the round (the usual case): thread 0 rewrites sh_top from its own `top` at
+                // the next pop, and the round ends with a full barrier -- none needed here
+                if (tid == 0) top += ptot;
+            } else {
+                lds_barrier();
+                if (tid == 0) { sh_top += ptot; top += ptot; }
+                lds_barrier();
+            }
         }
         if (status != kExpOk) break;
         // More than one chunk: the pushed region [top_before, top) is in ascending slot order;
