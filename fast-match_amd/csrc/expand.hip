@@ -400,6 +400,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             nxt_valid = 0;
             sh_i[0] = have;
             sh_i[3] = status;
+            sh_i[4] = 0;              // the radius query's candidate counter (read long before this point, by everyone)
             sh_i[7] = 0;
             sh_top = top;
             sh_seed = seed_i;
@@ -460,7 +461,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
             lds_barrier();
         }
-        lds_barrier();
+        // (the barrier behind the pop block, or the one that ends the last pass of the loop, is in front of these reads)
         status = sh_i[3];
         if (!sh_i[0] || status != kExpOk) break;
         const int col = sh_i[1], row = sh_i[2];
@@ -479,9 +480,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         const int64_t t1 = P.cell_off[cell + 1];
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
-        if (tid == 0) sh_i[4] = 0;
-        lds_barrier();
-        {
+        {   // (the counter sh_i[4] was cleared with the pop)
             const double r = (double)P.radius, b = P.idx_bucket;
             int bx0 = (int)floor(((double)qx - r - P.idx_x0) / b), bx1 = (int)floor(((double)qx + r - P.idx_x0) / b);
             int by0 = (int)floor(((double)qy - r - P.idx_y0) / b), by1 = (int)floor(((double)qy + r - P.idx_y0) / b);
