@@ -186,6 +186,12 @@ __device__ __forceinline__ int center_coord(int i, int cell, int limit)
 constexpr int kSortBuckets = 1024;
 __device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot);
 
+// Clears the counting-sort buckets; a barrier must lie between this and block_sort_pairs.
+__device__ __forceinline__ void block_sort_clear(int* hist)
+{
+    for (int b = threadIdx.x; b < kSortBuckets; b += kExpThreads) { hist[b] = 0; hist[kSortBuckets + 4 + b] = 0; }
+}
+
 template <int CAND>
 __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, unsigned long long* k2,
                                                  int* i2, int* hist, int n, double r2)
@@ -193,8 +199,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
     const int tid = threadIdx.x;
     int* start = hist;                       // [kSortBuckets + 1] after the scan
     int* cursor = hist + kSortBuckets + 4;   // [kSortBuckets]
-    for (int b = tid; b < kSortBuckets; b += kExpThreads) { start[b] = 0; cursor[b] = 0; }
-    lds_barrier();
+    // (the caller has cleared start[] and cursor[] -- block_sort_clear -- in front of a barrier it needs anyway)
     const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
     int myb[CAND / kExpThreads];
 #pragma unroll
@@ -258,9 +263,23 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
 
 // Exclusive scan of per-thread counts over the workgroup; returns the total.
 __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[kExpWaves]*/);
+// The same without the leading barrier: for a caller that has just passed one and whose wave_tot[] nobody reads any more.
 __device__ __forceinline__ int block_exclusive_scan_nosync(int v, int* my_offset, int* wave_tot)
 {
-    return block_exclusive_scan(v, my_offset, wave_tot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    lds_barrier();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kExpWaves; ++w) { if (w < wave) base += wave_tot[w]; tot += wave_tot[w]; }
+    *my_offset = base + inc - v;
+    return tot;
 }
 __device__ __forceinline__ int block_exclusive_scan(int v, int* my_offset, int* wave_tot /*LDS[kExpWaves]*/)
 {
@@ -480,6 +499,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         const int64_t t1 = P.cell_off[cell + 1];
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
+        block_sort_clear(hist);          // (for the sort behind the radius query: the barrier in between is the query's own)
         {   // (the counter sh_i[4] was cleared with the pop)
             const double r = (double)P.radius, b = P.idx_bucket;
             int bx0 = (int)floor(((double)qx - r - P.idx_x0) / b), bx1 = (int)floor(((double)qx + r - P.idx_x0) / b);
@@ -550,8 +570,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         } else {
             x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
                                     (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp);
+            // (nt > 0: the function's last chunk ends with a barrier behind its updates of keys[])
         }
-        lds_barrier();
+        if constexpr (F32) lds_barrier();
 
         EXP_STAMP(3);
         // ---- 4./5. accepted matches: neighbours and new results, in slot order ------------------
