@@ -550,6 +550,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         const int nq = sh_i[4];
         if (nq > CAND) { status = kExpCandFull; break; }
         EXP_STAMP(1);
+        // The cell's descriptor rows as MFMA B fragments (int8 round) are requested here: the sort touches no global
+        // memory, so the loads' latency passes under it (issued in front of the radius query they only delayed its
+        // own loads: vector-memory waits retire in order).
+        X1Frag<kExpThreads> pre_frag;
+        if constexpr (!F32) x1_load_bfrag<kExpThreads>(pre_frag, P.t_rows8, t0, (int)(t1 - t0), 0);
         // sort by (key bits, index): non-negative doubles order like their bit patterns
         block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq,
                                P.metric == 0 ? (double)P.radius * (double)P.radius : (double)P.radius);
@@ -569,7 +574,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (!ok) { status = kExpListFull; break; }
         } else {
             x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
-                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp);
+                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp, &pre_frag);
             // (nt > 0: the function's last chunk ends with a barrier behind its updates of keys[])
         }
         if constexpr (F32) lds_barrier();

@@ -32,6 +32,32 @@ __device__ __forceinline__ float x1_key_distance(unsigned hi, int tie_guard)
     return tie_guard ? __uint_as_float(hi) : sqrtf((float)hi);
 }
 
+// The stationary operand of one 128-column chunk of train rows: NB column blocks of 32 rows per wave, four
+// 32-byte K-steps each.  A caller that knows the cell long before it knows the query subset (K7: right after
+// the pop) loads chunk 0 ahead of time and hands it to x1_round_wsplit.
+template <int NT>
+struct X1Frag {
+    static constexpr int NB = 4 / ((NT / 64) / 4);
+    v4i v[NB][4];
+};
+
+template <int NT>
+__device__ __forceinline__ void x1_load_bfrag(X1Frag<NT>& f, gptr<const int8_t> t_rows8, int64_t t0, int nt, int cb0)
+{
+    constexpr int kGroups = (NT / 64) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int blk0 = (wave % kGroups) * X1Frag<NT>::NB;
+#pragma unroll
+    for (int j = 0; j < X1Frag<NT>::NB; ++j) {
+        const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (n < nt) f.v[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
+            else        f.v[j][c] = v4i{0, 0, 0, 0};
+        }
+    }
+}
+
 constexpr int kTbestWords = 128 + 4;       // 128 train rows of a chunk + the tie repair's two masks and its accumulator
 
 template <int SR, int NT = 256>
@@ -40,7 +66,8 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                                                 gptr<const int8_t> t_rows8, gptr<const int32_t> t_norm,
                                                 int64_t t0, int nt, char* smem, unsigned long long* qbest,
                                                 unsigned long long* tbest /* LDS [kTbestWords] */, int tie_guard,
-                                                long long* pt = nullptr, long long* ts = nullptr)
+                                                long long* pt = nullptr, long long* ts = nullptr,
+                                                const X1Frag<NT>* pre0 = nullptr /* chunk 0, loaded by the caller */)
 {
 #define X1_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
     constexpr int NW = NT / 64;                   // waves
@@ -65,16 +92,11 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
 
     for (int cb0 = 0; cb0 < nt; cb0 += 128) {
         if (tid < 128) tbest[tid] = ~0ull;
-        v4i bf[NB][4];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (n < nt) bf[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
-                else        bf[j][c] = v4i{0, 0, 0, 0};
-            }
-        }
+        static_assert(NB == X1Frag<NT>::NB, "fragment shape");
+        X1Frag<NT> fr;
+        if (pre0 != nullptr && cb0 == 0) fr = *pre0;
+        else x1_load_bfrag<NT>(fr, t_rows8, t0, nt, cb0);
+        v4i (&bf)[NB][4] = fr.v;
         TopTile top[NB];
         int thr[NB];
 #pragma unroll
