@@ -34,7 +34,7 @@ constexpr int kExpCand = 2048;            // radius-subset capacity per round (t
 constexpr int kExpCandBig = 4096;         // ... of the kernel a pair is re-run with when a round exceeds it (int8 banks)
 
 // Capacities of one kernel variant.  LDS: gather stage | keys/qbest u64[CAND] | cand i32[CAND] |
-// nkey u64[CAND] | tix i32[CAND] | hist | tbest.  The big variant pays for its 4096-row arrays with a
+// nkey u64[CAND] | tix i32[CAND] | hist | tbest | the cell's first 128 train rows (x1_stage_cell).  The big variant pays for its 4096-row arrays with a
 // 256-row gather stage (two gather steps for a typical round) and keeps almost no match positions in LDS.
 template <int CAND>
 struct ExpCfg {
@@ -43,7 +43,7 @@ struct ExpCfg {
     static constexpr int kSR = CAND <= 2048 ? 512 : 256;                     // query rows gathered per staging step
     static constexpr int kStageBytes = kSR * kDim + kSR / 32 * 256;
     static constexpr int kPosCap = (kStageBytes - CAND * 8) / 32;            // accepted matches whose positions are kept in LDS
-    static constexpr int kLdsBytes = kStageBytes + CAND * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + kTbestWords * 8;
+    static constexpr int kLdsBytes = kStageBytes + CAND * (8 + 8 + 4 + 4) + (2 * 1024 + 16) * 4 + kTbestWords * 8 + kCellStageBytes;
     // float32 route: candidate list of x1_round_f32 aliases the sort scratch (nkey + tix + hist), free during step 3
     static constexpr int kClistCap = (CAND * (8 + 4) + 2 * 1024 * 4) / 4;
     static_assert((1 << kSlotBits) >= CAND, "slot bits");
@@ -550,11 +550,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         const int nq = sh_i[4];
         if (nq > CAND) { status = kExpCandFull; break; }
         EXP_STAMP(1);
-        // The cell's descriptor rows as MFMA B fragments (int8 round) are requested here: the sort touches no global
-        // memory, so the loads' latency passes under it (issued in front of the radius query they only delayed its
-        // own loads: vector-memory waits retire in order).
-        X1Frag<kExpThreads> pre_frag;
-        if constexpr (!F32) x1_load_bfrag<kExpThreads>(pre_frag, P.t_rows8, t0, (int)(t1 - t0), 0);
+        // The cell's first 128 descriptor rows (int8 round: the MFMA B operand) go to LDS by DMA from here: the sort
+        // touches no global memory, so their latency passes under it and no register waits for them (issued in
+        // front of the radius query they only delayed its own loads -- vector-memory waits retire in order; loaded
+        // into registers here they were spilled across the sort, which put the wait into the sort).
+        char* const cell_lds = dyn_lds + C::kLdsBytes - kCellStageBytes;
+        if constexpr (!F32) { if (t1 > t0) x1_stage_cell<kExpThreads>(cell_lds, P.t_rows8, t0, (int)(t1 - t0)); }
         // sort by (key bits, index): non-negative doubles order like their bit patterns
         block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq,
                                P.metric == 0 ? (double)P.radius * (double)P.radius : (double)P.radius);
@@ -574,7 +575,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (!ok) { status = kExpListFull; break; }
         } else {
             x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
-                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp, &pre_frag);
+                                    (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp, cell_lds);
             // (nt > 0: the function's last chunk ends with a barrier behind its updates of keys[])
         }
         if constexpr (F32) lds_barrier();

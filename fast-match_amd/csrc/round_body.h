@@ -32,29 +32,24 @@ __device__ __forceinline__ float x1_key_distance(unsigned hi, int tie_guard)
     return tie_guard ? __uint_as_float(hi) : sqrtf((float)hi);
 }
 
-// The stationary operand of one 128-column chunk of train rows: NB column blocks of 32 rows per wave, four
-// 32-byte K-steps each.  A caller that knows the cell long before it knows the query subset (K7: right after
-// the pop) loads chunk 0 ahead of time and hands it to x1_round_wsplit.
-template <int NT>
-struct X1Frag {
-    static constexpr int NB = 4 / ((NT / 64) / 4);
-    v4i v[NB][4];
-};
+// The first 128-column chunk of a cell's train rows can be staged in LDS ahead of time by a caller that knows
+// the cell long before it knows the query subset (K7: while it sorts the radius subset): 16 KiB, the rows in the
+// swizzled layout of the query stages (the B fragments are read with the A fragments' pattern: row = lane & 31,
+// 16-byte chunk 2 c + h).  Rows past the cell repeat its last row; their columns are never looked at.
+constexpr int kCellStageBytes = 128 * kDim;
 
 template <int NT>
-__device__ __forceinline__ void x1_load_bfrag(X1Frag<NT>& f, gptr<const int8_t> t_rows8, int64_t t0, int nt, int cb0)
+__device__ __forceinline__ void x1_stage_cell(char* lds, gptr<const int8_t> t_rows8, int64_t t0, int nt)
 {
-    constexpr int kGroups = (NT / 64) / 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int blk0 = (wave % kGroups) * X1Frag<NT>::NB;
+    constexpr int kPieces = 16 / (NT / 64);           // 1-KiB pieces (8 rows) per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < X1Frag<NT>::NB; ++j) {
-        const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (n < nt) f.v[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
-            else        f.v[j][c] = v4i{0, 0, 0, 0};
-        }
+    for (int i = 0; i < kPieces; ++i) {
+        const int g = wave * kPieces + i;
+        const int row = g * 8 + (lane >> 3);
+        const int r = row < nt ? row : nt - 1;
+        gptr<const int8_t> src = t_rows8 + (size_t)(t0 + r) * kDim + 16 * ((lane & 7) ^ ((row >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((gptr<const void>)src, (__attribute__((address_space(3))) void*)(lds + g * 1024), 16, 0, 0);
     }
 }
 
@@ -67,7 +62,7 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                                                 int64_t t0, int nt, char* smem, unsigned long long* qbest,
                                                 unsigned long long* tbest /* LDS [kTbestWords] */, int tie_guard,
                                                 long long* pt = nullptr, long long* ts = nullptr,
-                                                const X1Frag<NT>* pre0 = nullptr /* chunk 0, loaded by the caller */)
+                                                const char* cell0 = nullptr /* LDS: chunk 0 staged by x1_stage_cell */)
 {
 #define X1_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
     constexpr int NW = NT / 64;                   // waves
@@ -92,11 +87,28 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
 
     for (int cb0 = 0; cb0 < nt; cb0 += 128) {
         if (tid < 128) tbest[tid] = ~0ull;
-        static_assert(NB == X1Frag<NT>::NB, "fragment shape");
-        X1Frag<NT> fr;
-        if (pre0 != nullptr && cb0 == 0) fr = *pre0;
-        else x1_load_bfrag<NT>(fr, t_rows8, t0, nt, cb0);
-        v4i (&bf)[NB][4] = fr.v;
+        v4i bf[NB][4];
+        if (cell0 != nullptr && cb0 == 0) {
+            // staged while the caller was busy elsewhere: the DMA is long done, the wait and the barrier (every
+            // wave's pieces) return at once
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    bf[j][c] = *(const v4i*)(cell0 + (32 * (blk0 + j)) * kDim + aoff[c]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n < nt) bf[j][c] = *(gptr<const v4i>)(t_rows8 + (size_t)(t0 + n) * kDim + 32 * c + 16 * h);
+                    else        bf[j][c] = v4i{0, 0, 0, 0};
+                }
+            }
+        }
         TopTile top[NB];
         int thr[NB];
 #pragma unroll
