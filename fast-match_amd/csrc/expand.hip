@@ -752,6 +752,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (sh_i[7]) { status = kExpTableFull; break; }
         EXP_STAMP(6);
     }
+    // (a round with an empty radius subset leaves its cell DMA un-awaited: nothing may be in flight towards this
+    // workgroup's LDS when it is given back)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
         P.result[0] = n_matches;
         P.result[1] = n_rounds;
