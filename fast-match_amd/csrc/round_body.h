@@ -88,16 +88,14 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
     for (int cb0 = 0; cb0 < nt; cb0 += 128) {
         if (tid < 128) tbest[tid] = ~0ull;
         v4i bf[NB][4];
-        if (cell0 != nullptr && cb0 == 0) {
-            // staged while the caller was busy elsewhere: the DMA is long done, the wait and the barrier (every
-            // wave's pieces) return at once
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
+        const bool staged = cell0 != nullptr && cb0 == 0;
+        if (staged) {
+            // staged in LDS while the caller was busy elsewhere; read below, behind the wait and the barrier of
+            // the first query stage (the cell's DMA is older than that stage's: it has landed when they return)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    bf[j][c] = *(const v4i*)(cell0 + (32 * (blk0 + j)) * kDim + aoff[c]);
+                for (int c = 0; c < 4; ++c) bf[j][c] = v4i{0, 0, 0, 0};
         } else {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -155,6 +153,13 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
+            if (staged && st == 0) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        bf[j][c] = *(const v4i*)(cell0 + (32 * (blk0 + j)) * kDim + aoff[c]);
+            }
             X1_STAMP(9);
             const int ntiles = min(SR / kTileRows, (nq - st * SR + kTileRows - 1) / kTileRows);
             for (int tt = tphase; tt < ntiles; tt += 4) {         // this wave's tiles, ascending
