@@ -1,0 +1,149 @@
+"""Time-boxed differential fuzz of the C-ABI operators and of fastmatch.match() against the oracle.
+Random shapes (1 row .. tens of thousands, ragged, duplicates, tie-range rows), integer and float32
+routes, random per-context options, random grid / radius / metric / threshold options of the
+expansion loop.  Stops at the first difference and prints the seed that reproduces it.
+
+    python tests/tools/gpu_fuzz.py [seconds] [seed]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import fastmatch_amd as fm
+from fastmatch_amd import synth, cache, fastmatch
+import oracle
+from oracle import fastmatch_oracle as fo
+from kat import far_banks
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+ctx = fm.Context(0)
+eq = lambda a, b: a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+counts = {}
+
+
+def size(rng, big):
+    k = rng.integers(0, 4)
+    return int([rng.integers(1, 8), rng.integers(1, 200), rng.integers(1, 3000), rng.integers(1, big)][k])
+
+
+def banks(rng):
+    nq, nt = size(rng, 30000), size(rng, 60000)
+    kind = rng.choice(["sift", "planted", "dups", "far", "nonint", "lowrange"])
+    if kind == "far":
+        Q, T = far_banks(nq, max(nt, 2), rng, int(rng.integers(1, 14)), int(rng.integers(1, 4)))
+    elif kind == "planted":
+        Q, T, _ = synth.planted_pair(nq, nt, int(rng.integers(1 << 30)))
+    else:
+        Q, T = synth.synth_sift(nq, rng), synth.synth_sift(nt, rng)
+    if kind == "dups" and nt > 1:                       # equal rows: index tie-breaks, self distance 0
+        for _ in range(int(rng.integers(1, 20))):
+            i, j = rng.integers(0, nt, 2)
+            T[i] = T[j]
+            Q[rng.integers(0, nq)] = T[j]
+    if kind == "lowrange":
+        Q, T = Q // 64, T // 64                          # many exact d2 ties
+    if kind == "nonint":
+        Q = (Q.astype(np.float32) + rng.uniform(-0.5, 0.5, Q.shape).astype(np.float32)) * np.float32(rng.choice([1.0, 1 / 512.0]))
+        T = (T.astype(np.float32) + rng.uniform(-0.5, 0.5, T.shape).astype(np.float32)) * np.float32(rng.choice([1.0, 1 / 512.0]))
+    elif rng.integers(0, 3) == 0:
+        Q, T = Q.astype(np.float32), T.astype(np.float32)   # integer valued float32: int8 route
+    return kind, Q, T
+
+
+def fuzz_operators(rng):
+    kind, Q, T = banks(rng)
+    for k, v in (("nsplit", int(rng.choice([0, 0, 1, 3, 8, 13]))), ("nbuf", int(rng.choice([0, 2, 3]))),
+                 ("coop", int(rng.integers(0, 2))), ("f32_filter", int(rng.choice([0, 0, 1, 2])))):
+        ctx.set_option(k, v)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    order = 1 if kind == "nonint" else 0                 # the device's fixed float32 accumulation order
+    what = rng.choice(["knn2", "xcheck", "accepted", "selfdist", "batch"])
+    tag = (what, kind, Q.shape[0], T.shape[0], str(Q.dtype))
+    if what == "knn2":
+        idx, d = ctx.knn2(qb, tb)
+        oi, od = oracle.bf_knn(Q, T, 2, order=order)
+        assert eq(idx, oi) and eq(d, od), tag
+    elif what == "xcheck":
+        for a, b, A, B in ((qb, tb, Q, T), (tb, qb, T, Q)):
+            t, x = ctx.xcheck1(a, b)
+            ot, ox = oracle.bf_xcheck1(A, B, order=order)
+            assert eq(t, ot) and eq(x, ox), tag
+    elif what == "selfdist":
+        assert eq(ctx.self_dist(qb), oracle.self_dist(Q, order=order)), tag
+    else:
+        sd = oracle.self_dist(Q, order=order)
+        qb.set_selfdist(sd)
+        tau = float(rng.choice([0.5, 0.7, 0.9, 1.0, 1.5, 1e9]))
+        ot, ox = oracle.bf_xcheck1(Q, T, order=order)
+        rows = np.nonzero(ot >= 0)[0]
+        ratio, passed = oracle.ratio_filter(ox[rows], sd, tau, qrows=rows)
+        exp = (rows[passed].astype(np.int32), ot[rows][passed].astype(np.int32), ox[rows][passed], ratio[passed])
+        if what == "accepted":
+            got = ctx.match_accepted(qb, tb, tau)
+        else:
+            n, cap = int(rng.integers(1, 5)), Q.shape[0]
+            outs = [(ctx.pinned_empty(cap, np.int32), ctx.pinned_empty(cap, np.int32), ctx.pinned_empty(cap, np.float32),
+                     ctx.pinned_empty(cap, np.float64)) for _ in range(n)]
+            cnts = [ctx.pinned_empty(1, np.int64) for _ in range(n)]
+            ctx.match_accepted_batch([(qb, tb)] * n, tau, outs, cnts)
+            ctx.sync()
+            k = int(rng.integers(0, n))
+            got = tuple(a[:int(cnts[k][0])] for a in outs[k])
+        for g, e in zip(got, exp):
+            assert eq(np.asarray(g), np.asarray(e)), tag
+    return tag
+
+
+def fuzz_match(rng):
+    w, h = int(rng.integers(120, 1100)), int(rng.integers(120, 1100))
+    n = int(rng.integers(20, 9000))
+    opts = {}
+    if rng.integers(0, 2):
+        opts["grid_size"] = (int(rng.integers(30, 120)), int(rng.integers(30, 120)))
+    if rng.integers(0, 2):
+        opts["grid_margin"] = int(rng.integers(0, 45))
+    if rng.integers(0, 2):
+        opts["radius"] = int(rng.integers(20, 160))
+    if rng.integers(0, 3) == 0:
+        opts["metric"] = str(rng.choice(["euclidean", "chebyshev", "manhattan"]))
+    seed = int(rng.integers(1 << 30))
+    q, t = synth.image_pair((w, h), n, seed, n_thumb=min(600, n))
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options=dict(opts, context=ctx))
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"],
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]},
+                   **({"metric": opts["metric"]} if "metric" in opts else {}))
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    stats = {}
+    get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4))))
+    oget = fo.o_match(oq, ot, dict(opts))
+    taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
+    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus)
+    if rng.integers(0, 2) and len(taus) > 1:
+        got_all = get(taus)
+    else:
+        got_all = [get(x) for x in taus]
+    for x, got in zip(taus, got_all):
+        exp = oget(x)
+        assert len(got) == len(exp), tag + (x, len(got), len(exp))
+        for (ia, da), (ib, db) in zip(got, exp):
+            assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"]), tag + (x,)
+    return tag
+
+
+t0, it = time.time(), 0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed0 + it)
+    fn = fuzz_match if it % 4 == 3 else fuzz_operators
+    try:
+        tag = fn(rng)
+    except Exception:
+        print("FUZZ FAILURE at seed %d (iteration %d of base %d): python tests/tools/gpu_fuzz.py 1 %d" % (seed0 + it, it, seed0, seed0 + it), flush=True)
+        raise
+    counts[tag[0]] = counts.get(tag[0], 0) + 1
+    it += 1
+print("fuzz ok: %d problems in %.0f s, base seed %d: %s" % (it, time.time() - t0, seed0, sorted(counts.items())))
