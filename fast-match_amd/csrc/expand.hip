@@ -155,6 +155,26 @@ __device__ __forceinline__ bool found_insert(gptr<unsigned long long> tab, long 
     return false;
 }
 
+// Duplicates inside one round's list of accepted matches, by a hash table in LDS: own[] = the entry that claimed a
+// slot (-1 = empty), mn[] = the lowest entry index of that slot's key.  All entries insert at once; entry k is a
+// duplicate of an earlier one iff mn[slot] != k after the barrier.  Equal keys probe the same sequence, so they meet
+// in the first slot one of them claimed, whatever the order of the claims: the result does not depend on the race.
+// No more than kDupMax entries (half the slots) may insert.
+constexpr int kDupSlots = 1024, kDupMax = 512;
+static_assert(4 * kDupSlots * 4 <= kCellStageBytes, "the four tables live in the train-cell stage, which is idle behind the cross-check");
+template <class SAME>
+__device__ __forceinline__ int dup_insert(int* own, int* mn, unsigned long long h, int k, SAME same_key)
+{
+    int p = (int)(h & (unsigned long long)(kDupSlots - 1));
+    for (;;) {
+        const int old = atomicCAS(&own[p], -1, k);
+        if (old == -1 || same_key(old)) break;
+        p = (p + 1) & (kDupSlots - 1);
+    }
+    atomicMin(&mn[p], k);
+    return p;
+}
+
 // Single-writer insert-if-absent in one probe sequence: 1 = inserted, 0 = was present, -1 = full.
 __device__ __forceinline__ int set_insert_new(gptr<unsigned long long> tab, long long cap, unsigned long long key)
 {
@@ -586,6 +606,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         //     nkey[k] = ratio bits  (k < na)
         const int ccx = center_coord(row, P.cell_w, P.width), ccy = center_coord(col, P.cell_h, P.height);
         double* const pos4 = (double*)(smem + CAND * 8);              // [C::kPosCap][4] behind rk[] (stage buffer)
+        int* const dup_tab = (int*)cell_lds;                          // push own | push min | emit own | emit min
+        for (int i = tid; i < kDupSlots; i += kExpThreads) {          // (the cell stage was consumed when the cross-check began)
+            const int v = ((i >> 8) & 1) ? INT32_MAX : -1;
+            ((v4i*)dup_tab)[i] = v4i{v, v, v, v};
+        }
         int na = 0;
         for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
             const int i = s0 + tid;
@@ -667,12 +692,22 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 rk[k] = k1;
             }
             lds_barrier();
-            // Earlier entries of this round with the same key win (lists are in slot order).  A round
-            // accepts some tens of matches; one thread per entry walking all earlier entries is a chain
-            // of dependent LDS reads as long as the list.  Instead every WAVE takes entries k and its
-            // lanes the earlier entries j: one pass of <= 64 comparisons per entry, flags in dupf[].
-            int* const dupf = hist;                                  // bit 0 push, bit 1 emit duplicate
-            {
+            // Earlier entries of this round with the same key win (lists are in slot order).
+            bool push = live && nk != ~0ull, emit = live && !known;
+            if (na <= kDupMax) {
+                // the usual case (one chunk): every entry looks its two keys up in the LDS tables (dup_insert)
+                int sp = -1, se = -1;
+                if (push) sp = dup_insert(dup_tab, dup_tab + kDupSlots, mix64(nk), k, [&](int j) { return keys[j] == nk; });
+                if (live) se = dup_insert(dup_tab + 2 * kDupSlots, dup_tab + 3 * kDupSlots, mix64(rbits ^ mix64(k1)), k,
+                                          [&](int j) { return rk[j] == k1 && nkey[j] == rbits; });
+                lds_barrier();
+                if (push && dup_tab[kDupSlots + sp] != k) push = false;
+                if (live && dup_tab[3 * kDupSlots + se] != k) emit = false;
+            } else {
+                // A long list: one thread per entry walking all earlier entries would be a chain of LDS reads as long
+                // as the list.  Every WAVE takes entries k and its lanes the earlier entries j: one pass of <= 64
+                // comparisons per entry, flags in dupf[].
+                int* const dupf = hist;                              // bit 0 push, bit 1 emit duplicate
                 const int kend = min(na, k0 + kExpThreads);
                 const int lane = tid & 63, wave = tid >> 6;
                 for (int kk = k0 + wave; kk < kend; kk += kExpWaves) {
@@ -685,13 +720,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     const int f = (__builtin_amdgcn_ballot_w64(dp) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(de) != 0ull ? 2 : 0);
                     if (lane == 0) dupf[kk - k0] = f;
                 }
-            }
-            lds_barrier();
-            bool push = live && nk != ~0ull, emit = live && !known;
-            if (live) {
-                const int f = dupf[k - k0];
-                if (f & 1) push = false;
-                if (f & 2) emit = false;
+                lds_barrier();
+                if (live) {
+                    const int f = dupf[k - k0];
+                    if (f & 1) push = false;
+                    if (f & 2) emit = false;
+                }
             }
             // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
             // chunks of kExpThreads accepted matches are pushed in reverse chunk order below
