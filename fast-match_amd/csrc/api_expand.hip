@@ -125,6 +125,12 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
         if (!(x >= 0.0) || !(y >= 0.0) || x / d->cell_w >= 65535.0 || y / d->cell_h >= 65535.0)
             return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: query position outside the 16-bit cell-key range");
     }
+    // the positions once more in the index's order: the radius query reads them beside the keypoint indices
+    std::vector<double> pos_ord((size_t)nq * 2);
+    for (int64_t j = 0; j < nq; ++j) {
+        pos_ord[2 * j] = d->query_pos[2 * (size_t)d->index_order[j]];
+        pos_ord[2 * j + 1] = d->query_pos[2 * (size_t)d->index_order[j] + 1];
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     fm_expand* ex = new (std::nothrow) fm_expand();
     if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
@@ -136,7 +142,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
     const size_t o_qpos = carve((size_t)nq * 16), o_order = carve((size_t)nq * 4), o_start = carve((size_t)(nb + 1) * 4);
-    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16);
+    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16), o_qord = carve((size_t)nq * 16);
     hipError_t e = hipMalloc(&ex->blob, off);
     if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
     char* b = (char*)ex->blob;
@@ -145,6 +151,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
         return bail(fail(ctx, FM_EDEVICE, std::string(#expr " failed: ") + hipGetErrorString(_e))); } } while (0)
     if (nq) ETRY(hipMemcpyAsync(b + o_qpos, d->query_pos, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
     if (nq) ETRY(hipMemcpyAsync(b + o_order, d->index_order, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nq) ETRY(hipMemcpyAsync(b + o_qord, pos_ord.data(), (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
     ETRY(hipMemcpyAsync(b + o_start, d->index_start, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     ETRY(hipMemcpyAsync(b + o_coff, d->cell_off, (size_t)(ncells + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (nt) ETRY(hipMemcpyAsync(b + o_tpos, d->target_pos, (size_t)nt * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -152,7 +159,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
 #undef ETRY
     ExpandPair& P = ex->dev;
     P.q_rows8 = d->query->rows8; P.q_norm = d->query->norm; P.q_selfdist = d->query->selfdist;
-    P.q_pos = (const double*)(b + o_qpos);
+    P.q_pos = (const double*)(b + o_qpos); P.q_pos_ord = (const double*)(b + o_qord);
     P.idx_order = (const int32_t*)(b + o_order); P.idx_start = (const int32_t*)(b + o_start);
     P.idx_bucket = d->index_bucket; P.idx_x0 = d->index_x0; P.idx_y0 = d->index_y0;
     P.idx_nbx = d->index_nbx; P.idx_nby = d->index_nby;

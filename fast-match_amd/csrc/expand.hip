@@ -383,7 +383,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     // the descriptor whose pointers are typed as global memory.
     const ExpandPair& M = pairs[blockIdx.x];
     struct View {
-        gptr<const int8_t> q_rows8; gptr<const int32_t> q_norm; gptr<const double> q_selfdist, q_pos;
+        gptr<const int8_t> q_rows8; gptr<const int32_t> q_norm; gptr<const double> q_selfdist, q_pos, q_pos_ord;
         gptr<const int32_t> idx_order, idx_start;
         double idx_bucket, idx_x0, idx_y0; int idx_nbx, idx_nby, metric;
         gptr<const int8_t> t_rows8; gptr<const int32_t> t_norm; gptr<const int64_t> cell_off; gptr<const double> t_pos;
@@ -396,7 +396,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<long long> result; int prof;
     } P;
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
-    P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos;
+    P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos; P.q_pos_ord = (gptr<const double>)M.q_pos_ord;
     P.idx_order = (gptr<const int32_t>)M.idx_order; P.idx_start = (gptr<const int32_t>)M.idx_start;
     P.idx_bucket = M.idx_bucket; P.idx_x0 = M.idx_x0; P.idx_y0 = M.idx_y0; P.idx_nbx = M.idx_nbx; P.idx_nby = M.idx_nby; P.metric = M.metric;
     P.t_rows8 = (gptr<const int8_t>)M.t_rows8; P.t_norm = (gptr<const int32_t>)M.t_norm;
@@ -549,8 +549,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         int base = rs[0], off = pre[0];
 #pragma unroll
                         for (int q = 1; q < 8; ++q) { base = (j == q) ? rs[q] : base; off = (j == q) ? pre[q] : off; }
-                        const int qi = P.idx_order[base + f - off];
-                        const double dx = P.q_pos[2 * qi] - (double)qx, dy = P.q_pos[2 * qi + 1] - (double)qy;
+                        // (the positions in index order: fetched beside the keypoint index, not behind it)
+                        const int io = base + f - off;
+                        const int qi = P.idx_order[io];
+                        const double dx = P.q_pos_ord[2 * io] - (double)qx, dy = P.q_pos_ord[2 * io + 1] - (double)qy;
                         // sort key and inclusion test of the pair's metric (BallTree(positions, metric), cache.pyx:276):
                         // squared Euclidean distance against r^2 (no fma: NumPy order), or |dx| + |dy| /
                         // max(|dx|, |dy|) against r

@@ -11,6 +11,7 @@ struct ExpandPair {
     const int32_t* q_norm;
     const double*  q_selfdist;
     const double*  q_pos;          // [nq][2]
+    const double*  q_pos_ord;      // [nq][2] the same positions in the position index's order (q_pos[idx_order[j]])
     const int32_t* idx_order;      // keypoints sorted by bucket
     const int32_t* idx_start;      // [nbx*nby + 1]
     double idx_bucket, idx_x0, idx_y0;
