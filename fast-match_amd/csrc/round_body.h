@@ -109,8 +109,13 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
         }
         TopTile top[NB];
         int thr[NB];
+        int tnorm[NB];                            // the merge's train-row norms: on their way from here
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { thr[j] = INT32_MIN; top[j].init(); }
+        for (int j = 0; j < NB; ++j) {
+            thr[j] = INT32_MIN; top[j].init();
+            const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
+            tnorm[j] = t_norm[t0 + (n < nt ? n : nt - 1)];
+        }
 
         for (int st = 0; st < nstages; ++st) {
             lds_barrier();                       // previous stage fully consumed
@@ -200,7 +205,7 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             const int ri = mine ? mi : oi;
             const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
             if (h == 0 && n < nt && ri >= 0) {
-                const unsigned d2 = (unsigned)(t_norm[t0 + n] + 1 - rh);
+                const unsigned d2 = (unsigned)(tnorm[j] + 1 - rh);
                 atomicMin(&tbest[32 * (blk0 + j) + (lane & 31)], ((unsigned long long)d2 << 32) | (unsigned)ri);
             }
         }
