@@ -613,66 +613,31 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             const int v = ((i >> 8) & 1) ? INT32_MAX : -1;
             ((v4i*)dup_tab)[i] = v4i{v, v, v, v};
         }
-        int na = 0;
-        for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
-            const int i = s0 + tid;
-            bool acc = false;
-            double ratio = 0.0, pq0 = 0, pq1 = 0, pt0 = 0, pt1 = 0;
-            int t_local = 0;
+        unsigned long long* rk = (unsigned long long*)smem;        // result keys (the stage buffer is free now)
+        int n_emit = 0, na = 0;
+        if (nq <= kExpThreads) {
+            // The usual size -- one thread per slot, nothing is compacted: slot order IS the order of the accepted list.
+            const int i = tid;
+            bool acc = false, known = false;
+            double ratio = 0.0, mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
+            unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
+            int qrow_idx = 0;
+            long long nslot = 0;
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
-                    // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
                     const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
-                    // the positions step (b) needs ride on the same memory round trip as the self distance
-                    const int qrow = cand[i];
-                    t_local = (int)(unsigned)qb;
-                    const double sd = P.q_selfdist[qrow];
-                    pq0 = P.q_pos[2 * qrow]; pq1 = P.q_pos[2 * qrow + 1];
-                    pt0 = P.t_pos[2 * (t0 + t_local)]; pt1 = P.t_pos[2 * (t0 + t_local) + 1];
+                    qrow_idx = cand[i];
+                    const int t_local = (int)(unsigned)qb;
+                    const double sd = P.q_selfdist[qrow_idx];
+                    mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
+                    px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
                     ratio = (double)d / sd;
                     acc = ratio < P.tau;
                 }
             }
-            int o, o_unused;
-            const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
-            // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
-            // those reads from these writes): entries na+o <= i never clobber unread ones
             if (acc) {
-                tix[na + o] = i | (t_local << C::kSlotBits);
-                nkey[na + o] = (unsigned long long)__double_as_longlong(ratio);
-                if (na + o < C::kPosCap) {               // (the stage buffer is free after the cross-check)
-                    double* pp = pos4 + 4 * (na + o);
-                    pp[0] = pq0; pp[1] = pq1; pp[2] = pt0; pp[3] = pt1;
-                }
-            }
-            na += cnt;
-        }
-        lds_barrier();
-        EXP_STAMP(4);
-        // (b) per accepted match: neighbour key + seen probe, result key + found probe.
-        //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
-        unsigned long long* rk = (unsigned long long*)smem;        // stage buffer is free now
-        int n_emit = 0;
-        for (int k0 = 0; k0 < na; k0 += kExpThreads) {
-            const int k = k0 + tid;
-            const bool live = k < na;
-            double mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
-            unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
-            int qrow_idx = 0;
-            bool known = false;
-            long long nslot = 0;
-            if (live) {
-                const int slot = tix[k] & ((1 << C::kSlotBits) - 1), t_local = tix[k] >> C::kSlotBits;
-                qrow_idx = cand[slot];
-                rbits = nkey[k];
-                if (k < C::kPosCap) {                    // fetched together with the self distances in (a)
-                    const double* pp = pos4 + 4 * k;
-                    mqx = pp[0]; mqy = pp[1]; px = pp[2]; py = pp[3];
-                } else {
-                    mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
-                    px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
-                }
+                rbits = (unsigned long long)__double_as_longlong(ratio);
                 const int xd = (int)px - ccx, yd = (int)py - ccy;          // Grid_Cache.get_neighbor
                 int ncol = col, nrow = row;
                 if (yd < xd && yd < -xd) ncol = col - 1;
@@ -685,88 +650,199 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     nk = pack4x16(blk(ny, P.cell_h), blk(nx, P.cell_w), blk(mqy, P.cell_h), blk(mqx, P.cell_w));
                 }
                 k1 = pack4x16((int)mqx, (int)mqy, (int)px, (int)py);
-                // two independent probes: would the neighbour be skipped when popped? is the
-                // result already in the list?
                 bool in_seen;
                 probe_both(P.seen, P.seen_cap, nk, P.found, P.found_cap, rbits, k1, &in_seen, &nslot, &known);
                 if (in_seen) nk = ~0ull;
-                keys[k] = nk;
-                rk[k] = k1;
+                keys[i] = nk;                 // (a thread reads and rewrites its own slot only)
+                rk[i] = k1;
+                nkey[i] = rbits;
             }
             lds_barrier();
-            // Earlier entries of this round with the same key win (lists are in slot order).
-            bool push = live && nk != ~0ull, emit = live && !known;
-            if (na <= kDupMax) {
-                // the usual case (one chunk): every entry looks its two keys up in the LDS tables (dup_insert)
-                int sp = -1, se = -1;
-                if (push) sp = dup_insert(dup_tab, dup_tab + kDupSlots, mix64(nk), k, [&](int j) { return keys[j] == nk; });
-                if (live) se = dup_insert(dup_tab + 2 * kDupSlots, dup_tab + 3 * kDupSlots, mix64(rbits ^ mix64(k1)), k,
-                                          [&](int j) { return rk[j] == k1 && nkey[j] == rbits; });
-                lds_barrier();
-                if (push && dup_tab[kDupSlots + sp] != k) push = false;
-                if (live && dup_tab[3 * kDupSlots + se] != k) emit = false;
-            } else {
-                // A long list: one thread per entry walking all earlier entries would be a chain of LDS reads as long
-                // as the list.  Every WAVE takes entries k and its lanes the earlier entries j: one pass of <= 64
-                // comparisons per entry, flags in dupf[].
-                int* const dupf = hist;                              // bit 0 push, bit 1 emit duplicate
-                const int kend = min(na, k0 + kExpThreads);
-                const int lane = tid & 63, wave = tid >> 6;
-                for (int kk = k0 + wave; kk < kend; kk += kExpWaves) {
-                    const unsigned long long a_nk = keys[kk], a_rk = rk[kk], a_rb = nkey[kk];
-                    bool dp = false, de = false;
-                    for (int j = lane; j < kk; j += 64) {
-                        dp |= a_nk != ~0ull && keys[j] == a_nk;
-                        de |= rk[j] == a_rk && nkey[j] == a_rb;
-                    }
-                    const int f = (__builtin_amdgcn_ballot_w64(dp) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(de) != 0ull ? 2 : 0);
-                    if (lane == 0) dupf[kk - k0] = f;
-                }
-                lds_barrier();
-                if (live) {
-                    const int f = dupf[k - k0];
-                    if (f & 1) push = false;
-                    if (f & 2) emit = false;
-                }
-            }
-            // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
-            // chunks of kExpThreads accepted matches are pushed in reverse chunk order below
-            // one scan for both ranks: pushes in the low half-word, emits in the high one (<= kExpThreads each)
+            bool push = acc && nk != ~0ull, emit = acc && !known;
+            int sp = -1, se = -1;
+            if (push) sp = dup_insert(dup_tab, dup_tab + kDupSlots, mix64(nk), i, [&](int j) { return keys[j] == nk; });
+            if (acc) se = dup_insert(dup_tab + 2 * kDupSlots, dup_tab + 3 * kDupSlots, mix64(rbits ^ mix64(k1)), i,
+                                     [&](int j) { return rk[j] == k1 && nkey[j] == rbits; });
+            lds_barrier();
+            if (push && dup_tab[kDupSlots + sp] != i) push = false;
+            if (acc && dup_tab[3 * kDupSlots + se] != i) emit = false;
             int po, eo;
             const int petot = block_rank_flags(push, emit, &po, &eo, wave_cnt, rank_toggle);
             const int ptot = petot & 0xffff, etot = petot >> 16;
-            // (every thread holds the same totals and counters and sh_top is stable here: no flag, no barrier)
             if (sh_top + ptot > P.stack_cap) { status = kExpStackFull; break; }
-            if (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) { status = kExpMatchFull; break; }
-            if (push) {
-                // The first accepted match must be popped first, i.e. sit on top.  One chunk
-                // (na <= kExpThreads, the usual case): write in reverse rank order.  More: chunks are
-                // written in ascending order and the whole region is reversed afterwards.
-                const long long dst = (na <= kExpThreads) ? sh_top + (ptot - 1 - po) : sh_top + po;
+            if (n_matches + etot > P.match_cap || 2 * (n_matches + etot) > P.found_cap) { status = kExpMatchFull; break; }
+            if (push) {                        // the first accepted match is popped first: reverse rank order
+                const long long dst = sh_top + (ptot - 1 - po);
                 P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
                 P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
-                if (na <= kExpThreads && po == 0) {            // this entry ends up on top: cache it for the next pop
+                if (po == 0) {                 // this entry ends up on top: cache it for the next pop
                     nxt_e[0] = mqx; nxt_e[1] = mqy; nxt_e[2] = nx; nxt_e[3] = ny;
                     nxt_key = nk; nxt_slot = nslot; nxt_valid = 1;
                 }
             }
             if (emit) {
-                const long long dst = n_matches + n_emit + eo;
+                const long long dst = n_matches + eo;
                 P.m_index[dst] = qrow_idx;
                 P.m_pos[dst * 4 + 0] = mqx; P.m_pos[dst * 4 + 1] = mqy;
                 P.m_pos[dst * 4 + 2] = px;  P.m_pos[dst * 4 + 3] = py;
-                P.m_ratio[dst] = __longlong_as_double((long long)rbits);
+                P.m_ratio[dst] = ratio;
                 if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
             }
-            n_emit += etot;
-            if (na <= kExpThreads) {
-                // the only chunk of the round (the usual case): thread 0 rewrites sh_top from its own `top` at
-                // the next pop, and the round ends with a full barrier -- none needed here
-                if (tid == 0) top += ptot;
-            } else {
+            n_emit = etot;
+            if (tid == 0) top += ptot;         // (sh_top is rewritten from `top` at the next pop)
+        } else {
+            for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
+                const int i = s0 + tid;
+                bool acc = false;
+                double ratio = 0.0, pq0 = 0, pq1 = 0, pt0 = 0, pt1 = 0;
+                int t_local = 0;
+                if (i < nq) {
+                    const unsigned long long qb = keys[i];
+                    if (qb != ~0ull) {
+                        // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
+                        const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
+                        // the positions step (b) needs ride on the same memory round trip as the self distance
+                        const int qrow = cand[i];
+                        t_local = (int)(unsigned)qb;
+                        const double sd = P.q_selfdist[qrow];
+                        pq0 = P.q_pos[2 * qrow]; pq1 = P.q_pos[2 * qrow + 1];
+                        pt0 = P.t_pos[2 * (t0 + t_local)]; pt1 = P.t_pos[2 * (t0 + t_local) + 1];
+                        ratio = (double)d / sd;
+                        acc = ratio < P.tau;
+                    }
+                }
+                int o, o_unused;
+                const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
+                // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
+                // those reads from these writes): entries na+o <= i never clobber unread ones
+                if (acc) {
+                    tix[na + o] = i | (t_local << C::kSlotBits);
+                    nkey[na + o] = (unsigned long long)__double_as_longlong(ratio);
+                    if (na + o < C::kPosCap) {               // (the stage buffer is free after the cross-check)
+                        double* pp = pos4 + 4 * (na + o);
+                        pp[0] = pq0; pp[1] = pq1; pp[2] = pt0; pp[3] = pt1;
+                    }
+                }
+                na += cnt;
+            }
+            lds_barrier();
+            EXP_STAMP(4);
+            // (b) per accepted match: neighbour key + seen probe, result key + found probe.
+            //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
+            for (int k0 = 0; k0 < na; k0 += kExpThreads) {
+                const int k = k0 + tid;
+                const bool live = k < na;
+                double mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
+                unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
+                int qrow_idx = 0;
+                bool known = false;
+                long long nslot = 0;
+                if (live) {
+                    const int slot = tix[k] & ((1 << C::kSlotBits) - 1), t_local = tix[k] >> C::kSlotBits;
+                    qrow_idx = cand[slot];
+                    rbits = nkey[k];
+                    if (k < C::kPosCap) {                    // fetched together with the self distances in (a)
+                        const double* pp = pos4 + 4 * k;
+                        mqx = pp[0]; mqy = pp[1]; px = pp[2]; py = pp[3];
+                    } else {
+                        mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
+                        px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
+                    }
+                    const int xd = (int)px - ccx, yd = (int)py - ccy;          // Grid_Cache.get_neighbor
+                    int ncol = col, nrow = row;
+                    if (yd < xd && yd < -xd) ncol = col - 1;
+                    else if (xd > yd) nrow = row + 1;
+                    else if (yd > -xd) ncol = col + 1;
+                    else nrow = row - 1;
+                    if (ncol >= 0 && ncol < P.cols && nrow >= 0 && nrow < P.rows) {
+                        nx = (double)center_coord(nrow, P.cell_w, P.width);
+                        ny = (double)center_coord(ncol, P.cell_h, P.height);
+                        nk = pack4x16(blk(ny, P.cell_h), blk(nx, P.cell_w), blk(mqy, P.cell_h), blk(mqx, P.cell_w));
+                    }
+                    k1 = pack4x16((int)mqx, (int)mqy, (int)px, (int)py);
+                    // two independent probes: would the neighbour be skipped when popped? is the
+                    // result already in the list?
+                    bool in_seen;
+                    probe_both(P.seen, P.seen_cap, nk, P.found, P.found_cap, rbits, k1, &in_seen, &nslot, &known);
+                    if (in_seen) nk = ~0ull;
+                    keys[k] = nk;
+                    rk[k] = k1;
+                }
                 lds_barrier();
-                if (tid == 0) { sh_top += ptot; top += ptot; }
-                lds_barrier();
+                // Earlier entries of this round with the same key win (lists are in slot order).
+                bool push = live && nk != ~0ull, emit = live && !known;
+                if (na <= kDupMax) {
+                    // the usual case (one chunk): every entry looks its two keys up in the LDS tables (dup_insert)
+                    int sp = -1, se = -1;
+                    if (push) sp = dup_insert(dup_tab, dup_tab + kDupSlots, mix64(nk), k, [&](int j) { return keys[j] == nk; });
+                    if (live) se = dup_insert(dup_tab + 2 * kDupSlots, dup_tab + 3 * kDupSlots, mix64(rbits ^ mix64(k1)), k,
+                                              [&](int j) { return rk[j] == k1 && nkey[j] == rbits; });
+                    lds_barrier();
+                    if (push && dup_tab[kDupSlots + sp] != k) push = false;
+                    if (live && dup_tab[3 * kDupSlots + se] != k) emit = false;
+                } else {
+                    // A long list: one thread per entry walking all earlier entries would be a chain of LDS reads as long
+                    // as the list.  Every WAVE takes entries k and its lanes the earlier entries j: one pass of <= 64
+                    // comparisons per entry, flags in dupf[].
+                    int* const dupf = hist;                              // bit 0 push, bit 1 emit duplicate
+                    const int kend = min(na, k0 + kExpThreads);
+                    const int lane = tid & 63, wave = tid >> 6;
+                    for (int kk = k0 + wave; kk < kend; kk += kExpWaves) {
+                        const unsigned long long a_nk = keys[kk], a_rk = rk[kk], a_rb = nkey[kk];
+                        bool dp = false, de = false;
+                        for (int j = lane; j < kk; j += 64) {
+                            dp |= a_nk != ~0ull && keys[j] == a_nk;
+                            de |= rk[j] == a_rk && nkey[j] == a_rb;
+                        }
+                        const int f = (__builtin_amdgcn_ballot_w64(dp) != 0ull ? 1 : 0) | (__builtin_amdgcn_ballot_w64(de) != 0ull ? 2 : 0);
+                        if (lane == 0) dupf[kk - k0] = f;
+                    }
+                    lds_barrier();
+                    if (live) {
+                        const int f = dupf[k - k0];
+                        if (f & 1) push = false;
+                        if (f & 2) emit = false;
+                    }
+                }
+                // stack push, first accepted match on top: entry of rank r goes to top + (total-1-r);
+                // chunks of kExpThreads accepted matches are pushed in reverse chunk order below
+                // one scan for both ranks: pushes in the low half-word, emits in the high one (<= kExpThreads each)
+                int po, eo;
+                const int petot = block_rank_flags(push, emit, &po, &eo, wave_cnt, rank_toggle);
+                const int ptot = petot & 0xffff, etot = petot >> 16;
+                // (every thread holds the same totals and counters and sh_top is stable here: no flag, no barrier)
+                if (sh_top + ptot > P.stack_cap) { status = kExpStackFull; break; }
+                if (n_matches + n_emit + etot > P.match_cap || 2 * (n_matches + n_emit + etot) > P.found_cap) { status = kExpMatchFull; break; }
+                if (push) {
+                    // The first accepted match must be popped first, i.e. sit on top.  One chunk
+                    // (na <= kExpThreads, the usual case): write in reverse rank order.  More: chunks are
+                    // written in ascending order and the whole region is reversed afterwards.
+                    const long long dst = (na <= kExpThreads) ? sh_top + (ptot - 1 - po) : sh_top + po;
+                    P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
+                    P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
+                    if (na <= kExpThreads && po == 0) {            // this entry ends up on top: cache it for the next pop
+                        nxt_e[0] = mqx; nxt_e[1] = mqy; nxt_e[2] = nx; nxt_e[3] = ny;
+                        nxt_key = nk; nxt_slot = nslot; nxt_valid = 1;
+                    }
+                }
+                if (emit) {
+                    const long long dst = n_matches + n_emit + eo;
+                    P.m_index[dst] = qrow_idx;
+                    P.m_pos[dst * 4 + 0] = mqx; P.m_pos[dst * 4 + 1] = mqy;
+                    P.m_pos[dst * 4 + 2] = px;  P.m_pos[dst * 4 + 3] = py;
+                    P.m_ratio[dst] = __longlong_as_double((long long)rbits);
+                    if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
+                }
+                n_emit += etot;
+                if (na <= kExpThreads) {
+                    // the only chunk of the round (the usual case): thread 0 rewrites sh_top from its own `top` at
+                    // the next pop, and the round ends with a full barrier -- none needed here
+                    if (tid == 0) top += ptot;
+                } else {
+                    lds_barrier();
+                    if (tid == 0) { sh_top += ptot; top += ptot; }
+                    lds_barrier();
+                }
             }
         }
         if (status != kExpOk) break;
