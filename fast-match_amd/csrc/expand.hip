@@ -417,8 +417,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     long long n_matches = 0, n_rounds = 0, n_pairs = 0;
     long long seen_n = 0;
     int status = kExpOk;
-    long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tstamp = P.prof ? wall_clock64() : 0;
+    // phase timers (expand_prof): thread 0's alone, kept in LDS so that they hold no registers; pt[12] = the last stamp
+    __shared__ long long pt[13];
+    long long& tstamp = pt[12];
+    if (tid == 0) { for (int k = 0; k < 12; ++k) pt[k] = 0; tstamp = P.prof ? wall_clock64() : 0; }
 #define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
 
     for (;;) {

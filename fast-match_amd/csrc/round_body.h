@@ -172,6 +172,9 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
 #pragma unroll
                 for (int c = 0; c < 4; ++c) af[c] = *(const v4i*)(smem + tt * (kTileRows * kDim) + aoff[c]);
                 const v16i ci = lds_read16(smem + xoff + tt * (kAuxPerTile * 4));
+                // the exact path's low words, unconditionally and with the operands: in a round's few tiles nearly every
+                // block takes that path, and each visit otherwise waits for an LDS round trip of its own
+                const v16i low = lds_read16(smem + xoff + tt * (kAuxPerTile * 4) + 128);
                 v16i acc[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bf[j][0], ci, 0, 0, 0);
@@ -184,7 +187,6 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
                 for (int j = 0; j < NB; ++j) {
                     const int tmax = max16(acc[j]);
                     if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                        const v16i low = lds_read16(smem + xoff + tt * (kAuxPerTile * 4) + 128);
                         top[j].update(acc[j], low, st * (SR / kTileRows) + tt);
                         thr[j] = top[j].own_threshold();
                     }

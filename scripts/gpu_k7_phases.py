@@ -10,6 +10,10 @@ fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_p
 st = {}
 get = fastmatch.match(mc, fi, {"context": ctx, "stats": st})
 get(0.7)
+for rep in range(3):                       # un-instrumented first: the timers themselves cost ~0.2 us per round
+    st.clear(); ctx.reset_stats()
+    get(0.7)
+    print("no timers: rounds", st["rounds"], "us/round %.2f" % (ctx.stats()["kernel_ms"] * 1e3 / st["rounds"]))
 ctx.set_option("expand_prof", 1)
 st.clear(); ctx.reset_stats()
 t0 = time.perf_counter(); m = get(0.7); w = time.perf_counter() - t0
