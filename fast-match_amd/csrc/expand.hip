@@ -34,7 +34,8 @@ constexpr int kExpCand = 2048;            // radius-subset capacity per round (t
 constexpr int kExpCandBig = 4096;         // ... of the kernel a pair is re-run with when a round exceeds it (int8 banks)
 
 // Capacities of one kernel variant.  LDS: gather stage | keys/qbest u64[CAND] | cand i32[CAND] |
-// nkey u64[CAND] | tix i32[CAND] | hist | tbest | the cell's first 128 train rows (x1_stage_cell).  The big variant pays for its 4096-row arrays with a
+// nkey u64[CAND] | tix i32[CAND] | hist | tbest | the cell's first 128 train rows (x1_stage_cell; behind the cross-check the
+// same 16 KiB hold the duplicate tables of steps 4/5, dup_insert).  The big variant pays for its 4096-row arrays with a
 // 256-row gather stage (two gather steps for a typical round) and keeps almost no match positions in LDS.
 template <int CAND>
 struct ExpCfg {
