@@ -1,0 +1,18 @@
+"""GPU: a fixed slice of the differential fuzz (tests/tools/gpu_fuzz.py) as a regression test -- random banks through
+every operator and random image pairs through fastmatch.match(), each against the oracle.  The seeds are fixed, so a
+failure names a reproducible problem; the tool itself runs open-ended with fresh seeds."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed0", [1000, 777000, 20261003])
+def test_fixed_fuzz_slice_equals_oracle(ctx, seed0):
+    import gpu_fuzz
+    n, counts = gpu_fuzz.run(budget=120.0, seed0=seed0, max_problems=24, context=ctx)
+    assert n == 24 and counts.get("match", 0) == 6 and len(counts) >= 4

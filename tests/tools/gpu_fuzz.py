@@ -15,11 +15,8 @@ import oracle
 from oracle import fastmatch_oracle as fo
 from kat import far_banks
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-ctx = fm.Context(0)
+ctx = None                      # set by run()
 eq = lambda a, b: a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
-counts = {}
 
 
 def size(rng, big):
@@ -135,15 +132,35 @@ def fuzz_match(rng):
     return tag
 
 
-t0, it = time.time(), 0
-while time.time() - t0 < budget:
-    rng = np.random.default_rng(seed0 + it)
-    fn = fuzz_match if it % 4 == 3 else fuzz_operators
+def run(budget, seed0, max_problems=None, context=None):
+    """Random problems seed0, seed0 + 1, ... until the time budget or the problem count is used up.
+    Returns (problems, counts by kind); raises AssertionError at the first difference."""
+    global ctx
+    ctx = context if context is not None else fm.Context(0)
+    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter")}
+    counts = {}
+    t0, it = time.time(), 0
     try:
-        tag = fn(rng)
-    except Exception:
-        print("FUZZ FAILURE at seed %d (iteration %d of base %d): python tests/tools/gpu_fuzz.py 1 %d" % (seed0 + it, it, seed0, seed0 + it), flush=True)
-        raise
-    counts[tag[0]] = counts.get(tag[0], 0) + 1
-    it += 1
-print("fuzz ok: %d problems in %.0f s, base seed %d: %s" % (it, time.time() - t0, seed0, sorted(counts.items())))
+        while time.time() - t0 < budget and (max_problems is None or it < max_problems):
+            rng = np.random.default_rng(seed0 + it)
+            fn = fuzz_match if it % 4 == 3 else fuzz_operators
+            try:
+                tag = fn(rng)
+            except Exception:
+                print("FUZZ FAILURE at seed %d (iteration %d of base %d): python tests/tools/gpu_fuzz.py 1 %d"
+                      % (seed0 + it, it, seed0, seed0 + it), flush=True)
+                raise
+            counts[str(tag[0])] = counts.get(str(tag[0]), 0) + 1
+            it += 1
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+    return it, counts
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    t0 = time.time()
+    n, counts = run(budget, seed0)
+    print("fuzz ok: %d problems in %.0f s, base seed %d: %s" % (n, time.time() - t0, seed0, sorted(counts.items())))
