@@ -108,11 +108,10 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
             }
         }
         TopTile top[NB];
-        int thr[NB];
         int tnorm[NB];                            // the merge's train-row norms: on their way from here
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            thr[j] = INT32_MIN; top[j].init();
+            top[j].init();
             const int n = cb0 + 32 * (blk0 + j) + (lane & 31);
             tnorm[j] = t_norm[t0 + (n < nt ? n : nt - 1)];
         }
@@ -183,14 +182,11 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[c], bf[j][c], acc[j], 0, 0, 0);
+                // No threshold test in front of the update (the dense kernel's fast path): a wave sees a handful of
+                // tiles per chunk, and one of its 64 lanes improves its best in nearly every one of them (the k-th tile
+                // of a lane does with probability 1/k) -- the test only added its nine instructions to every visit.
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int tmax = max16(acc[j]);
-                    if (__builtin_amdgcn_ballot_w64(tmax >= thr[j]) != 0ull) {
-                        top[j].update(acc[j], low, st * (SR / kTileRows) + tt);
-                        thr[j] = top[j].own_threshold();
-                    }
-                }
+                for (int j = 0; j < NB; ++j) top[j].update(acc[j], low, st * (SR / kTileRows) + tt);
             }
         }
         X1_STAMP(10);
