@@ -26,7 +26,6 @@ import struct
 
 import numpy as np
 
-from . import _ffi
 from . import matchutil
 
 

@@ -138,7 +138,6 @@ def xcheck1_sharded(ctx, qbank, tbank_shard, t_offset, device=None, group=None):
     """Cross-checked 1-NN of the (replicated) query bank against a train set whose rows are
     split over the ranks (this rank holds rows [t_offset, t_offset + tbank_shard.n)).
     Every rank returns the full (tidx, dist) of the unsharded fm_xcheck1, bit for bit."""
-    from . import _ffi
     on_gpu = device is not None and not (isinstance(device, str) and device == "cpu")
     if on_gpu:                                  # keys stay in HBM from the election to the collective
         import torch
