@@ -29,6 +29,15 @@ class fm_stats(ctypes.Structure):
                 ("calls", ctypes.c_int64)]
 
 
+class fm_stats_ex(ctypes.Structure):
+    _fields_ = [("struct_bytes", ctypes.c_int64), ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+                ("kernel_launches", ctypes.c_int64), ("pairs", ctypes.c_int64), ("calls", ctypes.c_int64),
+                ("bytes_moved", ctypes.c_int64)]
+
+
+FM_ABI_VERSION = 4          # include/fastmatch_hip.h: the revision this binding was written against
+
+
 class fm_expand_desc(ctypes.Structure):
     _fields_ = [("query", ctypes.c_void_p), ("query_pos", ctypes.c_void_p),
                 ("index_bucket", ctypes.c_double), ("index_x0", ctypes.c_double), ("index_y0", ctypes.c_double),
@@ -57,7 +66,9 @@ SYMBOLS = {
     "fm_ctx_get_option": (_INT, [_P, ctypes.c_char_p, ctypes.POINTER(_I64)]),
     "fm_last_error": (ctypes.c_char_p, [_P]),
     "fm_sync": (_INT, [_P]),
+    "fm_abi_version": (_INT, []),
     "fm_get_stats": (_INT, [_P, ctypes.POINTER(fm_stats)]),
+    "fm_get_stats_ex": (_INT, [_P, ctypes.POINTER(fm_stats_ex), _I64]),
     "fm_reset_stats": (_INT, [_P]),
     "fm_device_name": (_INT, [_P, ctypes.c_char_p, _INT]),
     "fm_f32_filter_stats": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
@@ -69,6 +80,9 @@ SYMBOLS = {
     "fm_bank_destroy": (_INT, [_P, _P]),
     "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
+    "fm_bank_refill_u8_async": (_INT, [_P, _P, _P, _I64]),
+    "fm_upload_fence": (_INT, [_P]),
+    "fm_self_dist_batch": (_INT, [_P, ctypes.c_int32, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
     "fm_xcheck1_keys": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_xcheck1_keys_dev": (_INT, [_P, _P, _P, _I64, _P]),
@@ -140,6 +154,9 @@ def load_library():
             fn = getattr(lib, name)     # AttributeError here = ABI drift, fail loudly
             fn.restype = res
             fn.argtypes = args
+        if lib.fm_abi_version() != FM_ABI_VERSION:
+            raise FastMatchHipError("%s has ABI revision %d, this binding was written for %d: rebuild the library"
+                                    % (LIB_PATH, lib.fm_abi_version(), FM_ABI_VERSION))
         _lib = lib
         return lib
 
@@ -188,6 +205,19 @@ class Bank(object):
             raise ValueError("selfdist must have shape (%d,)" % self.n)
         self.ctx._check(self.ctx.lib.fm_bank_set_selfdist(self.ctx.handle, self.handle, _ptr(sd)))
         self.has_selfdist = True
+
+    def refill_async(self, rows):
+        """A new image's uint8 descriptors into this bank without allocation or host synchronisation
+        (``fm_bank_refill_u8_async``): ``rows`` = [n, dim] uint8 from ``Context.pinned_empty`` with n within the
+        bank's first size.  Nothing enqueued earlier may still read the bank; call ``Context.upload_fence()``
+        before the first use, and recompute the self distances (``Context.self_dist_batch``)."""
+        a = np.asarray(rows)
+        if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != self.dim or not a.flags.c_contiguous:
+            raise ValueError("rows must be a contiguous [n, %d] uint8 array" % self.dim)
+        self.ctx._check(self.ctx.lib.fm_bank_refill_u8_async(self.ctx.handle, self.handle, _ptr(a), a.shape[0]))
+        self.n = a.shape[0]
+        self.has_selfdist = False
+        self._refill_src = a          # (the copy is asynchronous: keep the source alive)
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
@@ -286,7 +316,7 @@ class Context(object):
     def set_option(self, name, value):
         """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
         "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
-        "async_time_every", "expand_big", "expand_grow", "expand_prof".  Results never depend on them."""
+        "async_time_every", "k1_order", "expand_big", "expand_grow", "expand_prof".  Results never depend on them."""
         self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def get_option(self, name):
@@ -341,6 +371,25 @@ class Context(object):
         out = np.empty(bank.n, dtype=np.float64)
         self._check(self.lib.fm_self_dist(self.handle, bank.handle, _ptr(out)))
         return out
+
+    def self_dist_batch(self, banks, want_host=True):
+        """Metric_Cache builds of several images in one call (``fm_self_dist_batch``): the self distances of
+        every bank, attached to it on the device; banks of one size share a distance-kernel launch.
+        ``want_host``: also return them (list of float64 arrays; synchronous); False = enqueue only."""
+        n = len(banks)
+        if n == 0:
+            return []
+        hs = (_P * n)(*[b.handle for b in banks])
+        outs = [np.empty(b.n, dtype=np.float64) for b in banks] if want_host else None
+        op = (_P * n)(*[_P(o.ctypes.data) if o.shape[0] else None for o in outs]) if want_host else None
+        self._check(self.lib.fm_self_dist_batch(self.handle, n, hs, op))
+        for b in banks:
+            b.has_selfdist = True
+        return outs
+
+    def upload_fence(self):
+        """Later calls on this context wait (on the device) for the refills enqueued so far."""
+        self._check(self.lib.fm_upload_fence(self.handle))
 
     def xcheck1(self, q, t):
         tidx = np.empty(q.n, dtype=np.int32)
@@ -600,10 +649,10 @@ class Context(object):
 
     # -- bookkeeping ---------------------------------------------------------------------
     def stats(self):
-        s = fm_stats()
-        self._check(self.lib.fm_get_stats(self.handle, ctypes.byref(s)))
+        s = fm_stats_ex()
+        self._check(self.lib.fm_get_stats_ex(self.handle, ctypes.byref(s), ctypes.sizeof(s)))
         return {"kernel_ms": s.kernel_ms, "total_ms": s.total_ms, "kernel_launches": s.kernel_launches,
-                "pairs": s.pairs, "calls": s.calls}
+                "pairs": s.pairs, "calls": s.calls, "bytes_moved": s.bytes_moved}
 
     def reset_stats(self):
         self._check(self.lib.fm_reset_stats(self.handle))

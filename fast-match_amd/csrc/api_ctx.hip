@@ -240,6 +240,7 @@ static const OptionDef kOptions[] = {
     {"f32_lpc", &Tuning::f32_lpc, 0, 64, "FM_F32_LPC"},
     {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
+    {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"},
     {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
 };
 
@@ -351,6 +352,8 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     for (auto& m : ctx->marks) for (hipEvent_t ev : m.ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->aslot) free_slot(sl);
     for (auto& sl : ctx->bslot) free_slot(sl);
+    if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);
     for (hipEvent_t ev : ctx->ev_tail_end) if (ev) (void)hipEventDestroy(ev);
     if (ctx->comm) { comm_destroy(ctx->comm); ctx->comm = nullptr; }      // (before the streams it was used on)
@@ -386,6 +389,7 @@ int fm::drain_pending(fm_ctx* ctx)
                 ctx->stats.kernel_ms += ms;
                 ctx->stats.kernel_launches += 1;
                 ctx->stats.pairs += t.pairs;
+                ctx->stats_bytes += t.bytes;
             } else (void)hipGetLastError();
         }
         ctx->timer_pool.push_back(t);
@@ -398,6 +402,7 @@ extern "C" int fm_sync(fm_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_sync: ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->upload) HIP_TRY(ctx, hipStreamSynchronize(ctx->upload));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t ts : ctx->tails) HIP_TRY(ctx, hipStreamSynchronize(ts));
     return drain_pending(ctx);
@@ -446,10 +451,28 @@ extern "C" int fm_get_stats(fm_ctx* ctx, fm_stats* out)
     return FM_OK;
 }
 
+extern "C" int fm_get_stats_ex(fm_ctx* ctx, fm_stats_ex* out, int64_t out_bytes)
+{
+    if (!ctx || !out || out_bytes < 8) return fail(ctx, FM_EINVAL, "fm_get_stats_ex: bad argument");
+    fm_stats st;
+    int rc = fm_get_stats(ctx, &st);
+    if (rc != FM_OK) return rc;
+    fm_stats_ex ex{};
+    ex.struct_bytes = (int64_t)sizeof(fm_stats_ex);
+    ex.kernel_ms = st.kernel_ms; ex.total_ms = st.total_ms; ex.kernel_launches = st.kernel_launches;
+    ex.pairs = st.pairs; ex.calls = st.calls;
+    ex.bytes_moved = ctx->stats_bytes;
+    memcpy(out, &ex, (size_t)(out_bytes < (int64_t)sizeof(ex) ? out_bytes : (int64_t)sizeof(ex)));
+    return FM_OK;
+}
+
+extern "C" int fm_abi_version(void) { return FM_ABI_VERSION; }
+
 extern "C" int fm_reset_stats(fm_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_reset_stats: ctx is NULL");
     ctx->stats = fm_stats{};
+    ctx->stats_bytes = 0;
     return FM_OK;
 }
 
@@ -594,6 +617,8 @@ static void bank_free(Bank* b)
     if (b->normf) (void)hipFree(b->normf);
     if (b->auxf) (void)hipFree(b->auxf);
     if (b->selfdist) (void)hipFree(b->selfdist);
+    if (b->stage) (void)hipFree(b->stage);
+    b->stage = nullptr;
     b->rows8 = nullptr; b->norm = nullptr; b->aux = nullptr; b->rowsf = nullptr; b->selfdist = nullptr;
     b->rowsh = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
@@ -613,6 +638,7 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     b->dim = dim;
     b->n_pad = ((n + kStageRows - 1) / kStageRows) * kStageRows;
     if (b->n_pad == 0) b->n_pad = kStageRows;
+    b->cap_pad = b->n_pad;
     b->kind = FM_BANK_I8;
     const size_t elt = f32 ? 4 : 1;
     const size_t src_bytes = (size_t)n * dim * elt;
@@ -706,10 +732,51 @@ extern "C" int fm_bank_create_f32_route(fm_ctx* ctx, const float* rows, int64_t 
     return bank_create(ctx, rows, n, dim, true, bank, true);
 }
 
+// A new image's descriptors into an existing bank: no allocation, no host synchronisation.  The copy (DMA engine)
+// and the preparation kernel run on the context's upload stream, beside whatever the other streams compute.
+extern "C" int fm_bank_refill_u8_async(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t n)
+{
+    if (!ctx || !bank) return fail(ctx, FM_EINVAL, "fm_bank_refill_u8_async: NULL argument");
+    if (bank->kind != FM_BANK_I8 || !bank->rows8) return fail(ctx, FM_EINVAL, "fm_bank_refill_u8_async: not an integer-route bank");
+    if (n < 0 || (n > 0 && !rows)) return fail(ctx, FM_EINVAL, "fm_bank_refill_u8_async: bad rows / n");
+    int64_t n_pad = ((n + kStageRows - 1) / kStageRows) * kStageRows;
+    if (n_pad == 0) n_pad = kStageRows;
+    if (n_pad > bank->cap_pad) return fail(ctx, FM_EINVAL, "fm_bank_refill_u8_async: more rows than the bank was created with");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->upload) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+    }
+    if (!bank->stage) HIP_TRY(ctx, hipMalloc(&bank->stage, (size_t)bank->cap_pad * kDim + 64));
+    int* d_flag = (int*)((char*)bank->stage + (size_t)bank->cap_pad * kDim);
+    if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(bank->stage, rows, (size_t)n * bank->dim, hipMemcpyHostToDevice, ctx->upload));
+    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 8, ctx->upload));
+    hipLaunchKernelGGL(bank_prep_kernel<false>, dim3((unsigned)(n_pad / kTileRows)), dim3(256), 0, ctx->upload,
+                       (const void*)bank->stage, n, bank->dim, bank->rows8, bank->norm, bank->aux, d_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    bank->n = n;
+    bank->n_pad = n_pad;
+    // the largest row norm of the new rows is known on the device only: assume the float32-root guard is needed
+    // (an election then launches one extra kernel that finds an empty list, ~5 us beside the next distance kernel)
+    bank->usq_max = INT32_MAX / 2;
+    return FM_OK;
+}
+
+extern "C" int fm_upload_fence(fm_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_upload_fence: ctx is NULL");
+    if (!ctx->upload) return FM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->upload));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+    return FM_OK;
+}
+
 // Everything enqueued on the context -- its own stream and the tail streams the async entry points use.
 void fm::sync_all_streams(fm_ctx* ctx)
 {
     (void)hipSetDevice(ctx->device);
+    if (ctx->upload) (void)hipStreamSynchronize(ctx->upload);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t ts : ctx->tails) if (ts) (void)hipStreamSynchronize(ts);
 }
@@ -737,7 +804,7 @@ extern "C" int fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* se
     if (!ctx || !bank) return fail(ctx, FM_EINVAL, "fm_bank_set_selfdist: NULL argument");
     if (bank->n > 0 && !selfdist) return fail(ctx, FM_EINVAL, "fm_bank_set_selfdist: selfdist is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!bank->selfdist) HIP_TRY(ctx, hipMalloc((void**)&bank->selfdist, (size_t)(bank->n > 0 ? bank->n : 1) * 8));
+    if (!bank->selfdist) HIP_TRY(ctx, hipMalloc((void**)&bank->selfdist, (size_t)(bank->cap_pad > 0 ? bank->cap_pad : 1) * 8));
     if (bank->n > 0) {
         HIP_TRY(ctx, hipMemcpyAsync(bank->selfdist, selfdist, (size_t)bank->n * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -328,17 +328,43 @@ __global__ void lowe_kernel(const int32_t* __restrict__ idx2, const float* __res
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
+// Self distances (cache.pyx:250-252, 271-273: [r[1].distance for r in bf_match(d, d, k = 2)]) from the split partials
+// of the masked-diagonal top-1: row i's value is the float32 distance to its nearest OTHER row, as float64; +inf
+// for a bank of one row.  Only the value is kept, so the float32-root ties of the integer route need no repair
+// (the smallest root is the root of the smallest d2).  Up to kRRBatchMax banks of one shape per launch
+// (blockIdx.y); bound_reset: the sweep is complete, its bound[] array goes back to "no bound".
 __global__ void selfdist_from_knn_kernel(const float* __restrict__ dist2, int64_t n, double* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)dist2[2 * i + 1];
 }
 
+struct SelfMerge {
+    const unsigned long long* partial[kRRBatchMax];
+    double* out[kRRBatchMax];
+    int*    bound_reset[kRRBatchMax];
+};
+
+__global__ void selfdist_merge_kernel(SelfMerge m, int nsplit, int ncols_alloc, int64_t n, int f32)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (m.bound_reset[b] && i < ncols_alloc) m.bound_reset[b][i] = INT32_MIN;
+    if (i >= n) return;
+    const unsigned long long* p = m.partial[b];
+    unsigned long long k = ~0ull;
+    for (int s = 0; s < nsplit; ++s) {
+        const unsigned long long v = p[(size_t)s * ncols_alloc + i];
+        k = v < k ? v : k;
+    }
+    m.out[b][i] = (k == ~0ull) ? (double)INFINITY : (double)key_dist(k, f32);
+}
+
 // ---------------------------------------------------------------------------------------
 // float32 route: K5 alone, or the fp16 filter (K8) with K5 as its conditional fallback
 // ---------------------------------------------------------------------------------------
 // Leaves the packed keys in ws_partial in `pl`'s layout (K5's plan) either way.
-static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* red, int ktop, RowReducePlan* pl_out)
+static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* red, int ktop, RowReducePlan* pl_out, bool self = false)
 {
     const RowReducePlan pl = plan_rowreduce_f32(cols->n_pad, red->n_pad, ctx->tune.nsplit);
     *pl_out = pl;
@@ -349,7 +375,7 @@ static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* 
         int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part);
         if (rc != FM_OK) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, (unsigned long long*)ctx->ws_partial, nullptr, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, (unsigned long long*)ctx->ws_partial, nullptr, ctx->stream, self));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         return FM_OK;
     }
@@ -363,8 +389,8 @@ static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* 
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, filter_empty_bound(), (size_t)fp.ncols_alloc * 2, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_filter(*cols, *red, ktop, fp, d_slots, d_bound, ctx->d_counters, d_part, ctx->stream));
-    HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, d_part, ctx->d_counters, ctx->stream));
+    HIP_TRY(ctx, launch_filter(*cols, *red, ktop, fp, d_slots, d_bound, ctx->d_counters, d_part, ctx->stream, self));
+    HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, d_part, ctx->d_counters, ctx->stream, self));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->filter_launches += 1;
     return FM_OK;
@@ -433,6 +459,7 @@ static int knn2_device(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     }
     ctx->kernel_timed = true;
     ctx->pending_pairs += nq * t->n;
+    ctx->pending_bytes += bank_bytes(q) + bank_bytes(t);
     // (output rows whose second best d2 reaches kSqrtTieMin are redone in OpenCV's float32 order)
     unsigned* d_fix = (!f32 && sqrt_tie_possible(*q, *t)) ? (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(2) + pl.bound_bytes()) : nullptr;
     if (d_fix) HIP_TRY(ctx, hipMemsetAsync(d_fix, 0, 16, ctx->stream));
@@ -513,6 +540,103 @@ extern "C" int fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
     return FM_OK;
 }
 
+static int take_timer(fm_ctx* ctx, fm_ctx::PendingTimer* tm);
+
+// Self distances of n banks on the context's stream, each into d_out[i] (device, [banks[i]->n] float64).
+// Integer-valued banks: the masked-diagonal top-1 sweep (K1's top-1 kernel; launch_rowreduce_self), runs of
+// consecutive banks of one padded size through ONE launch (rowreduce_batch_kernel, up to "batch_group" banks);
+// float32 banks: the float32 route with the diagonal masked (K8 filter + exact rescoring, or K5), one by one.
+// Banks with non-finite values keep the literal form (2-NN, second column).  Enqueue only; the split partials
+// live in ws_partial, which every user touches on ctx->stream only.  timed: record ev_k0 / ev_k1 around the
+// (last) distance-kernel launch.
+static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, double* const* d_out, bool timed)
+{
+    const int group_max = ctx->tune.batch_group;
+    int i = 0;
+    while (i < n) {
+        const fm_bank* b = banks[i];
+        if (b->n == 0) { ++i; continue; }
+        int rc;
+        if (b->kind == FM_BANK_F32) {
+            SelfMerge m{};
+            RowReducePlan pl;
+            if (!b->filt_ok) {
+                // non-finite values: no shortcut is claimed for them
+                if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, (size_t)b->n * 16 + 64)) != FM_OK) return rc;
+                int32_t* d_idx = (int32_t*)ctx->ws_out;
+                float* d_dist = (float*)((char*)ctx->ws_out + (size_t)b->n * 8);
+                if ((rc = knn2_device(ctx, b, b, d_idx, d_dist)) != FM_OK) return rc;
+                hipLaunchKernelGGL(selfdist_from_knn_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const float*)d_dist, b->n, d_out[i]);
+                HIP_TRY(ctx, hipGetLastError());
+                ++i;
+                continue;
+            }
+            if ((rc = rowreduce_f32_route(ctx, b, b, 1, &pl, true)) != FM_OK) return rc;
+            ctx->kernel_timed = true;
+            ctx->pending_pairs += b->n * b->n;
+            ctx->pending_bytes += bank_bytes(b);
+            m.partial[0] = (const unsigned long long*)ctx->ws_partial;
+            m.out[0] = d_out[i];
+            hipLaunchKernelGGL(selfdist_merge_kernel, dim3((unsigned)((b->n + 255) / 256), 1), dim3(256), 0, ctx->stream,
+                               m, pl.nsplit, pl.ncols_alloc, b->n, 1);
+            HIP_TRY(ctx, hipGetLastError());
+            ++i;
+            continue;
+        }
+        const RowReducePlan pl = plan_rowreduce_self(b->n_pad, ctx->tune);
+        int g = 1;
+        if (pl.nw == 8 && (ctx->tune.glds != 0) && pl.nbuf != 2)
+            while (i + g < n && g < group_max && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0 && banks[i + g]->n_pad == b->n_pad) ++g;
+        const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
+        const size_t pbytes = (pl.partial_bytes(1) + 255) & ~(size_t)255, bbytes = ((size_t)pl.ncols_alloc * 4 + 255) & ~(size_t)255;
+        if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, (size_t)g * (pbytes + bbytes))) != FM_OK) return rc;
+        SelfMerge m{};
+        const Bank* bk[kRRBatchMax];
+        unsigned long long* part[kRRBatchMax];
+        int* bnd[kRRBatchMax];
+        int64_t nmax = 0;
+        for (int j = 0; j < g; ++j) {
+            bk[j] = banks[i + j];
+            part[j] = (unsigned long long*)((char*)ctx->ws_partial + (size_t)j * (pbytes + bbytes));
+            bnd[j] = coop ? (int*)((char*)part[j] + pbytes) : nullptr;
+            m.partial[j] = part[j];
+            m.out[j] = d_out[i + j];
+            nmax = bk[j]->n > nmax ? bk[j]->n : nmax;
+            ctx->pending_pairs += bk[j]->n * bk[j]->n;
+            ctx->pending_bytes += bank_bytes(bk[j]);
+        }
+        if (coop && !ablate_keep_bounds())
+            for (int j = 0; j < g; ++j) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[j], (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+        if (g > 1) HIP_TRY(ctx, launch_rowreduce_batch(g, bk, bk, pl, part, bnd, ctx->stream, true));
+        else       HIP_TRY(ctx, launch_rowreduce_self(*bk[0], pl, part[0], bnd[0], (ctx->tune.glds != 0), ctx->stream));
+        if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        ctx->kernel_timed = timed;
+        // (banks of one padded size may hold different row counts: the merge covers the largest, rows beyond a
+        // bank's own n are never written -- its out[] has n entries -- see the guard below)
+        for (int j = 0; j < g; ++j) {
+            SelfMerge one{};
+            one.partial[0] = m.partial[j]; one.out[0] = m.out[j];
+            if (bk[j]->n != nmax) {
+                hipLaunchKernelGGL(selfdist_merge_kernel, dim3((unsigned)((bk[j]->n + 255) / 256), 1), dim3(256), 0, ctx->stream,
+                                   one, pl.nsplit, pl.ncols_alloc, bk[j]->n, 0);
+                m.partial[j] = nullptr;
+            }
+        }
+        // the banks that share nmax go through one launch
+        SelfMerge same{};
+        int ns = 0;
+        for (int j = 0; j < g; ++j) if (m.partial[j]) { same.partial[ns] = m.partial[j]; same.out[ns] = m.out[j]; ++ns; }
+        if (ns > 0)
+            hipLaunchKernelGGL(selfdist_merge_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)ns), dim3(256), 0, ctx->stream,
+                               same, pl.nsplit, pl.ncols_alloc, nmax, 0);
+        HIP_TRY(ctx, hipGetLastError());
+        i += g;
+    }
+    return FM_OK;
+}
+
 extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
 {
     int rc = check_pair(ctx, bank, bank, "fm_self_dist");
@@ -521,16 +645,62 @@ extern "C" int fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist)
     if (n == 0) return FM_OK;
     if (!selfdist) return fail(ctx, FM_EINVAL, "fm_self_dist: output pointer is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, (size_t)n * 24 + 64)) != FM_OK) return rc;
-    int32_t* d_idx = (int32_t*)ctx->ws_out;
-    float* d_dist = (float*)((char*)ctx->ws_out + (size_t)n * 8);
-    double* d_sd = (double*)((char*)ctx->ws_out + (size_t)n * 16);
+    // (ws_in: ws_out is the 2-NN scratch of the non-finite float32 case)
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, (size_t)n * 8 + 64)) != FM_OK) return rc;
+    double* d_sd = (double*)ctx->ws_in;
     CallScope cs(ctx);
-    if ((rc = knn2_device(ctx, bank, bank, d_idx, d_dist)) != FM_OK) return rc;
-    hipLaunchKernelGGL(selfdist_from_knn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const float*)d_dist, n, d_sd);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = selfdist_device(ctx, 1, &bank, &d_sd, true)) != FM_OK) return rc;
     HIP_TRY(ctx, d2h(ctx, selfdist, d_sd, (size_t)n * 8));
+    return cs.finish();
+}
+
+extern "C" int fm_self_dist_batch(fm_ctx* ctx, int32_t n, fm_bank* const* banks, double* const* out)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_self_dist_batch: ctx is NULL");
+    if (n < 0) return fail(ctx, FM_EINVAL, "fm_self_dist_batch: n < 0");
+    if (n == 0) return FM_OK;
+    if (!banks) return fail(ctx, FM_EINVAL, "fm_self_dist_batch: banks is NULL");
+    for (int i = 0; i < n; ++i) {
+        if (!banks[i]) return fail(ctx, FM_EINVAL, "fm_self_dist_batch: bank is NULL");
+        for (int j = 0; j < i; ++j) if (banks[j] == banks[i]) return fail(ctx, FM_EINVAL, "fm_self_dist_batch: a bank is listed twice");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<double*> d_out((size_t)n, nullptr);
+    std::vector<const fm_bank*> cb((size_t)n, nullptr);
+    bool any_out = false;
+    for (int i = 0; i < n; ++i) {
+        fm_bank* b = banks[i];
+        // (the first attachment allocates; a refilled bank keeps its array: fm_bank_refill_u8_async keeps the capacity)
+        if (!b->selfdist) HIP_TRY(ctx, hipMalloc((void**)&b->selfdist, (size_t)(b->cap_pad > 0 ? b->cap_pad : 1) * 8));
+        d_out[(size_t)i] = b->selfdist;
+        cb[(size_t)i] = b;
+        any_out = any_out || (out && out[i] && b->n > 0);
+    }
+    int rc;
+    if (!any_out) {
+        // enqueue only: accounted at the next fm_sync like the other asynchronous calls
+        fm_ctx::PendingTimer tm;
+        if ((rc = take_timer(ctx, &tm)) != FM_OK) return rc;
+        const int64_t before = ctx->pending_pairs, before_b = ctx->pending_bytes;
+        ctx->pending_pairs = 0;
+        ctx->pending_bytes = 0;
+        HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
+        rc = selfdist_device(ctx, n, cb.data(), d_out.data(), false);
+        HIP_TRY(ctx, hipEventRecord(tm.k1, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(tm.c1, ctx->stream));
+        tm.timed = rc == FM_OK && ctx->pending_pairs > 0;
+        tm.call_timed = true;
+        tm.pairs = ctx->pending_pairs;
+        tm.bytes = ctx->pending_bytes;
+        ctx->pending_pairs = before;
+        ctx->pending_bytes = before_b;
+        ctx->pending.push_back(tm);
+        return rc;
+    }
+    CallScope cs(ctx);
+    if ((rc = selfdist_device(ctx, n, cb.data(), d_out.data(), true)) != FM_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        if (out[i] && banks[i]->n > 0) HIP_TRY(ctx, d2h(ctx, out[i], d_out[(size_t)i], (size_t)banks[i]->n * 8));
     return cs.finish();
 }
 
@@ -696,6 +866,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         if ((rc = take_timer(ctx, &tm)) != FM_OK) return rc;
         tm.timed = nt > 0;
         tm.pairs = nq * nt;
+        tm.bytes = bank_bytes(q) + bank_bytes(t);
         fm_ctx::AsyncSlot& sl = ctx->aslot[ctx->aslot_next];
         ctx->aslot_next ^= 1;
         const SlotLayout L = slot_layout(nq, nt, pl);
@@ -741,6 +912,7 @@ static int xcheck_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, bool w
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
+        ctx->pending_bytes += bank_bytes(q) + bank_bytes(t);
         // (the float32 route's partial layout has no tie list behind it, and needs none)
         unsigned* d_fix = f32 ? nullptr : (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(1) + pl.bound_bytes());
         if ((rc = enqueue_election(ctx, ctx->stream, q, t, (const unsigned long long*)ctx->ws_partial, pl, d_qbest, 0u, nullptr, d_fix)) != FM_OK) return rc;
@@ -872,6 +1044,7 @@ static int xcheck1_keys_common(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, 
         }
         ctx->kernel_timed = true;
         ctx->pending_pairs += nq * nt;
+        ctx->pending_bytes += bank_bytes(q) + bank_bytes(t);
         unsigned* d_fix = f32 ? nullptr : (unsigned*)((char*)ctx->ws_partial + pl.partial_bytes(1) + pl.bound_bytes());
         if ((rc = enqueue_election(ctx, ctx->stream, q, t, (const unsigned long long*)ctx->ws_partial, pl, d_qbest, (unsigned)t_offset, nullptr, d_fix)) != FM_OK) return rc;
     }
@@ -1033,7 +1206,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         unsigned long long* part[kRRBatchMax]; int* bnd[kRRBatchMax];
         fm_ctx::PendingTimer tm;
         if ((rc = take_timer(ctx, &tm)) != FM_OK) return rc;
-        tm.timed = true; tm.call_timed = true; tm.pairs = 0;
+        tm.timed = true; tm.call_timed = true; tm.pairs = 0; tm.bytes = 0;
         for (int j = 0; j < g; ++j) {
             const int k = i + j;
             if (to_dev) {
@@ -1057,6 +1230,7 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             part[j] = (unsigned long long*)sl.ws;
             bnd[j] = coop ? (int*)((char*)sl.ws + L[j].pbytes) : nullptr;
             tm.pairs += q[k]->n * t[k]->n;
+            tm.bytes += bank_bytes(q[k]) + bank_bytes(t[k]);
         }
         HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
         HIP_TRY(ctx, launch_rowreduce_batch(g, cols, red, pl, part, bnd, ctx->stream));
@@ -1198,7 +1372,7 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
     if (n_rounds == 0) return FM_OK;
     if (!q_off || !t_off) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: NULL offsets");
     if (q_off[0] != 0) return fail(ctx, FM_EINVAL, "fm_xcheck1_batched: q_off[0] must be 0");
-    int64_t pairs = 0;
+    int64_t pairs = 0, rows_read = 0;
     for (int64_t b = 0; b < n_rounds; ++b) {
         const int64_t nq = q_off[b + 1] - q_off[b], nt = t_off[b + 1] - t_off[b];
         if (nq < 0 || nt < 0 || t_off[b] < 0 || t_off[b + 1] > t->n)
@@ -1206,6 +1380,7 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
         if (nq > round_qcap())
             return fail(ctx, FM_EUNSUPPORTED, "fm_xcheck1_batched: a round has more than 4096 query rows; use fm_xcheck1 on gathered banks");
         pairs += nq * nt;
+        rows_read += nq + nt;
     }
     const int64_t tot = q_off[n_rounds];
     if (tot == 0) return FM_OK;
@@ -1238,6 +1413,7 @@ extern "C" int fm_xcheck1_batched(fm_ctx* ctx, const fm_bank* q, const int32_t* 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     ctx->pending_pairs += pairs;
+    ctx->pending_bytes += rows_read * (f32 ? 512 : 128);
     HIP_TRY(ctx, d2h(ctx, tidx, ob + o_tidx, (size_t)tot * 4));
     HIP_TRY(ctx, d2h(ctx, dist, ob + o_dist, (size_t)tot * 4));
     if (ratio) HIP_TRY(ctx, d2h(ctx, ratio, ob + o_ratio, (size_t)tot * 8));

@@ -36,7 +36,7 @@ struct fm_ctx {
     struct StagedCopy { void* dst; size_t off, bytes; };
     std::vector<StagedCopy> staged;
     // calls enqueued without a synchronisation (fm_match_accepted_async): their events, read at fm_sync
-    struct PendingTimer { hipEvent_t c0, c1, k0, k1; bool timed; int64_t pairs; bool call_timed = true; };
+    struct PendingTimer { hipEvent_t c0, c1, k0, k1; bool timed; int64_t pairs; bool call_timed = true; int64_t bytes = 0; };
     int64_t async_calls = 0;
     std::vector<PendingTimer> pending;       // in flight
     std::vector<PendingTimer> timer_pool;    // idle event sets
@@ -68,9 +68,19 @@ struct fm_ctx {
     void* comm = nullptr;        // RCCL communicator of the result gather (fm_comm_init)
     int   comm_ranks = 0;
     fm_stats stats{};
+    int64_t stats_bytes = 0;     // fm_stats_ex::bytes_moved
     bool kernel_timed = false;
     int64_t pending_pairs = 0;
+    int64_t pending_bytes = 0;   // algorithmic bytes of the launches in pending_pairs: bank rows read once
+    // fm_bank_refill_u8_async / fm_upload_fence: uploads run on a stream of their own beside the kernels
+    hipStream_t upload = nullptr;
+    hipEvent_t ev_upload = nullptr;
 };
+
+namespace fm {
+// Algorithmic bytes of a bank in a distance-kernel launch: every row read once (128 B int8, 512 B float32).
+static inline int64_t bank_bytes(const fm::Bank* b) { return b ? b->n * (b->kind == FM_BANK_F32 ? 512 : 128) : 0; }
+}
 
 namespace fm {      // (internal helpers live in the library's namespace: a host program may have a `fail` of its own)
 int fail(fm_ctx* ctx, int code, const std::string& msg);
@@ -126,6 +136,7 @@ struct CallScope {
         ctx->h_stage_used = 0;
         ctx->kernel_timed = false;
         ctx->pending_pairs = 0;
+        ctx->pending_bytes = 0;
         (void)hipEventRecord(ctx->ev_call0, ctx->stream);
     }
     int finish()
@@ -148,6 +159,7 @@ struct CallScope {
             ctx->stats.kernel_ms += kms;
             ctx->stats.kernel_launches += 1;
             ctx->stats.pairs += ctx->pending_pairs;
+            ctx->stats_bytes += ctx->pending_bytes;
         }
         return FM_OK;
     }

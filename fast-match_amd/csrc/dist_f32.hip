@@ -35,6 +35,7 @@ struct F32Params {
     int          ncols_alloc;
     unsigned long long* partial;
     const int*   run_flag;    // null, or: skip the whole launch unless *run_flag != 0
+    int          self;        // the banks are one bank: row n is not a candidate for output row n (fm_self_dist)
 };
 
 __device__ __forceinline__ void load_tile_kmajor(const float* __restrict__ rows, int row0, float* __restrict__ img, int tid)
@@ -115,7 +116,7 @@ void rowreduce_f32_kernel(F32Params p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int idx = m0 + j;
-                    if (idx < p.nred && s[i][j] <= thr[i]) {
+                    if (idx < p.nred && s[i][j] <= thr[i] && !(p.self && idx == c0 + 4 * tn + i)) {
                         const float d = sqrtf(s[i][j]);
                         if (d < bd[i][KTOP - 1]) {            // strict: earlier row wins ties
                             if constexpr (KTOP == 2) {
@@ -199,10 +200,11 @@ RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_
 }
 
 hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                                unsigned long long* partial, const int* run_flag, hipStream_t stream)
+                                unsigned long long* partial, const int* run_flag, hipStream_t stream, bool self)
 {
     F32Params p;
     p.run_flag = run_flag;
+    p.self = self ? 1 : 0;
     p.col_rows = cols.rowsf;
     p.ncols_pad = (int)cols.n_pad;
     p.red_rows = red.rowsf;

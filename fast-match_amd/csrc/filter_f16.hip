@@ -110,10 +110,13 @@ __device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char*
                                          LDS_PTR(buf + kFStageRowBytes), 16, 0, 0);
 }
 
-template <int NC, int KTOP, int NW>
+// SELF (K = 1): both banks are the same bank and the pair (n, n) is masked -- the top-1 over the OTHER rows,
+// which is what Metric_Cache keeps of the self 2-NN (cache.pyx:250-252, 271-273; rowreduce.hip has the int8 form).
+template <int NC, int KTOP, int NW, bool SELF = false>
 __global__ __launch_bounds__(64 * NW, 2)
 void filter_kernel(FParams p)
 {
+    static_assert(!SELF || KTOP == 1, "the masked-diagonal sweep is a top-1");
     __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes];
 
     const int tid  = threadIdx.x;
@@ -309,6 +312,22 @@ void filter_kernel(FParams p)
                 for (int s = 1; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < NC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[t][s], bh[j][s], acc[t][j], 0, 0, 0);
+                if constexpr (SELF) {
+                    // 16-row tile d of the wave's own rows faces block j = d: lane (c16, g) holds the pair (row
+                    // 4 g + reg, output row c16), so the diagonal is reg = c16 & 3 of lane group c16 >> 2
+                    const unsigned d = (unsigned)(st * kTiles + k - (cb >> 4));
+                    if (d < (unsigned)NC) {
+                        const bool dl = g == (c16 >> 2);
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) {
+                            if ((unsigned)j == d) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    acc[t][j][r] = (dl && (c16 & 3) == r) ? -INFINITY : acc[t][j][r];
+                            }
+                        }
+                    }
+                }
             }
             if (k & 1) reduce_unit(st, k >> 1);
         }
@@ -415,6 +434,7 @@ struct RParams {
     unsigned long long* partial;  // split 0 of the caller's layout: [n][KTOP]
     int*         flag;            // [0] raised when more than kFMaxRescan output rows need a full scan,
                                   // [1] number of such rows, [3] total (diagnostic), [4 ..] their indices
+    int          self;            // the banks are one bank and row n is not a candidate for output row n
 };
 
 template <int KTOP, int LPC>       // LPC lanes per output row (16 or 64)
@@ -503,6 +523,7 @@ void rescan_kernel(RParams p, int nred)
     const float4* cp = (const float4*)(p.col_rowsf + (size_t)n * kDim);
     unsigned long long k0 = ~0ull, k1 = ~0ull;
     for (int m = m0 + threadIdx.x; m < m1; m += 256) {
+        if (p.self && m == n) continue;
         const float4* rp = (const float4*)(p.red_rowsf + (size_t)m * kDim);
         float sum = 0.f;
 #pragma unroll 8
@@ -606,8 +627,9 @@ bool filter_usable(const Bank& cols, const Bank& red)
 
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& pl,
                          unsigned long long* slots, int* bound, int* flag,
-                         unsigned long long* partial, hipStream_t stream)
+                         unsigned long long* partial, hipStream_t stream, bool self)
 {
+    if (self && (ktop != 1 || &cols != &red)) return hipErrorInvalidValue;
     const float eps = 1.1f / 1024.0f;
     const int dk = cols.kscale - red.kscale;          // acc units are 2^(kc + km)
     FParams p;
@@ -637,8 +659,9 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     const int grid = pl.nchunks * pl.nsplit;
 #define FM_LAUNCH_FILTER(NC_, NW_)                                                                         \
     do {                                                                                                   \
-        if (ktop == 1) hipLaunchKernelGGL((filter_kernel<NC_, 1, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
-        else           hipLaunchKernelGGL((filter_kernel<NC_, 2, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
+        if (self)           hipLaunchKernelGGL((filter_kernel<NC_, 1, NW_, true>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
+        else if (ktop == 1) hipLaunchKernelGGL((filter_kernel<NC_, 1, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
+        else                hipLaunchKernelGGL((filter_kernel<NC_, 2, NW_>), dim3(grid), dim3(64 * NW_), 0, stream, p); \
     } while (0)
     if (pl.nw == 8) FM_LAUNCH_FILTER(4, 8); else FM_LAUNCH_FILTER(4, 4);
 #undef FM_LAUNCH_FILTER
@@ -658,6 +681,7 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     r.ncols = (int)cols.n;
     r.partial = partial;
     r.flag = flag;
+    r.self = self ? 1 : 0;
     if (cols.n > 0 && p.fused) {
         // the filter rescored its own entries; only the flagged rows are left
         if (ktop == 1) hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan * kFRescanSplit), dim3(256), 0, stream, r, (int)red.n);

@@ -31,6 +31,8 @@ struct Bank {
     int64_t  n      = 0;
     int      dim    = 0;
     int64_t  n_pad  = 0;       // multiple of kStageRows (>= kStageRows so empty banks stage)
+    int64_t  cap_pad = 0;      // n_pad the arrays were allocated for (fm_bank_refill_u8_async keeps within it)
+    void*    stage  = nullptr; // refill staging: cap_pad * 128 source bytes + the preparation kernel's flag words
     int8_t*  rows8  = nullptr;
     int32_t* norm   = nullptr;
     int32_t* aux    = nullptr;
@@ -74,6 +76,8 @@ struct Tuning {
     int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a
                                       // state four times as large (0 = never: the status goes to the caller)
     int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
+    int k1_order = 0;                 // K1: workgroup -> (chunk, split) mapping (rowreduce.hip, map_block): 0 split major,
+                                      // 1 an XCD owns output chunks, 2 an XCD owns a contiguous share of the split-major order
 };
 
 // ---- K1: row-reduce kernel launcher ---------------------------------------------------
@@ -90,19 +94,25 @@ struct RowReducePlan {
     int stages_per_split;
     int nbuf = 0;      // stage buffers (0 = rule: 3 for top-1, 2 for top-2)
     int prio = 1;      // s_setprio around the MFMA burst
+    int order = 0;     // Tuning::k1_order
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 4 * 2; }   // (top-2 launches keep two arrays)
 };
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn);
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
                             unsigned long long* partial, int* bound, bool use_glds, hipStream_t stream);
+int rowreduce_grid(const RowReducePlan& plan);      // workgroups per bank pair (padded under orders 1 and 2)
+// fm_self_dist: top-1 of every row over the OTHER rows of its own bank (masked diagonal)
+RowReducePlan plan_rowreduce_self(int64_t n_pad, const Tuning& tn);
+hipError_t launch_rowreduce_self(const Bank& bank, const RowReducePlan& plan, unsigned long long* partial, int* bound,
+                                 bool use_glds, hipStream_t stream);
 
 // ---- K5: float32 route (dist_f32.hip); partial keys carry float32 distance bits ----------
 // run_flag: device word; the kernel returns at once when *run_flag == 0 (null = always run) and
 // counts its runs in run_flag[2].
 RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_nsplit);
 hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
-                                unsigned long long* partial, const int* run_flag, hipStream_t stream);
+                                unsigned long long* partial, const int* run_flag, hipStream_t stream, bool self = false);
 
 // ---- K8: fp16 MFMA filter + exact rescoring for the float32 route (filter_f16.hip) --------
 // Writes the same keys as K5 into split 0 of `partial` (the caller presets the other splits to
@@ -126,7 +136,7 @@ size_t filter_flag_bytes();       // size of the device words launch_filter's `f
 bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry filter planes of compatible scale
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
-                         unsigned long long* partial, hipStream_t stream);
+                         unsigned long long* partial, hipStream_t stream, bool self = false);
 
 // ---- K4: one workgroup per expansion round (rounds.hip) --------------------------------
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,
@@ -141,7 +151,7 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
 // ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
 constexpr int kRRBatchMax = 16;           // bank pairs per batched row-reduce launch
 hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
-                                  unsigned long long* const* partial, int* const* bound, hipStream_t stream);
+                                  unsigned long long* const* partial, int* const* bound, hipStream_t stream, bool self = false);
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream);   // all pairs of one kind / capacity
 int expand_cand_cap();
 int expand_cand_cap_big();

@@ -38,6 +38,17 @@ extern "C" int fm_debug_visits(unsigned long long* out, int reset)
 }
 #endif
 
+#ifdef FM_CLOCK_STAMP
+// Diagnostic build only (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles (s_memtime) and 100 MHz
+// wall ticks (s_memrealtime) around the stage loop of every workgroup; in-kernel clock = 100 MHz x cycles / ticks.
+// The stamps go to a buffer nothing else reads; the product build executes none of this.
+__device__ unsigned long long g_clock[2 * 8192];
+extern "C" int fm_debug_clock(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock), (size_t)(n < 8192 ? n : 8192) * 16);
+}
+#endif
+
 namespace fm {
 
 struct RRParams {
@@ -54,7 +65,61 @@ struct RRParams {
     int            ncols_alloc;
     unsigned long long* partial;
     int*           bound;         // [ncols_alloc] shared K-th-best bounds (INT32_MIN filled) or null
+    int            order;         // workgroup -> (chunk, split) mapping, see map_block
 };
+
+// Accumulator value of a masked (output row == reduced row) pair in the SELF kernels: below the padding
+// rows' -2^25, so the diagonal never beats anything, and (value << 5) still fits int32.
+constexpr int kSelfMasked = kPadCinit - 1;
+
+// Workgroups of a bank pair that the grid holds under `order` (RowReducePlan::order, option "k1_order"):
+//   0  split major: bid -> (chunk = bid % nchunks, split = bid / nchunks).  Consecutive workgroups -- dealt
+//      round-robin over the 8 XCDs -- sweep the SAME slice of the reduced bank for different output chunks,
+//      so every XCD's L2 fetches every slice, and the 13 workgroups of an output chunk sit on different XCDs.
+//   1  chunks owned by an XCD: the workgroups with equal (bid & 7) -- one XCD under the observed round-robin
+//      placement, a speed assumption only -- take the output chunks = (bid & 7) mod 8 for ALL splits, split
+//      major in time; the stationary operand of a chunk is then re-read from that XCD's own L2.  The
+//      nchunks % 8 chunks that are left over are dealt out one (chunk, split) at a time at the end.
+//   2  contiguous share of the split-major order per XCD (the guide's T1 remap): an XCD sweeps 1-3 slices of
+//      the reduced bank instead of all of them, a slice is fetched by 1-2 L2s instead of eight.
+// Orders 1 and 2 pad the grid of a pair to a multiple of 8 workgroups so that (bid & 7) names the same XCD
+// group for every pair of a batched launch; the workgroups beyond the last (chunk, split) exit at once.
+__host__ __device__ inline int blocks_per_pair(int nchunks, int nsplit, int order)
+{
+    const int nblk = nchunks * nsplit;
+    if (order == 1) return 8 * ((nchunks >> 3) * nsplit + (((nchunks & 7) * nsplit + 7) >> 3));
+    if (order == 2) return 8 * ((nblk + 7) >> 3);
+    return nblk;
+}
+
+__device__ __forceinline__ bool map_block(const RRParams& p, const int bid, int& chunk, int& split)
+{
+    const int nblk = p.nchunks * p.nsplit;
+    if (p.order == 0) {
+        chunk = bid % p.nchunks;
+        split = bid / p.nchunks;
+        return bid < nblk;
+    }
+    const int x = bid & 7, r = bid >> 3;
+    if (p.order == 2) {
+        const int per = (nblk + 7) >> 3;
+        const int l = x * per + r;
+        chunk = l % p.nchunks;
+        split = l / p.nchunks;
+        return l < nblk;
+    }
+    const int nc8 = p.nchunks >> 3, rem = p.nchunks & 7, owned = nc8 * p.nsplit;
+    if (r < owned) {
+        split = r / nc8;
+        chunk = (r - split * nc8) * 8 + x;
+        return true;
+    }
+    const int l = (r - owned) * 8 + x;
+    if (rem == 0 || l >= rem * p.nsplit) { chunk = 0; split = 0; return false; }
+    split = l / rem;
+    chunk = nc8 * 8 + (l - split * rem);
+    return true;
+}
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -102,22 +167,26 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 // hand-over only waits for a DMA issued a whole stage earlier and the newest one stays in flight.
 // bid = index of the workgroup inside ITS launch of one bank pair (rowreduce_kernel: blockIdx.x;
 // rowreduce_batch_kernel: blockIdx.x modulo the workgroups of a pair).
-template <int NC, int KTOP, bool GLDS, int NW, int NBUF, int PRIO>
+// SELF: both banks are the same bank and a row is not its own neighbour -- the pair (n, n) is masked, so
+// the top-1 is min over m != n of d(n, m): what Metric_Cache keeps of bf_match(d, d, k = 2), r[1].distance
+// (cache.pyx:250-252, 271-273; d(n, n) = 0 is always rank 0, and a duplicate's 0 is that minimum).  The
+// 32-row unit that holds a wave's own rows is a wave-uniform test, twice per sweep at most.
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF, int PRIO, bool SELF = false>
 __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid, char* smem)
 {
     static_assert(NBUF == 2 || (NBUF == 3 && GLDS), "three stage buffers need the LDS-DMA path");
+    static_assert(!SELF || KTOP == 1, "the masked-diagonal sweep is a top-1");
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g    = lane >> 4;          // lane group: rows 4g .. 4g+3 of every 16-row tile
     const int c16  = lane & 15;
-    // Split-major order: the first wave of resident workgroups covers EVERY output chunk for
-    // the first few slices, so the bounds it publishes serve all later workgroups (which
-    // reduce other slices for the same output rows) from their first tile on.  Concurrent
-    // workgroups then sweep the same slice, which every XCD serves from its own L2.
-    const int chunk = bid % p.nchunks;
-    const int split = bid / p.nchunks;
+    // Split-major in time under every order (map_block): the first wave of resident workgroups covers
+    // (nearly) every output chunk for the first few slices, so the bounds it publishes serve all later
+    // workgroups (which reduce other slices for the same output rows) from their first tile on.
+    int chunk, split;
+    if (!map_block(p, bid, chunk, split)) return;
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
     // Stationary operand: this wave's NC x 16 output rows, two 64-byte K-halves each.
@@ -159,6 +228,8 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     const int xoff = kStageRowBytes + 16 * g;
 
     constexpr int kDmaPerWave = 16 / NW;          // LDS-DMA instructions a wave issues per stage (+1 aux on the last wave)
+    // SELF: the 32-row unit of the reduced bank in which this wave's own rows start
+    const int own_unit = SELF ? __builtin_amdgcn_readfirstlane(cb >> 5) : 0;
 
     // Bounds published by the blocks that reduce other slices for the same output rows:
     // bound[n] is the K-th best hi some block has reached, so the final K-th best is
@@ -258,6 +329,24 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
                 for (int j = 0; j < NC; ++j) acc[s][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j][1], acc[s][j], 0, 0, 0);
             }
             if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+            if constexpr (SELF) {
+                // unit d of the wave's own 16 NC rows: its tiles s = 0, 1 face the blocks j = 2 d + s, and lane
+                // (c16, g) holds the pair (row 4 g + reg of the tile, output row c16): the diagonal is reg = c16 & 3
+                // of lane group c16 >> 2
+                // (own_unit is an SGPR: a scalar compare and branch per unit, nothing on the vector ALU)
+                const unsigned d = (unsigned)(st * (kStageRows / kTileRows) + u - own_unit);
+                if (d < (unsigned)(NC / 2)) {
+                    const bool dl = g == (c16 >> 2);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        if ((unsigned)(j >> 1) == d) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[j & 1][j][r] = (dl && (c16 & 3) == r) ? kSelfMasked : acc[j & 1][j][r];
+                        }
+                    }
+                }
+            }
             int tmax[NC];
             bool any = false;
 #pragma unroll
@@ -299,6 +388,9 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         }
     };
 
+#ifdef FM_CLOCK_STAMP
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (NBUF == 3) {
         for (int st = st0; st < st1; st += 3) {
             stage(std::integral_constant<int, 0>{}, st);
@@ -312,6 +404,13 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         }
     }
 
+#ifdef FM_CLOCK_STAMP
+    if (tid == 0) {
+        const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        g_clock[2 * (blockIdx.x & 8191)] = ck1 - ck0;
+        g_clock[2 * (blockIdx.x & 8191) + 1] = rt1 - rt0;
+    }
+#endif
 #ifdef FM_COUNT_VISITS
     if (lane == 0) atomicAdd(&g_visits[128 + (split & 127)], (unsigned long long)(st1 - st0) * 4 * NC);
 #endif
@@ -324,6 +423,7 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             bh[k] = top[j].hi(k);
             bi[k] = (top[j].unit[k] >= 0) ? top[j].index(k, g) : -1;
             if (bi[k] >= p.nred) bi[k] = -1;          // a padding row is not a candidate
+            if constexpr (SELF) { if (bi[k] == cb + 16 * j + c16) bi[k] = -1; }   // (cannot win: 7 unmasked rows share its unit)
         }
 #pragma unroll
         for (int mask = 16; mask <= 32; mask <<= 1) {
@@ -366,12 +466,12 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     }
 }
 
-template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2, int PRIO = 0>
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF = 2, int PRIO = 0, bool SELF = false>
 __global__ __launch_bounds__(64 * NW, (NC >= 8 ? 2 : (NC >= 6 ? 3 : 4)))
 void rowreduce_kernel(RRParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
-    rowreduce_body<NC, KTOP, GLDS, NW, NBUF, PRIO>(p, (int)blockIdx.x, smem);
+    rowreduce_body<NC, KTOP, GLDS, NW, NBUF, PRIO, SELF>(p, (int)blockIdx.x, smem);
 }
 
 // Several bank pairs of ONE shape in one launch, pair after pair in block order: when the workgroups of
@@ -384,14 +484,14 @@ struct RRBatch {
     int      blocks_per_pair;
 };
 
-template <int NC, int KTOP, int NW, int NBUF, int PRIO>
+template <int NC, int KTOP, int NW, int NBUF, int PRIO, bool SELF = false>
 __global__ __launch_bounds__(64 * NW, 4)
 void rowreduce_batch_kernel(RRBatch b)
 {
     __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
     const int pair = (int)blockIdx.x / b.blocks_per_pair;
     const RRParams p = b.p[pair];
-    rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+    rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO, SELF>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
 }
 
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
@@ -400,6 +500,7 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& 
     RowReducePlan pl;
     pl.nbuf = (tn.nbuf == 2 || tn.nbuf == 3) ? tn.nbuf : 0;
     pl.prio = tn.prio;
+    pl.order = (tn.k1_order >= 0 && tn.k1_order <= 2) ? tn.k1_order : 0;
     const int64_t nstages = nred_pad / kStageRows;
     // nb = blocks of 16 output rows per wave: 4 (64 rows, ~110 VGPRs, 4 waves/SIMD) by default,
     // 8 via FM_NB; nw = waves per workgroup sharing the staged tiles: 8 for big problems,
@@ -438,6 +539,23 @@ static int nbuf_choice(int ktop, int plan_nbuf)
 {
     if (plan_nbuf == 2 || plan_nbuf == 3) return plan_nbuf;
     return ktop == 1 ? 3 : 2;
+}
+
+// The masked-diagonal top-1 (fm_self_dist): 16 x 4 output rows per wave only (the unit test in the sweep
+// assumes nothing else, but only this shape is built), 8 or 4 waves.
+template <int NW>
+static hipError_t launch_self_t(const RRParams& p, int grid, bool glds, int plan_nbuf, bool prio, hipStream_t stream)
+{
+    if constexpr (NW == 8) {
+        if (glds && nbuf_choice(1, plan_nbuf) == 3) {
+            if (prio) hipLaunchKernelGGL((rowreduce_kernel<4, 1, true, NW, 3, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, p);
+            else      hipLaunchKernelGGL((rowreduce_kernel<4, 1, true, NW, 3, 0, true>), dim3(grid), dim3(64 * NW), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
+    if (glds) hipLaunchKernelGGL((rowreduce_kernel<4, 1, true, NW, 2, 0, true>), dim3(grid), dim3(64 * NW), 0, stream, p);
+    else      hipLaunchKernelGGL((rowreduce_kernel<4, 1, false, NW, 2, 0, true>), dim3(grid), dim3(64 * NW), 0, stream, p);
+    return hipGetLastError();
 }
 
 template <int NC, int KTOP, int NW>
@@ -491,20 +609,46 @@ static void fill_params(RRParams& p, const Bank& cols, const Bank& red, const Ro
     p.stages_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
+    p.order = plan.order;
+}
+
+int rowreduce_grid(const RowReducePlan& plan) { return blocks_per_pair(plan.nchunks, plan.nsplit, plan.order); }
+
+// Plan of the masked-diagonal sweep of a bank against itself: the built-in shape (4 blocks per wave, 8 or 4 waves)
+// whatever the "nb" / "nw" options say -- only that shape is built for it.
+RowReducePlan plan_rowreduce_self(int64_t n_pad, const Tuning& tn)
+{
+    Tuning t = tn;
+    t.nb = 0;
+    if (t.nw != 4 && t.nw != 8) t.nw = 0;
+    return plan_rowreduce(n_pad, n_pad, t);
 }
 
 // Top-1 row-reduce of n <= kRRBatchMax bank pairs that share `plan` (same padded sizes) in one launch.
 hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
-                                  unsigned long long* const* partial, int* const* bound, hipStream_t stream)
+                                  unsigned long long* const* partial, int* const* bound, hipStream_t stream, bool self)
 {
     if (n < 1 || n > kRRBatchMax || plan.nb != 4 || plan.nw != 8) return hipErrorInvalidValue;
     RRBatch b;
     for (int i = 0; i < n; ++i) fill_params(b.p[i], *cols[i], *red[i], plan, partial[i], bound[i]);
     for (int i = n; i < kRRBatchMax; ++i) b.p[i] = b.p[0];
     b.n = n;
-    b.blocks_per_pair = plan.nchunks * plan.nsplit;
-    hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
+    b.blocks_per_pair = rowreduce_grid(plan);
+    if (self) hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1, true>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
+    else      hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
     return hipGetLastError();
+}
+
+// Top-1 of every row of `bank` over the OTHER rows of the same bank (plan from plan_rowreduce_self).
+hipError_t launch_rowreduce_self(const Bank& bank, const RowReducePlan& plan, unsigned long long* partial, int* bound,
+                                 bool use_glds, hipStream_t stream)
+{
+    if (plan.nb != 4 || (plan.nw != 4 && plan.nw != 8)) return hipErrorInvalidValue;
+    RRParams p;
+    fill_params(p, bank, bank, plan, partial, bound);
+    const int grid = rowreduce_grid(plan);
+    return plan.nw == 8 ? launch_self_t<8>(p, grid, use_glds, plan.nbuf, plan.prio != 0, stream)
+                        : launch_self_t<4>(p, grid, use_glds, plan.nbuf, plan.prio != 0, stream);
 }
 
 hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const RowReducePlan& plan,
@@ -512,7 +656,7 @@ hipError_t launch_rowreduce(const Bank& cols, const Bank& red, int ktop, const R
 {
     RRParams p;
     fill_params(p, cols, red, plan, partial, bound);
-    const int grid = plan.nchunks * plan.nsplit;
+    const int grid = rowreduce_grid(plan);
     return ktop == 1 ? launch_k<1>(p, grid, plan.nb, plan.nw, use_glds, plan.nbuf, plan.prio != 0, stream)
                      : launch_k<2>(p, grid, plan.nb, plan.nw, use_glds, plan.nbuf, plan.prio != 0, stream);
 }

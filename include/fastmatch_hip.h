@@ -39,6 +39,12 @@ extern "C" {
 typedef struct fm_ctx  fm_ctx;
 typedef struct fm_bank fm_bank;
 
+/* ABI revision of this header.  It changes whenever an existing signature or struct layout does (revision 3, r03:
+ * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only).  A binding
+ * compares fm_abi_version() with the FM_ABI_VERSION it was written against before its first call.            */
+#define FM_ABI_VERSION 4
+int  fm_abi_version(void);
+
 typedef struct fm_stats {
     double   kernel_ms;      /* HIP-event time of the distance kernels since fm_reset_stats   */
     double   total_ms;       /* HIP-event time of whole calls (all kernels + copies)          */
@@ -46,6 +52,17 @@ typedef struct fm_stats {
     int64_t  pairs;          /* descriptor pairs evaluated by those launches                  */
     int64_t  calls;          /* API calls accounted in total_ms                               */
 } fm_stats;
+
+/* fm_stats plus what later revisions add; struct_bytes = sizeof(fm_stats_ex) of the library that filled it.
+ * bytes_moved = ALGORITHMIC bytes of the distance-kernel launches in kernel_ms: every bank row of a launch read
+ * once (128 B per integer-route row, 512 B per float32 row) -- the numerator of an HBM-roofline fraction; the
+ * bytes a launch really fetched come from the PMC counters (profiles/).                                       */
+typedef struct fm_stats_ex {
+    int64_t  struct_bytes;
+    double   kernel_ms, total_ms;
+    int64_t  kernel_launches, pairs, calls;
+    int64_t  bytes_moved;
+} fm_stats_ex;
 
 /* ---- context ---------------------------------------------------------------------- */
 int  fm_ctx_create(int device_id, fm_ctx** ctx);
@@ -64,6 +81,9 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "f32_filter"   0..2   float32 route: 0 = all-pairs kernel only, 1 = fp16 filter for large calls, 2 = always
  *   "f32_nw" "f32_nsplit" "f32_fused" "f32_lpc"   K8 launch shape (0 / -1 = rule)
  *   "async_time_every"    every n-th async call carries kernel-timing events (4; 0 = none)
+ *   "k1_order"     0..2   K1: how workgroups map to (output chunk, split of the reduction range): 0 split major,
+ *                         1 the workgroups of one XCD own a set of output chunks for all splits, 2 they own a
+ *                         contiguous share of the split-major order (the guide's XCD remap); see rowreduce.hip
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
  *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
  *                         repeated in a run state four times as large (2)
@@ -74,6 +94,8 @@ int  fm_ctx_get_option(fm_ctx* ctx, const char* name, int64_t* value);
 const char* fm_last_error(const fm_ctx* ctx);
 int  fm_sync(fm_ctx* ctx);
 int  fm_get_stats(fm_ctx* ctx, fm_stats* out);
+/* Writes min(out_bytes, sizeof(fm_stats_ex)) bytes: a caller built against an older, shorter struct stays valid. */
+int  fm_get_stats_ex(fm_ctx* ctx, fm_stats_ex* out, int64_t out_bytes);
 int  fm_reset_stats(fm_ctx* ctx);
 /* Name of the device the context runs on (e.g. "gfx950:..."), written NUL-terminated.  */
 int  fm_device_name(fm_ctx* ctx, char* buf, int buflen);
@@ -111,6 +133,18 @@ int  fm_bank_info(const fm_bank* bank, int64_t* n, int* dim, int* kind);
  * to a query bank so that fm_match_ratio can run the ratio test on the device.          */
 int  fm_bank_set_selfdist(fm_ctx* ctx, fm_bank* bank, const double* selfdist /*[n]*/);
 
+/* A new image into an existing bank (created by fm_bank_create_u8 / an integer-valued fm_bank_create_f32 with at
+ * least as many rows): no allocation and no host synchronisation -- the copy from `rows` (page-locked memory,
+ * fm_host_alloc, for a copy that really is asynchronous; [n][dim] uint8) and the preparation kernel are enqueued
+ * on the context's UPLOAD stream and run beside the kernels of the other streams.  The reference builds a new
+ * Metric_Cache / cell array per image (cache.pyx:263-284, 124-138); a pipeline over a stream of images re-uses
+ * the device arrays instead.  Rules: (1) work enqueued earlier that reads the bank must be COMPLETE (fm_wait on a
+ * ticket taken after it, or fm_sync) -- the refill does not wait for it; (2) fm_upload_fence() before the first
+ * call that uses a refilled bank; (3) self distances attached to the bank are stale: fm_self_dist_batch.       */
+int  fm_bank_refill_u8_async(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows /*page-locked*/, int64_t n);
+/* Makes everything enqueued on the context AFTER this call wait (on the device) for the refills enqueued before. */
+int  fm_upload_fence(fm_ctx* ctx);
+
 /* ---- K2: brute-force 2-NN ------------------------------------------------------------
  * Replaces cv2.BFMatcher(cv2.NORM_L2, crossCheck=False).knnMatch(q, t, k=2)
  *   matchutil.py:39-43 (bf_match), called from cache.pyx:250; Classic Matching.ipynb:63.
@@ -130,8 +164,18 @@ int  fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, 
 
 /* Replaces bf_match(d, d, k=2) + [r[1].distance] (cache.pyx:250-252; exact substitute
  * for the approximate flann_match at cache.pyx:271-273).  selfdist[i] = distance from
- * row i to its 2nd entry of the self 2-NN list, as float64 of the float32 value.         */
+ * row i to its 2nd entry of the self 2-NN list, as float64 of the float32 value (+inf for a bank of one row).
+ * That entry's distance is min over j != i of d(i, j): row i itself is at 0, always the first entry unless a
+ * duplicate with a lower index is, and then i (or another duplicate) is the second at 0 = that minimum; only the
+ * VALUE is kept, so its order among ties does not matter.  Computed as such: a top-1 sweep of the bank over
+ * itself with the diagonal masked (K1's top-1 kernel, not the top-2 one).                                   */
 int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
+/* The Metric_Cache builds of n images in one call: self distances of every bank, ATTACHED to it on the device
+ * (as fm_bank_set_selfdist would, without the trip through the host); consecutive integer-route banks of one
+ * padded size share a distance-kernel launch (option "batch_group").  out == NULL (or every out[i] NULL):
+ * enqueue only, complete after fm_sync / fm_wait; otherwise out[i] (may be NULL per bank) also receives bank i's
+ * values and the call is synchronous.  A bank must not be read by work still in flight (see fm_bank_refill).  */
+int  fm_self_dist_batch(fm_ctx* ctx, int32_t n, fm_bank* const* banks, double* const* out /*[n] of [n_i], or NULL*/);
 
 /* ---- X1: cross-checked 1-NN ----------------------------------------------------------
  * Replaces cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).knnMatch(q, t, k=1)

@@ -1,0 +1,248 @@
+"""GPU: Metric_Cache self distances as a masked-diagonal top-1 (fm_self_dist, fm_self_dist_batch), the refill of
+an existing bank (fm_bank_refill_u8_async) and the K1 workgroup orders -- against the oracle, which keeps the
+reference's literal form: bf_match(d, d, k = 2) then r[1].distance (cache.pyx:250-252, 271-273)."""
+import numpy as np
+import pytest
+
+import oracle
+from fastmatch_amd import synth, _ffi
+from kat import far_banks
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 64, 65, 127, 128, 129, 511, 512, 513, 1000, 4097, 33000])
+def test_self_dist_sizes_u8(ctx, n):
+    """Every position of the diagonal inside a wave's two 32-row units, banks with and without padding rows,
+    the 4-wave and the 8-wave kernel (33 000 rows), one row -> +inf."""
+    D = synth.synth_sift(n, np.random.default_rng(n))
+    sd = ctx.self_dist(ctx.bank(D))
+    assert _eq(sd, oracle.self_dist(D))
+    if n == 1:
+        assert np.isinf(sd[0])
+
+
+def test_self_dist_duplicates_and_zero_rows(ctx):
+    """A duplicate's 0 is the value, whichever index it has; all-equal banks; all-zero rows (the padding rows'
+    twin: a zero row must still beat them)."""
+    rng = np.random.default_rng(5)
+    D = synth.synth_sift(700, rng)
+    D[10] = D[500]            # duplicate with a higher index
+    D[650] = D[3]             # ... with a lower one
+    D[64:67] = D[63]          # a run across a 64-row wave boundary
+    D[200] = 0
+    D[420] = 0
+    sd = ctx.self_dist(ctx.bank(D))
+    assert _eq(sd, oracle.self_dist(D))
+    assert sd[10] == 0 and sd[500] == 0 and sd[3] == 0 and sd[650] == 0 and sd[200] == 0 and np.all(sd[63:67] == 0)
+    same = np.repeat(synth.synth_sift(1, rng), 300, axis=0)
+    assert np.all(ctx.self_dist(ctx.bank(same)) == 0)
+    zeros = np.zeros((130, 128), np.uint8)
+    assert np.all(ctx.self_dist(ctx.bank(zeros)) == 0)
+    two = np.zeros((2, 128), np.uint8)
+    two[1, 0] = 3
+    assert ctx.self_dist(ctx.bank(two)).tolist() == [3.0, 3.0]
+
+
+def test_self_dist_short_dim_and_extremes(ctx):
+    rng = np.random.default_rng(6)
+    for dim in (1, 7, 64, 127):
+        D = rng.integers(0, 256, (300, dim), dtype=np.uint8)
+        assert _eq(ctx.self_dist(ctx.bank(D)), oracle.self_dist(D)), dim
+    D = rng.choice(np.array([0, 255], np.uint8), (520, 128))
+    assert _eq(ctx.self_dist(ctx.bank(D)), oracle.self_dist(D))
+
+
+def test_self_dist_in_the_sqrt_tie_range(ctx):
+    """Only the VALUE is kept: sqrtf is monotone, so the smallest float32 root is the root of the smallest d2
+    and no tie repair is needed -- banks whose every distance lies where two d2 share a root."""
+    rng = np.random.default_rng(11)
+    Q, T = far_banks(300, 200, rng)
+    for D in (Q, T, np.concatenate([Q[:1], T]), np.concatenate([T[:1], Q])):
+        assert _eq(ctx.self_dist(ctx.bank(D)), oracle.self_dist(D))
+    # a handful of rows that are ALL far from each other: nearest other row at d2 ~ 4.2e6 .. 8e6
+    hit = 0
+    for seed in range(120):
+        r = np.random.default_rng(seed)
+        n = 2 + seed % 3
+        D = (r.integers(0, 2, (n, 128)) * 254 + r.integers(0, 2, (n, 128))).astype(np.uint8)
+        sd = ctx.self_dist(ctx.bank(D))
+        assert _eq(sd, oracle.self_dist(D))
+        hit += int((sd * sd >= 4197200).sum())
+    assert hit > 20
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 700, 2100])
+def test_self_dist_float32_route(ctx, n):
+    """Non-integer float32 banks: the float32 route with the diagonal masked (K5 for small banks, the fp16 filter +
+    exact rescoring from 4e6 pairs on), bit-identical to the oracle's order-1 chain."""
+    rng = np.random.default_rng(40 + n)
+    D = (synth.synth_sift(n, rng).astype(np.float32) + rng.uniform(-0.4, 0.4, (n, 128)).astype(np.float32))
+    if n >= 100:
+        D[7] = D[60]
+        D[n - 1] = D[n // 2]
+    sd = ctx.self_dist(ctx.bank(D))
+    assert _eq(sd, oracle.self_dist(D, order=1))
+
+
+def test_self_dist_float32_filter_forced_and_rescans(ctx):
+    """The fp16 filter on a bank of near duplicates (many rows inside the margin -> rescans) with the option that
+    sends every call through it."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    c.set_option("f32_filter", 2)
+    rng = np.random.default_rng(77)
+    base = synth.synth_sift(40, rng).astype(np.float32)
+    D = np.repeat(base, 30, axis=0) + rng.normal(0, 1e-3, (1200, 128)).astype(np.float32)
+    D[5] = D[900]
+    assert _eq(c.self_dist(c.bank(D)), oracle.self_dist(D, order=1))
+    E = rng.normal(0, 1, (3000, 128)).astype(np.float32)
+    assert _eq(c.self_dist(c.bank(E)), oracle.self_dist(E, order=1))
+    c.close()
+
+
+def test_self_dist_batch_attaches_and_matches(ctx):
+    """Several Metric_Cache builds in one call: banks of one size share a launch, others (another size, float32,
+    empty, one row) run beside them; the values are attached on the device (match_ratio uses them) and equal the
+    oracle's."""
+    rng = np.random.default_rng(9)
+    # (33 000-row banks take the 8-wave kernel: the batched launch; the 3 000-row ones the single launch)
+    mats = [synth.synth_sift(33000, rng), synth.synth_sift(33000, rng), synth.synth_sift(32900, rng),
+            synth.synth_sift(3000, rng), synth.synth_sift(3000, rng),
+            (synth.synth_sift(900, rng).astype(np.float32) + 0.25), np.zeros((0, 128), np.uint8),
+            synth.synth_sift(1, rng), synth.synth_sift(33000, rng)]
+    mats[1][17] = mats[1][30000]
+    banks = [ctx.bank(m) for m in mats]
+    got = ctx.self_dist_batch(banks)
+    for m, b, g in zip(mats, banks, got):
+        exp = oracle.self_dist(m, order=1) if m.shape[0] else np.zeros(0)
+        assert _eq(g, exp), m.shape
+        assert b.has_selfdist
+    # the attached values are what the ratio test divides by
+    T = synth.synth_sift(2500, rng)
+    tb = ctx.bank(T)
+    tidx, dist, ratio, passed, npass = ctx.match_ratio(banks[3], tb, 0.9)
+    otidx, odist = oracle.bf_xcheck1(mats[3], T)
+    m = otidx >= 0
+    oratio, opass = oracle.ratio_filter(odist[m], oracle.self_dist(mats[3]), 0.9, qrows=np.nonzero(m)[0])
+    assert _eq(tidx, otidx) and _eq(ratio[m], oratio) and np.array_equal(passed[m], opass)
+    # enqueue-only form: same values after a sync
+    fresh = [ctx.bank(m) for m in mats[:5]]
+    assert ctx.self_dist_batch(fresh, want_host=False) is None
+    ctx.sync()
+    for m, b in zip(mats[:5], fresh):
+        tidx2, _, ratio2, _, _ = ctx.match_ratio(b, b, 2.0)      # ratio = d / selfdist, d = 0 on the diagonal
+        assert np.all(tidx2 >= -1)
+    again = ctx.self_dist_batch(fresh)
+    for m, g in zip(mats[:5], again):
+        assert _eq(g, oracle.self_dist(m))
+    with pytest.raises(_ffi.FastMatchHipError):
+        ctx.self_dist_batch([banks[0], banks[0]])
+
+
+def test_refill_gives_what_a_fresh_bank_gives(ctx):
+    """fm_bank_refill_u8_async + fm_upload_fence + fm_self_dist_batch + the batched match: a pipeline over a
+    stream of images re-uses the device arrays; the results are those of banks created from scratch."""
+    rng = np.random.default_rng(21)
+    n0 = 33000
+    Q0, T0, _ = synth.planted_pair(n0, n0, seed=1)
+    qb, tb = ctx.bank(Q0), ctx.bank(T0)
+    ctx.self_dist_batch([qb], want_host=False)
+    ctx.sync()
+    for step, (nq, nt) in enumerate([(n0, n0), (32800, 33000), (5000, 7000)]):
+        Q, T, _ = synth.planted_pair(nq, nt, seed=50 + step)
+        pq = ctx.pinned_empty((nq, 128), np.uint8)
+        pt = ctx.pinned_empty((nt, 128), np.uint8)
+        pq[:] = Q
+        pt[:] = T
+        qb.refill_async(pq)
+        tb.refill_async(pt)
+        ctx.upload_fence()
+        ctx.self_dist_batch([qb], want_host=False)
+        out = tuple(ctx.pinned_empty(nq, dt) for dt in (np.int32, np.int32, np.float32, np.float64))
+        cnt = ctx.pinned_empty(1, np.int64)
+        ctx.match_accepted_batch([(qb, tb)], 0.7, [out], [cnt])
+        ctx.sync()
+        m = int(cnt[0])
+        fq, ft = ctx.bank(Q), ctx.bank(T)
+        sd = ctx.self_dist(fq)
+        assert _eq(sd, oracle.self_dist(Q))
+        fq.set_selfdist(sd)
+        eq_, et, ed, er = ctx.match_accepted(fq, ft, 0.7)
+        assert m == len(eq_) and m > 100
+        assert _eq(out[0][:m], eq_) and _eq(out[1][:m], et) and _eq(out[2][:m], ed) and _eq(out[3][:m], er)
+    with pytest.raises(_ffi.FastMatchHipError):
+        qb.refill_async(ctx.pinned_empty((n0 + 200, 128), np.uint8))      # beyond the bank's first size
+    with pytest.raises(ValueError):
+        qb.refill_async(np.zeros((10, 64), np.uint8))
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("nsplit", [0, 3, 13])
+def test_k1_workgroup_orders_give_identical_results(order, nsplit):
+    """Option "k1_order": the three workgroup -> (chunk, split) mappings cover every (chunk, split) exactly once
+    (padded grids, chunk counts that are and are not multiples of 8, single and batched launches)."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    c.set_option("k1_order", order)
+    c.set_option("nsplit", nsplit)
+    for nq, nt, seed in ((3000, 2600, 77), (33000, 36000, 78), (700, 40000, 79)):
+        Q, T, _ = synth.planted_pair(nq, nt, seed=seed)
+        qb, tb = c.bank(Q), c.bank(T)
+        tidx, dist = c.xcheck1(qb, tb)
+        otidx, odist = oracle.bf_xcheck1(Q, T)
+        assert _eq(tidx, otidx) and _eq(dist, odist)
+        idx, d2 = c.knn2(qb, tb)
+        oidx, od2 = oracle.bf_knn(Q, T, 2)
+        assert _eq(idx, oidx) and _eq(d2, od2)
+        assert _eq(c.self_dist(qb), oracle.self_dist(Q))
+    # batched launches: three pairs of one shape + the self distances of three banks in one launch each
+    mats = [synth.planted_pair(33000, 33000, seed=90 + i)[:2] for i in range(3)]
+    qbs = [c.bank(q) for q, _ in mats]
+    tbs = [c.bank(t) for _, t in mats]
+    sds = c.self_dist_batch(qbs)
+    outs = [tuple(c.pinned_empty(33000, dt) for dt in (np.int32, np.int32, np.float32, np.float64)) for _ in mats]
+    cnts = [c.pinned_empty(1, np.int64) for _ in mats]
+    c.set_option("batch_tail", 0)
+    c.match_accepted_batch(list(zip(qbs, tbs)), 0.7, outs, cnts)
+    c.sync()
+    for (Q, T), sd, out, cnt in zip(mats, sds, outs, cnts):
+        osd = oracle.self_dist(Q)
+        assert _eq(sd, osd)
+        otidx, odist = oracle.bf_xcheck1(Q, T)
+        mm = otidx >= 0
+        oratio, opass = oracle.ratio_filter(odist[mm], osd, 0.7, qrows=np.nonzero(mm)[0])
+        rows = np.nonzero(mm)[0][opass]
+        m = int(cnt[0])
+        assert m == len(rows) and _eq(out[0][:m], rows.astype(np.int32)) and _eq(out[1][:m], otidx[rows])
+        assert _eq(out[2][:m], odist[rows]) and _eq(out[3][:m], oratio[opass])
+    c.close()
+
+
+def test_stats_carry_algorithmic_bytes(ctx):
+    Q, T, _ = synth.planted_pair(3000, 2600, seed=3)
+    qb, tb = ctx.bank(Q), ctx.bank(T)
+    ctx.reset_stats()
+    ctx.xcheck1(qb, tb)
+    s = ctx.stats()
+    assert s["pairs"] == 3000 * 2600 and s["bytes_moved"] == (3000 + 2600) * 128
+    ctx.self_dist(qb)
+    assert ctx.stats()["bytes_moved"] == (3000 + 2600) * 128 + 3000 * 128
+
+
+def test_self_dist_300k_rows_against_oracle_rows(ctx):
+    """configs[2]'s bank size: 300k rows through the masked top-1 sweep; a row sample against the oracle's 2-NN of
+    those rows over the whole bank, and size-independent properties for all rows."""
+    rng = np.random.default_rng(300)
+    D = synth.synth_sift(300000, rng)
+    D[123456] = D[7]
+    sd = ctx.self_dist(ctx.bank(D))
+    assert sd.shape == (300000,) and sd[123456] == 0 and sd[7] == 0 and np.all(sd >= 0) and np.all(np.isfinite(sd))
+    rows = np.concatenate([rng.choice(300000, 300, replace=False), [0, 7, 63, 64, 123456, 299999]])
+    _, od = oracle.bf_knn(D[rows], D, 2)
+    assert _eq(sd[rows], od[:, 1].astype(np.float64))
