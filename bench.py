@@ -246,6 +246,100 @@ def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=64, reps=3):
                     "all-gather of (pair, query index, ratio) rows; wall = max over ranks, best of %d" % reps}
 
 
+def leg_fresh_pair(ctx, Q, T, rank, resident_counts, steps=8):
+    """What a NEW image pair costs end to end (the headline times resident banks with precomputed self
+    distances): per step 12 new pairs go upload -> Metric_Cache self distances -> X1 + R1 + compaction, pipelined:
+      fm_bank_refill_u8_async  24 banks of 100k rows from page-locked host memory into one of two resident bank sets,
+                               on the upload stream, beside the previous step's kernels (no allocation, no host sync)
+      fm_upload_fence + fm_self_dist_batch   the 12 query banks' self distances in ONE launch of the masked-diagonal
+                               top-1 sweep, attached on the device
+      fm_match_accepted_batch  the headline's step on the refilled banks
+    two steps in flight (fm_mark / fm_wait).  Checked: every pair's accepted count equals the resident run's.  Beside it
+    the naive flow a caller without the pipeline runs per pair (two fm_bank_create_u8, fm_self_dist,
+    fm_bank_set_selfdist, fm_match_accepted)."""
+    rng = np.random.default_rng(SEED + 1000 + rank)
+    n = PAIRS_PER_STEP
+    src = []
+    for j in range(n):
+        Qj, Tj = derived_pair(Q, T, j, rng)
+        pq, pt = ctx.pinned_empty((NQ, 128), np.uint8), ctx.pinned_empty((NT, 128), np.uint8)
+        pq[:] = Qj
+        pt[:] = Tj
+        src.append((pq, pt))
+    sets = []
+    for s in range(2):
+        banks = [(ctx.bank(src[j][0]), ctx.bank(src[j][1])) for j in range(n)]
+        outs = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.float32),
+                 ctx.pinned_empty(NQ, np.float64)) for _ in range(n)]
+        cnts = [ctx.pinned_empty(1, np.int64) for _ in range(n)]
+        ctx.self_dist_batch([q for q, _ in banks], want_host=False)
+        ctx.sync()
+        sets.append({"banks": banks, "outs": outs, "cnts": cnts, "batch": ctx.prepare_batch(banks, outs, cnts)})
+
+    def enqueue(s):
+        st = sets[s]
+        for j, (qb, tb) in enumerate(st["banks"]):
+            qb.refill_async(src[j][0])
+            tb.refill_async(src[j][1])
+        ctx.upload_fence()
+        ctx.self_dist_batch([q for q, _ in st["banks"]], want_host=False)
+        ctx.match_accepted_batch(st["batch"], TAU)
+        return ctx.mark()
+
+    def run(k):
+        prev = None
+        for i in range(k):
+            tk = enqueue(i % 2)          # (set i % 2 was last used by step i - 2, whose ticket has been waited for)
+            if prev is not None:
+                ctx.wait(prev)
+            prev = tk
+        ctx.wait(prev)
+        ctx.sync()
+
+    run(2)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    same = all(int(c[0]) == int(r) for stt in sets for c, r in zip(stt["cnts"], resident_counts))
+    ms_pair = 1e3 * dt / steps / n
+    # upload alone: 24 refills + a sync, nothing else on the device
+    ctx.sync()
+    t0 = time.perf_counter()
+    for j, (qb, tb) in enumerate(sets[0]["banks"]):
+        qb.refill_async(src[j][0])
+        tb.refill_async(src[j][1])
+    ctx.sync()
+    up_ms = 1e3 * (time.perf_counter() - t0) / n
+    # the naive flow, one pair at a time
+    reps = 4
+    t0 = time.perf_counter()
+    for j in range(reps):
+        qb, tb = ctx.bank(src[j][0]), ctx.bank(src[j][1])
+        qb.set_selfdist(ctx.self_dist(qb))
+        nq_acc = len(ctx.match_accepted(qb, tb, TAU, out=sets[0]["outs"][0])[0])
+        qb.close()
+        tb.close()
+    naive_ms = 1e3 * (time.perf_counter() - t0) / reps
+    for stt in sets:
+        for qb, tb in stt["banks"]:
+            qb.close()
+            tb.close()
+    ops = 2.0 * float(NQ) * NT * OPS_PER_PAIR                     # self sweep + cross-check sweep per image pair
+    return {"workload": "%d NEW 100k x 100k uint8 image pairs per step: upload (2 x 12.8 MB per pair, page-locked source) -> "
+                        "self distances (Metric_Cache build) -> X1 + R1 at 0.7 + compaction; two steps in flight" % n,
+            "steps": steps, "ms_per_image_pair": ms_pair, "image_pairs_per_s": 1e3 / ms_pair,
+            "descriptor_pairs_per_s": 2.0 * float(NQ) * NT / (ms_pair * 1e-3),
+            "frac_int8_mfma_peak_over_2e10_pairs": ops / (ms_pair * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
+            "distance_kernel_ms_per_image_pair": st["kernel_ms"] / (steps * n),
+            "upload_alone_ms_per_image_pair": up_ms, "upload_gb_per_s": 2 * NQ * 128 / (up_ms * 1e-3) / 1e9,
+            "naive_flow_ms_per_image_pair": naive_ms, "accepted_counts_equal_resident_run": bool(same),
+            "note": "pipelined: fm_bank_refill_u8_async (upload stream) + fm_upload_fence + fm_self_dist_batch (one launch for the "
+                    "12 query banks, masked-diagonal top-1) + fm_match_accepted_batch; naive: fm_bank_create_u8 x 2, fm_self_dist, "
+                    "fm_bank_set_selfdist, fm_match_accepted per pair, each synchronous; distance_kernel_ms = both sweeps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -520,8 +614,9 @@ def main():
     # Metric_Cache build (fm_self_dist = self 2-NN, K2): the single call timed during set-up (between bank uploads,
     # clock still ramping) and, for the kernel's own rate, the mean of ten back-to-back calls
     self2 = {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms, "wall_s": self_s,
-             "note": "Metric_Cache build, 100k x 100k self 2-NN, outside the timed region; kernel_ms = one call during set-up, "
-                     "kernel_ms_steady = mean of 10 back-to-back calls"}
+             "kernel": "fm::rowreduce_kernel<4,1,true,8,3,1,true> (K1's top-1 kernel, diagonal masked; r01-r03: the top-2 kernel)",
+             "note": "Metric_Cache build, 100k x 100k self distances = min over j != i (the second entry of the self 2-NN), outside the "
+                     "timed region; kernel_ms = one call during set-up, kernel_ms_steady = mean of 10 back-to-back calls"}
     if rank == 0 and legs:
         ctx.self_dist(qb)
         ctx.reset_stats()
@@ -602,6 +697,10 @@ def main():
         qall.close()
         tbf.close()
 
+    fresh = None
+    if rank == 0 and world == 1 and legs and use_async and os.environ.get("FM_BENCH_FRESH", "1") != "0":
+        fresh = leg_fresh_pair(ctx, Q, T, rank, [int(c[0]) for c in counts_sets[0]])
+
     c3 = c3t = None
     if rank == 0 and world == 1 and legs and os.environ.get("FM_BENCH_C3", "1") != "0":
         c3, c3_get = leg_expand_c3(ctx)
@@ -680,6 +779,7 @@ def main():
             "self_2nn": self2,
             "classic_ratio_match": crm,
             "single_pair": single,
+            "fresh_pair": fresh,
             "expand_c3": c3,
             "expand_c3_taus": c3t,
             "expand_c4": c4,

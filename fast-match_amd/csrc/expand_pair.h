@@ -43,6 +43,10 @@ struct ExpandPair {
     double*  m_pos;                // [match_cap][4]
     double*  m_ratio;              // [match_cap]
     int64_t  match_cap;
+    // huge tier (a radius subset beyond the LDS tables, expand.hip): per-run scratch in global memory, or null
+    int32_t* h_cand;               // [nq] the round's sorted query rows, all slots
+    unsigned long long* h_qbest;   // [nq] cross-check table of the round, all slots
+    unsigned long long* h_tbest;   // [largest cell] per train row: running (d2 << 32 | slot) minimum over the chunks
     long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers
     int        prof;               // non-zero: thread 0 accumulates per-phase 100 MHz ticks
 };

@@ -55,14 +55,21 @@ __device__ __forceinline__ void x1_stage_cell(char* lds, gptr<const int8_t> t_ro
 
 constexpr int kTbestWords = 128 + 4;       // 128 train rows of a chunk + the tie repair's two masks and its accumulator
 
-template <int SR, int NT = 256>
+// MERGE (K7's huge rounds, expand.hip): the query rows are ONE CHUNK (slots slot_base .. slot_base + nq of a radius
+// subset that does not fit LDS) and the function stops at the reverse-NN step: per train row the running minimum
+// (d2 << 32 | global slot) over the chunks seen so far is kept in tb_all[0 .. nt) (global memory; row cb0 + tid is
+// read and written by thread tid only, chunk after chunk, so no other thread ever needs to see it before the caller's
+// election) -- the cross-check is a per-train-row minimum over the query slots, and a minimum merges exactly.
+// qbest is not touched; tie_guard must be 0 (the float32-root repair looks at slots below the elected one).
+template <int SR, int NT = 256, bool MERGE = false>
 __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr<const int32_t> q_norm,
                                                 const int* q_rows, int nq,
                                                 gptr<const int8_t> t_rows8, gptr<const int32_t> t_norm,
                                                 int64_t t0, int nt, char* smem, unsigned long long* qbest,
                                                 unsigned long long* tbest /* LDS [kTbestWords] */, int tie_guard,
                                                 long long* pt = nullptr, long long* ts = nullptr,
-                                                const char* cell0 = nullptr /* LDS: chunk 0 staged by x1_stage_cell */)
+                                                const char* cell0 = nullptr /* LDS: chunk 0 staged by x1_stage_cell */,
+                                                gptr<unsigned long long> tb_all = nullptr, unsigned slot_base = 0)
 {
 #define X1_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
     constexpr int NW = NT / 64;                   // waves
@@ -212,13 +219,18 @@ __device__ __forceinline__ void x1_round_wsplit(gptr<const int8_t> q_rows8, gptr
         if (tid < 128 && cb0 + tid < nt) {
             const unsigned long long tb = tbest[tid];
             if (tb != ~0ull) {
-                const unsigned d2 = (unsigned)(tb >> 32);
-                tied = tie_guard && d2 >= kSqrtTieMin && sqrt_ties_up(d2);
-                if (!tied)
-                    atomicMin(&qbest[(unsigned)tb], ((unsigned long long)(tie_guard ? sqrt_bits(d2) : d2) << 32) | (unsigned)(cb0 + tid));
+                if constexpr (MERGE) {
+                    const unsigned long long g = tb + slot_base;        // (the slot is the low word and stays below 2^31)
+                    if (g < tb_all[cb0 + tid]) tb_all[cb0 + tid] = g;
+                } else {
+                    const unsigned d2 = (unsigned)(tb >> 32);
+                    tied = tie_guard && d2 >= kSqrtTieMin && sqrt_ties_up(d2);
+                    if (!tied)
+                        atomicMin(&qbest[(unsigned)tb], ((unsigned long long)(tie_guard ? sqrt_bits(d2) : d2) << 32) | (unsigned)(cb0 + tid));
+                }
             }
         }
-        if (tie_guard) {
+        if (!MERGE && tie_guard) {
             // Cold path (never with SIFT-range descriptors): train row n's best d2 shares its float32
             // root with d2 + 1, so a query slot at d2 + 1 with a LOWER slot number is the one OpenCV
             // elects.  Exact rescan of the slots below the elected one, row by row.
