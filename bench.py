@@ -108,9 +108,9 @@ def derived_pair(Q, T, j, rng):
     return np.ascontiguousarray(np.roll(Q[pq], 8 * j, axis=1)), np.ascontiguousarray(np.roll(T[pt], 8 * j, axis=1))
 
 
-def build_image_pair(ctx, size, n, seed, n_thumb):
+def build_image_pair(ctx, size, n, seed, n_thumb, **kw):
     from fastmatch_amd import synth, cache
-    q, t = synth.image_pair(size, n, seed, n_thumb=n_thumb)
+    q, t = synth.image_pair(size, n, seed, n_thumb=n_thumb, **kw)
     mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
                                         q["thumb_positions"], q["thumb_size"], options={"context": ctx})
     fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
@@ -150,6 +150,38 @@ def leg_expand_c3(ctx, reps=3):
             "note": "fm_expand_run (K7): exact depth-first replay of do_iter on the device, results fetched to the host; "
                     "pairs = sum over rounds of nq_i x nt_i; setup_s = synthetic pair + Metric_Cache (self 2-NN of 300k rows), "
                     "expander_build_s = cell packing + position index + upload (once per pair, reused by every threshold)"}, get
+
+
+def leg_expand_c3_clustered(ctx, uniform_rounds_per_s, reps=2):
+    """configs[2] on CLUSTERED keypoints (real SIFT crowds on texture; the uniform synthetic pair hides every capacity of
+    the device loop): the same 6000 x 4000 image and 300k keypoints per side, half of them in 12 Gaussian blobs
+    (sigma 60 px) -- radius subsets of ~10 000 rows and cells of thousands where r03 gave the whole pair back to the
+    host loop at 4096.  The device loop takes such rounds in chunks (expand.hip, HUGE tier)."""
+    from fastmatch_amd import fastmatch
+    mc, fi = build_image_pair(ctx, (6000, 4000), 300000, 20250004, 2000, p=0.15, clusters=12, cluster_sigma=60.0, cluster_frac=0.5)
+    qpos = mc.original["positions"]
+    dens = max(int((((qpos - c) ** 2).sum(axis=1) <= 100.0 ** 2).sum()) for c in qpos[::2503])
+    stats = {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": stats, "return_arrays": True})
+    get.expander()
+    t0 = time.perf_counter()
+    get(TAU)                                            # first run: climbs the capacity tiers (2048 -> 4096 -> chunked)
+    first = time.perf_counter() - t0
+    best = None
+    for _ in range(reps):
+        stats.clear()
+        t0 = time.perf_counter()
+        index, pos, ratio = get(TAU)
+        wall = time.perf_counter() - t0
+        if best is None or wall < best[0]:
+            best = (wall, stats.get("rounds", 0), stats.get("pairs", 0), len(index), stats.get("device_fallbacks", 0))
+    wall, rounds, pairs, nm, fb = best
+    return {"workload": "configs[2] geometry, 300k keypoints/side, half of them in 12 Gaussian blobs (sigma 60 px), p 0.15, tau 0.7",
+            "largest_radius_subset_sampled": dens, "wall_s": wall, "first_run_wall_s": first, "rounds": rounds,
+            "descriptor_pairs": pairs, "matches": nm, "rounds_per_s": rounds / wall, "pairs_per_s": pairs / wall,
+            "device_fallbacks": fb, "uniform_rounds_per_s": uniform_rounds_per_s,
+            "note": "first_run_wall_s includes the runs in the 2048- and 4096-row kernels that end at the first oversize subset; "
+                    "later runs of the pair start in the chunked variant (tier hint)"}
 
 
 def leg_expand_c3_taus(ctx, get, single_wall):
@@ -706,6 +738,8 @@ def main():
         c3, c3_get = leg_expand_c3(ctx)
         c3t = leg_expand_c3_taus(ctx, c3_get, c3["wall_s"])
         del c3_get
+        if os.environ.get("FM_BENCH_C3_CLUSTERED", "1") != "0":
+            c3["clustered"] = leg_expand_c3_clustered(ctx, c3["rounds_per_s"])
     c4 = None
     if legs and os.environ.get("FM_BENCH_C4", "1") != "0":
         c4 = leg_expand_c4(ctx, rank, world, dev, backend)

@@ -25,12 +25,16 @@ struct ExpandRun {
     // capacities of THIS run state: they start at the pair's defaults and are multiplied by four when a run
     // ends with the matching FM_EXPAND_*_FULL status (fm_expand_run then repeats the run)
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0, found_cap = 0;
+    // huge tier: the tables of a round whose radius subset does not fit LDS (created when a run first needs them)
+    void* huge = nullptr;          // h_cand i32[nq] | h_qbest u64[nq] | h_tbest u64[largest cell]
 };
 
 struct fm_expand {
     ExpandPair dev{};              // device pointers + parameters (run state, seeds and tau filled per run)
     void* blob = nullptr;          // the shared arrays
     int64_t nq = 0;
+    int64_t tmax = 0;              // rows of the largest cell
+    int tier_hint = 0;             // capacity tier (launch_expand) the pair's last complete run needed: the next run starts there
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0;       // defaults of a new run state
     std::vector<ExpandRun> runs;   // run slot k = the k-th run of this pair inside one launch
 };
@@ -42,6 +46,7 @@ static void expand_run_free(ExpandRun& r)
 {
     if (r.blob) (void)hipFree(r.blob);
     if (r.d_seeds) (void)hipFree(r.d_seeds);
+    if (r.huge) (void)hipFree(r.huge);
     r = ExpandRun{};
 }
 
@@ -82,8 +87,25 @@ static int expand_ensure_run(fm_ctx* ctx, fm_expand* ex, size_t slot)
     return FM_OK;
 }
 
-static void expand_bind_run(ExpandPair& P, const ExpandRun& r)
+// The global tables of the chunked rounds (expand.hip, HUGE) for one run state.
+static int expand_run_huge(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
 {
+    if (r.huge) return FM_OK;
+    const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1), tm = (size_t)(ex->tmax > 0 ? ex->tmax : 1);
+    hipError_t e = hipMalloc(&r.huge, al256(nq * 4) + al256(nq * 8) + al256(tm * 8));
+    if (e != hipSuccess) { (void)hipGetLastError(); r.huge = nullptr; return fail(ctx, FM_ENOMEM, std::string("fm_expand: chunked-round tables: ") + hipGetErrorString(e)); }
+    return FM_OK;
+}
+
+static void expand_bind_run(ExpandPair& P, const ExpandRun& r, const fm_expand* ex = nullptr)
+{
+    P.h_cand = nullptr; P.h_qbest = nullptr; P.h_tbest = nullptr;
+    if (r.huge && ex) {
+        const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1);
+        P.h_cand = (int32_t*)r.huge;
+        P.h_qbest = (unsigned long long*)((char*)r.huge + al256(nq * 4));
+        P.h_tbest = (unsigned long long*)((char*)r.huge + al256(nq * 4) + al256(nq * 8));
+    }
     P.stack = r.stack; P.stack_cap = r.stack_cap;
     P.seen = r.seen; P.seen_cap = r.seen_cap;
     P.found = r.found; P.found_cap = r.found_cap;
@@ -135,6 +157,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     fm_expand* ex = new (std::nothrow) fm_expand();
     if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
     ex->nq = nq;
+    for (int64_t c = 0; c < ncells; ++c) ex->tmax = std::max<int64_t>(ex->tmax, d->cell_off[c + 1] - d->cell_off[c]);
     ex->match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
     ex->stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
     ex->seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
@@ -251,16 +274,33 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         host[i].tau = tau[i];
         host[i].prof = ctx->tune.expand_prof;
     }
-    // the int8 and the float32 pairs are two kernels: descriptors grouped by kind, one launch each
+    // the int8 and the float32 pairs are different kernels, and so are the capacity tiers of the int8 one (a pair starts
+    // in the tier its last complete run needed): descriptors grouped by kernel, one launch each
+    std::vector<char> big((size_t)n, 0);          // capacity tier of the run's last launch (launch_expand)
+    for (int i = 0; i < n; ++i) {
+        if (host[i].f32) continue;
+        int t = pairs[i]->tier_hint;
+        if (t == 2 && (host[i].tie_guard || !ctx->tune.expand_huge || expand_run_huge(ctx, pairs[i], *run[(size_t)i]) != FM_OK)) t = 1;
+        if (t == 1 && !ctx->tune.expand_big) t = 0;
+        big[(size_t)i] = (char)t;
+        if (t == 2) expand_bind_run(host[i], *run[(size_t)i], pairs[i]);
+    }
     std::vector<ExpandPair> grouped;
     grouped.reserve((size_t)n);
-    for (int i = 0; i < n; ++i) if (!host[i].f32) grouped.push_back(host[i]);
-    const int n_i8 = (int)grouped.size();
-    for (int i = 0; i < n; ++i) if (host[i].f32) grouped.push_back(host[i]);
+    int n_tier[4] = {0, 0, 0, 0};
+    for (int v = 0; v < 3; ++v)
+        for (int i = 0; i < n; ++i) if (!host[i].f32 && (int)big[(size_t)i] == v) { grouped.push_back(host[i]); ++n_tier[v]; }
+    for (int i = 0; i < n; ++i) if (host[i].f32) { grouped.push_back(host[i]); ++n_tier[3]; }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (n_i8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n_i8, false, false, ctx->stream));
-    if (n - n_i8 > 0) HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n_i8 * sizeof(ExpandPair), n - n_i8, true, false, ctx->stream));
+    {
+        size_t at = 0;
+        for (int v = 0; v < 4; ++v) {
+            if (n_tier[v] > 0)
+                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + at * sizeof(ExpandPair), n_tier[v], v == 3, v == 3 ? 0 : v, ctx->stream));
+            at += (size_t)n_tier[v];
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     std::vector<long long> res((size_t)n * 4);
@@ -268,18 +308,26 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // Runs that ended on a capacity run again, from the start: a radius subset beyond the kernel's 2048 rows
-    // (status 2, int8 banks) in the 4096-row variant of the kernel; a full pending stack, result list or
+    // (status 2, int8 banks) in the 4096-row variant of the kernel and, beyond that, in the variant that takes a
+    // subset of any size in chunks (option expand_huge; not for pairs under the float32-root guard); a full pending stack, result list or
     // hash table (status 1, 4, 5: thresholds above 1 accept nearly every cross-checked pair and the
     // expansion heads for every (cell, query cell) combination) in a run state four times as large, at most
     // `expand_grow` times over (default 2; the status stands after that).  The other runs keep their results.
-    std::vector<char> big((size_t)n, 0);
-    for (int pass = 0; pass <= ctx->tune.expand_grow + 1; ++pass) {
+    for (int pass = 0; pass <= ctx->tune.expand_grow + 2; ++pass) {
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) {
             const long long st = res[(size_t)i * 4 + 3];
             ExpandRun* r = run[(size_t)i];
-            if (st == 2 && !host[i].f32 && ctx->tune.expand_big && !big[(size_t)i]) { big[(size_t)i] = 1; redo.push_back(i); continue; }
-            if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (big[(size_t)i] ? 1 : 0)) {
+            if (st == 2 && !host[i].f32 && ctx->tune.expand_big && big[(size_t)i] == 0) { big[(size_t)i] = 1; redo.push_back(i); continue; }
+            if (st == 2 && !host[i].f32 && !host[i].tie_guard && ctx->tune.expand_huge && big[(size_t)i] <= 1) {
+                if (expand_run_huge(ctx, pairs[i], *r) == FM_OK) {
+                    big[(size_t)i] = 2;
+                    expand_bind_run(host[i], *r, pairs[i]);
+                    redo.push_back(i);
+                }
+                continue;                                 // (no memory for the tables: the status stands)
+            }
+            if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (int)big[(size_t)i]) {
                 const int64_t limit = (int64_t)1 << 28;
                 if (st == 1) { if (r->stack_cap >= limit) continue; r->stack_cap *= 4; }
                 if (st == 4) { if (r->match_cap >= limit) continue; r->match_cap *= 4; }
@@ -289,15 +337,15 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                     if ((rc = expand_run_alloc(ctx, *r)) != FM_OK) return rc;
                     continue;
                 }
-                expand_bind_run(host[i], *r);
+                expand_bind_run(host[i], *r, pairs[i]);
                 redo.push_back(i);
             }
         }
         if (redo.empty()) break;
-        for (int v = 0; v < 2; ++v) {                   // the two int8 capacity variants (float32 pairs: the small one)
+        for (int v = 0; v < 3; ++v) {                   // the three int8 capacity variants (float32 pairs: the small one)
             grouped.clear();
             std::vector<int> idx;
-            for (int i : redo) if ((big[(size_t)i] ? 1 : 0) == v && !host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
+            for (int i : redo) if ((int)big[(size_t)i] == v && !host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
             const int n8 = (int)idx.size();
             if (v == 0) for (int i : redo) if (host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
             if (idx.empty()) continue;
@@ -305,16 +353,19 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 HIP_TRY(ctx, hipMemsetAsync(run[(size_t)i]->seen, 0xff, (size_t)((char*)run[(size_t)i]->found - (char*)run[(size_t)i]->seen) +
                                             (size_t)run[(size_t)i]->found_cap * 16, ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), grouped.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
-            if (n8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n8, false, v == 1, ctx->stream));
+            if (n8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n8, false, v, ctx->stream));
             if ((int)idx.size() > n8)
-                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n8 * sizeof(ExpandPair), (int)idx.size() - n8, true, false, ctx->stream));
+                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n8 * sizeof(ExpandPair), (int)idx.size() - n8, true, 0, ctx->stream));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
             for (int i : idx)
                 HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (ws_in is reused by the next variant)
         }
     }
-    for (int i = 0; i < n; ++i) ctx->pending_pairs += res[(size_t)i * 4 + 2];
+    for (int i = 0; i < n; ++i) {
+        ctx->pending_pairs += res[(size_t)i * 4 + 2];
+        if (res[(size_t)i * 4 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
+    }
     if (ctx->tune.expand_prof) {
         long long pr[16];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);

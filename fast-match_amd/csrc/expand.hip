@@ -213,15 +213,16 @@ __device__ __forceinline__ void block_sort_clear(int* hist)
     for (int b = threadIdx.x; b < kSortBuckets; b += kExpThreads) { hist[b] = 0; hist[kSortBuckets + 4 + b] = 0; }
 }
 
+// lo: the keys lie in [lo, r2] (a chunk of a huge round: the buckets then spread over that range only).
 template <int CAND>
 __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* idx, unsigned long long* k2,
-                                                 int* i2, int* hist, int n, double r2)
+                                                 int* i2, int* hist, int n, double r2, double lo = 0.0)
 {
     const int tid = threadIdx.x;
     int* start = hist;                       // [kSortBuckets + 1] after the scan
     int* cursor = hist + kSortBuckets + 4;   // [kSortBuckets]
     // (the caller has cleared start[] and cursor[] -- block_sort_clear -- in front of a barrier it needs anyway)
-    const double scale = r2 > 0.0 ? (double)kSortBuckets / r2 : 0.0;
+    const double scale = r2 > lo ? (double)kSortBuckets / (r2 - lo) : 0.0;
     int myb[CAND / kExpThreads];
 #pragma unroll
     for (int s = 0; s < CAND / kExpThreads; ++s) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
         myb[s] = 0;
         if (i < n) {
             const double d2 = __longlong_as_double((long long)keys[i]);
-            int b = (int)(d2 * scale);
+            int b = (int)((d2 - lo) * scale);           // (monotone in d2; a value just below lo truncates to bucket 0)
             b = b < kSortBuckets - 1 ? b : kSortBuckets - 1;
             myb[s] = b;
             atomicAdd(&start[b], 1);
@@ -267,7 +268,7 @@ __device__ __forceinline__ void block_sort_pairs(unsigned long long* keys, int* 
             const unsigned long long k = k2[p];
             const int v = i2[p];
             double d2 = __longlong_as_double((long long)k);
-            int b = (int)(d2 * scale);
+            int b = (int)((d2 - lo) * scale);
             b = b < kSortBuckets - 1 ? b : kSortBuckets - 1;
             const int s0 = start[b], s1 = start[b + 1];
             int rank = s0;
@@ -345,12 +346,23 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 // F32: the pairs of the launch hold float32 banks (float32 round) -- a kernel of its own, so that
 // the int8 kernel does not carry the float32 round's registers (inlined together they spill).
 // CAND: capacity variant (ExpCfg); the big one exists for int8 banks only.
-template <bool F32, int CAND = kExpCand>
+// HUGE (int8 banks, no float32-root guard): a round whose radius subset exceeds CAND rows -- denser keypoints than a
+// uniform image has, or a larger `radius` option; the reference has no limit (cache.pyx:173-188) -- is processed in
+// chunks of at most CAND rows instead of ending the run: the subset's histogram over the sort's buckets cuts it into
+// ranges of the sort key, every range is selected by a radius query of its own, sorted (ranges are disjoint and
+// ascending, so chunk order + order inside the chunk = the order of the whole subset) and matched against the cell
+// with the per-train-row minimum carried from chunk to chunk in global memory (x1_round_wsplit, MERGE); the election
+// and steps 4 / 5 then read the whole subset's tables from global memory.  Rounds that fit run the code of the
+// other variants unchanged.  Still given up (status 2 -> host loop): a single bucket of more than CAND keypoints
+// (thousands at one distance), more than CAND ACCEPTED matches in one round, more than kHugeChunks chunks.
+constexpr int kHugeChunks = 640;
+template <bool F32, int CAND = kExpCand, bool HUGE = false>
 __global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
     using C = ExpCfg<CAND>;
     static_assert(!F32 || CAND == kExpCand, "the float32 round needs the 512-row stage buffer");
+    static_assert(!HUGE || (!F32 && CAND == kExpCand), "the chunked round exists for the int8 round of the first variant");
     // dynamic LDS (C::kLdsBytes): the gather stage, the sort keys / qbest table, the
     // candidate rows, and two scratch arrays
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -395,6 +407,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<unsigned long long> found; int64_t found_cap;
         gptr<int32_t> m_index; gptr<double> m_pos, m_ratio; int64_t match_cap;
         gptr<long long> result; int prof;
+        gptr<int32_t> h_cand; gptr<unsigned long long> h_qbest, h_tbest;
     } P;
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
     P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos; P.q_pos_ord = (gptr<const double>)M.q_pos_ord;
@@ -410,6 +423,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.found = (gptr<unsigned long long>)M.found; P.found_cap = M.found_cap;
     P.m_index = (gptr<int32_t>)M.m_index; P.m_pos = (gptr<double>)M.m_pos; P.m_ratio = (gptr<double>)M.m_ratio;
     P.match_cap = M.match_cap; P.result = (gptr<long long>)M.result; P.prof = M.prof;
+    P.h_cand = (gptr<int32_t>)M.h_cand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest;
     const RoundF32G RF(M.rf);
     const int tid = threadIdx.x;
 
@@ -573,13 +587,19 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         }
         lds_barrier();
         const int nq = sh_i[4];
-        if (nq > CAND) { status = kExpCandFull; break; }
+        bool huge_round = false;                            // (uniform)
+        if (nq > CAND) {
+            if constexpr (HUGE) huge_round = true;
+            else { status = kExpCandFull; break; }
+        }
         EXP_STAMP(1);
+        char* const cell_lds = dyn_lds + C::kLdsBytes - kCellStageBytes;
+        const int nt = (int)(t1 - t0);
+        if (!huge_round) {
         // The cell's first 128 descriptor rows (int8 round: the MFMA B operand) go to LDS by DMA from here: the sort
         // touches no global memory, so their latency passes under it and no register waits for them (issued in
         // front of the radius query they only delayed its own loads -- vector-memory waits retire in order; loaded
         // into registers here they were spilled across the sort, which put the wait into the sort).
-        char* const cell_lds = dyn_lds + C::kLdsBytes - kCellStageBytes;
         if constexpr (!F32) { if (t1 > t0) x1_stage_cell<kExpThreads>(cell_lds, P.t_rows8, t0, (int)(t1 - t0)); }
         // sort by (key bits, index): non-negative doubles order like their bit patterns
         block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nq,
@@ -587,7 +607,6 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
-        const int nt = (int)(t1 - t0);
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
         for (int i = tid; i < nq; i += kExpThreads) keys[i] = ~0ull;     // keys[] becomes the qbest table
@@ -602,6 +621,93 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             x1_round_wsplit<C::kSR, kExpThreads>(P.q_rows8, P.q_norm, cand, nq, P.t_rows8, P.t_norm, t0, nt, smem, keys,
                                     (unsigned long long*)(hist + 2 * kSortBuckets + 16), P.tie_guard, P.prof ? pt : nullptr, &tstamp, cell_lds);
             // (nt > 0: the function's last chunk ends with a barrier behind its updates of keys[])
+        }
+        } else if constexpr (HUGE) {
+            // ---- 2b / 3b. a radius subset beyond the LDS tables: chunks of the sort-key range -----------------
+            if (nt == 0) continue;
+            n_pairs += (long long)nq * nt;
+            __shared__ int chb[kHugeChunks + 1];            // chunk c = sort buckets [chb[c], chb[c + 1])
+            const double rr = (double)P.radius;
+            const double lim_all = P.metric == 0 ? rr * rr : rr;
+            const double bscale = lim_all > 0.0 ? (double)kSortBuckets / lim_all : 0.0;
+            auto bucket_of = [&](double d2) __attribute__((always_inline)) {
+                const int b = (int)(d2 * bscale);
+                return b < kSortBuckets - 1 ? b : kSortBuckets - 1;
+            };
+            // every keypoint inside the radius once more (step 2's walk): fn(sort key, keypoint index)
+            auto walk = [&](auto fn) __attribute__((always_inline)) {
+                const double b = P.idx_bucket;
+                int bx0 = (int)floor(((double)qx - rr - P.idx_x0) / b), bx1 = (int)floor(((double)qx + rr - P.idx_x0) / b);
+                int by0 = (int)floor(((double)qy - rr - P.idx_y0) / b), by1 = (int)floor(((double)qy + rr - P.idx_y0) / b);
+                bx0 = max(bx0, 0); by0 = max(by0, 0);
+                bx1 = min(bx1, P.idx_nbx - 1); by1 = min(by1, P.idx_nby - 1);
+                if (!(P.idx_nbx > 0 && bx1 >= bx0)) return;
+                for (int by = by0; by <= by1; ++by) {
+                    const int s0 = P.idx_start[by * P.idx_nbx + bx0], e0 = P.idx_start[by * P.idx_nbx + bx1 + 1];
+                    for (int io = s0 + tid; io < e0; io += kExpThreads) {
+                        const int qi = P.idx_order[io];
+                        const double dx = P.q_pos_ord[2 * io] - (double)qx, dy = P.q_pos_ord[2 * io + 1] - (double)qy;
+                        double d2, lim;
+                        if (P.metric == 0) { d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)); lim = lim_all; }
+                        else if (P.metric == 1) { d2 = __dadd_rn(fabs(dx), fabs(dy)); lim = rr; }
+                        else { d2 = fmax(fabs(dx), fabs(dy)); lim = rr; }
+                        if (d2 <= lim) fn(d2, qi);
+                    }
+                }
+            };
+            // (a) the subset's histogram over the sort's buckets (cleared in front of step 2, untouched since)
+            walk([&](double d2, int) { atomicAdd(&hist[bucket_of(d2)], 1); });
+            for (int i = tid; i < nq; i += kExpThreads) P.h_qbest[i] = ~0ull;
+            if (tid < 128) for (int t = tid; t < nt; t += 128) P.h_tbest[t] = ~0ull;      // (row t belongs to thread t % 128 throughout)
+            lds_barrier();
+            if (tid == 0) {
+                int c = 0, acc = 0, ok = 1;
+                chb[0] = 0;
+                for (int b = 0; b < kSortBuckets && ok; ++b) {
+                    const int hb = hist[b];
+                    if (hb > CAND) ok = 0;                                   // thousands of keypoints at one distance
+                    else if (acc + hb > CAND) { if (c + 2 > kHugeChunks) ok = 0; else { chb[++c] = b; acc = hb; } }
+                    else acc += hb;
+                }
+                chb[++c] = kSortBuckets;
+                sh_i[5] = ok ? c : -1;
+            }
+            lds_barrier();
+            const int nch = sh_i[5];
+            if (nch < 0) { status = kExpCandFull; break; }
+            unsigned base = 0;
+            for (int c = 0; c < nch; ++c) {
+                const int b0 = chb[c], b1 = chb[c + 1];
+                if (tid == 0) sh_i[4] = 0;
+                block_sort_clear(hist);
+                lds_barrier();
+                walk([&](double d2, int qi) {
+                    const int b = bucket_of(d2);
+                    if (b >= b0 && b < b1) {
+                        const int slot = atomicAdd(&sh_i[4], 1);
+                        keys[slot] = (unsigned long long)__double_as_longlong(d2);
+                        cand[slot] = qi;
+                    }
+                });
+                lds_barrier();
+                const int nc = sh_i[4];
+                block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, (double)b1 / bscale, (double)b0 / bscale);
+                for (int i = tid; i < nc; i += kExpThreads) P.h_cand[base + i] = cand[i];
+                x1_round_wsplit<C::kSR, kExpThreads, true>(P.q_rows8, P.q_norm, cand, nc, P.t_rows8, P.t_norm, t0, nt, smem,
+                                        (unsigned long long*)nullptr, (unsigned long long*)(hist + 2 * kSortBuckets + 16), 0,
+                                        nullptr, nullptr, nullptr, P.h_tbest, base);
+                base += (unsigned)nc;
+            }
+            // (b) election: train row t elects the slot its minimum names; the slot keeps its closest train row
+            __syncthreads();                  // the fill of h_qbest and the copies of h_cand have reached memory
+            if (tid < 128)
+                for (int t = tid; t < nt; t += 128) {
+                    const unsigned long long tb = P.h_tbest[t];
+                    if (tb != ~0ull)
+                        __hip_atomic_fetch_min(P.h_qbest + (unsigned)tb, (tb & 0xffffffff00000000ull) | (unsigned long long)(unsigned)t,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            __syncthreads();
         }
         if constexpr (F32) lds_barrier();
 
@@ -699,13 +805,18 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 bool acc = false;
                 double ratio = 0.0, pq0 = 0, pq1 = 0, pt0 = 0, pt1 = 0;
                 int t_local = 0;
+                int qrow = 0;
                 if (i < nq) {
-                    const unsigned long long qb = keys[i];
+                    // (a huge round's tables are in global memory: agent-scope loads, the election's atomics ran in L2)
+                    unsigned long long qb;
+                    if (HUGE && huge_round) qb = __hip_atomic_load(P.h_qbest + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else qb = keys[i];
                     if (qb != ~0ull) {
                         // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
                         const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
                         // the positions step (b) needs ride on the same memory round trip as the self distance
-                        const int qrow = cand[i];
+                        if (HUGE && huge_round) qrow = __hip_atomic_load(P.h_cand + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else qrow = cand[i];
                         t_local = (int)(unsigned)qb;
                         const double sd = P.q_selfdist[qrow];
                         pq0 = P.q_pos[2 * qrow]; pq1 = P.q_pos[2 * qrow + 1];
@@ -718,8 +829,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
                 // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
                 // those reads from these writes): entries na+o <= i never clobber unread ones
+                if constexpr (HUGE) { if (huge_round && na + cnt > CAND) { status = kExpCandFull; break; } }   // (uniform)
                 if (acc) {
-                    tix[na + o] = i | (t_local << C::kSlotBits);
+                    // (a huge round's slot numbers do not fit beside t_local: the accepted list keeps the query row itself,
+                    // in cand[], which the round no longer needs -- its reads above came from global memory)
+                    if (HUGE && huge_round) { tix[na + o] = t_local; cand[na + o] = qrow; }
+                    else tix[na + o] = i | (t_local << C::kSlotBits);
                     nkey[na + o] = (unsigned long long)__double_as_longlong(ratio);
                     if (na + o < C::kPosCap) {               // (the stage buffer is free after the cross-check)
                         double* pp = pos4 + 4 * (na + o);
@@ -728,6 +843,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 }
                 na += cnt;
             }
+            if (status != kExpOk) break;
             lds_barrier();
             EXP_STAMP(4);
             // (b) per accepted match: neighbour key + seen probe, result key + found probe.
@@ -741,8 +857,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 bool known = false;
                 long long nslot = 0;
                 if (live) {
-                    const int slot = tix[k] & ((1 << C::kSlotBits) - 1), t_local = tix[k] >> C::kSlotBits;
-                    qrow_idx = cand[slot];
+                    int t_local;
+                    if (HUGE && huge_round) { t_local = tix[k]; qrow_idx = cand[k]; }
+                    else { t_local = tix[k] >> C::kSlotBits; qrow_idx = cand[tix[k] & ((1 << C::kSlotBits) - 1)]; }
                     rbits = nkey[k];
                     if (k < C::kPosCap) {                    // fetched together with the self distances in (a)
                         const double* pp = pos4 + 4 * k;
@@ -879,17 +996,24 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 }
 
-hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream)
+// tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8, no float32-root guard)
+hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream)
 {
     static bool attr_set = false;
+    const bool big = tier == 1;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCandBig>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCandBig>::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (f32 && big) return hipErrorInvalidValue;
+    if (f32 && tier != 0) return hipErrorInvalidValue;
+    if (tier == 2) {
+        hipLaunchKernelGGL((expand_kernel<false, kExpCand, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+        return hipGetLastError();
+    }
     if (f32)      hipLaunchKernelGGL((expand_kernel<true, kExpCand>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
     else if (big) hipLaunchKernelGGL((expand_kernel<false, kExpCandBig>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCandBig>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
     else          hipLaunchKernelGGL((expand_kernel<false, kExpCand>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);

@@ -73,6 +73,7 @@ struct Tuning {
     int batch_tail = 2;               // ... pairs of the short launch a run ends with (0 = none)
     int async_time_every = 4;         // async calls: every n-th call carries kernel timing events (0 = none)
     int expand_big = 1;               // K7: re-run pairs that overflow the 2048-row round in the 4096-row variant
+    int expand_huge = 1;              // K7: re-run pairs that still overflow in the variant that chunks a radius subset of any size
     int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a
                                       // state four times as large (0 = never: the status goes to the caller)
     int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
@@ -152,7 +153,7 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
 constexpr int kRRBatchMax = 16;           // bank pairs per batched row-reduce launch
 hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
                                   unsigned long long* const* partial, int* const* bound, hipStream_t stream, bool self = false);
-hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, bool big, hipStream_t stream);   // all pairs of one kind / capacity
+hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream);   // all pairs of one kind / capacity tier (expand.hip)
 int expand_cand_cap();
 int expand_cand_cap_big();
 

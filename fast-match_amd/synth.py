@@ -46,8 +46,21 @@ def _thumb_dims(size, box):
     return (max(1, int(size[0] * s)), max(1, int(size[1] * s)))
 
 
+def _positions(rng, n, w, h, centres, cluster_sigma, cluster_frac):
+    """Keypoint positions: uniform, or (centres given) a Gaussian mixture over the uniform background -- real SIFT
+    keypoints crowd on texture, 5-10x the mean density and more."""
+    pos = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], axis=1)
+    if centres is not None and len(centres):
+        inc = rng.random(n) < cluster_frac
+        k = rng.integers(0, len(centres), n)
+        g = centres[k] + rng.normal(0.0, cluster_sigma, (n, 2))
+        pos[inc] = np.clip(g[inc], 0.0, [w - 1.0, h - 1.0])
+    return pos
+
+
 def image_pair(size, n_keypoints, seed, p=0.3, sigma=6.0, shift=(37.0, -21.0), jitter=2.0,
-               n_thumb=600, q_thumb_box=(600, 600), t_thumb_box=(400, 400)):
+               n_thumb=600, q_thumb_box=(600, 600), t_thumb_box=(400, 400),
+               clusters=0, cluster_sigma=60.0, cluster_frac=0.5):
     """A synthetic query/target image pair as pre-extracted features.
 
     Keypoint positions are uniform in the image; a fraction p of the query keypoints are
@@ -55,6 +68,10 @@ def image_pair(size, n_keypoints, seed, p=0.3, sigma=6.0, shift=(37.0, -21.0), j
     target position - shift + N(0, jitter), so accepted matches propagate the expansion.
     Thumbnail banks are a subset of the keypoints (planted pairs first) with positions
     scaled to the thumbnail sizes and freshly perturbed descriptors.
+
+    clusters = k > 0: a fraction ``cluster_frac`` of the keypoints of BOTH images sits in k Gaussian blobs
+    (sigma ``cluster_sigma`` px, the query's blobs displaced by ``shift`` like the planted pairs), the rest is
+    uniform: radius subsets and grid cells in a blob hold many times the uniform count.
 
     Returns (query, target) dicts:
       query : descriptors u8[n,128], positions f64[n,2], size, thumb_descriptors,
@@ -64,8 +81,13 @@ def image_pair(size, n_keypoints, seed, p=0.3, sigma=6.0, shift=(37.0, -21.0), j
     rng = np.random.default_rng(seed)
     T = synth_sift(n_keypoints, rng)
     Q = synth_sift(n_keypoints, rng)
-    t_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
-    q_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
+    if clusters > 0:
+        centres = np.stack([rng.uniform(0.15 * w, 0.85 * w, clusters), rng.uniform(0.15 * h, 0.85 * h, clusters)], axis=1)
+        t_pos = _positions(rng, n_keypoints, w, h, centres, cluster_sigma, cluster_frac)
+        q_pos = _positions(rng, n_keypoints, w, h, centres - np.array(shift), cluster_sigma, cluster_frac)
+    else:           # (the draws of the uniform case are kept as they were: seeds of existing tests and bench legs)
+        t_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
+        q_pos = np.stack([rng.uniform(0, w, n_keypoints), rng.uniform(0, h, n_keypoints)], axis=1)
     planted = np.full(n_keypoints, -1, dtype=np.int64)
     k = int(round(p * n_keypoints))
     qsel = rng.choice(n_keypoints, size=k, replace=False)

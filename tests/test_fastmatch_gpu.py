@@ -198,14 +198,71 @@ def test_device_loop_return_arrays_and_many_pairs(ctx):
 
 
 def test_device_loop_falls_back_when_it_cannot_run(ctx):
-    # a radius that makes the query subset exceed every device capacity (4096 rows): the device
-    # reports it and match() silently replays the loop on the host with identical results
+    # a radius that makes the query subset exceed the LDS tables of both kernels (4096 rows) with the chunked
+    # variant switched off: the device reports it and match() silently replays the loop on the host, same results
     mc, fi, oq, ot = _build((400, 300), 6000, seed=77, ctx=ctx)
     stats = {}
-    got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.7)
+    ctx.set_option("expand_huge", 0)
+    try:
+        got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.7)
+    finally:
+        ctx.set_option("expand_huge", 1)
     exp = fo.o_match(oq, ot, {"radius": 200})(0.7)
     _same_matches(got, exp)
     assert stats.get("device_fallbacks") == 1 and "device_loops" not in stats
+
+
+def test_device_loop_chunks_radius_subsets_of_any_size(ctx):
+    """The reference's radius query has no size limit (cache.pyx:173-188).  Subsets beyond 4096 rows (here: nearly
+    the whole 6000-keypoint image inside radius 200) stay on the device: the round takes the subset in chunks of the
+    sort-key range and merges the per-train-row minimum across them (expand.hip, HUGE)."""
+    mc, fi, oq, ot = _build((400, 300), 6000, seed=77, ctx=ctx)
+    pos = mc.original["positions"]
+    assert ((pos[:, 0] - 200.0) ** 2 + (pos[:, 1] - 150.0) ** 2 <= 200.0 ** 2).sum() > 4096
+    for metric in ("minkowski", "manhattan", "chebyshev"):
+        q = cache.Metric_Cache.from_arrays(mc.original["descriptors"], pos, mc.original["size"], mc.thumb["descriptors"],
+                                           mc.thumb["positions"], mc.thumb["size"], options={"context": ctx, "metric": metric})
+        oqm = fo.OQuery(mc.original["descriptors"], pos, mc.original["size"],
+                        thumb={"descriptors": mc.thumb["descriptors"], "positions": mc.thumb["positions"], "size": mc.thumb["size"]},
+                        metric=metric)
+        for tau in (0.7, 0.95):
+            stats, hs = {}, {}
+            got = fastmatch.match(q, fi, {"context": ctx, "radius": 200, "stats": stats})(tau)
+            assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats
+            _same_matches(got, fo.o_match(oqm, ot, {"radius": 200})(tau))
+            host = fastmatch.match(q, fi, {"context": ctx, "radius": 200, "stats": hs, "device_loop": False})(tau)
+            _same_matches(got, host)
+            assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"] and len(got) > 300
+
+
+def test_device_loop_on_clustered_keypoints(ctx):
+    """Real SIFT keypoints crowd on texture.  A Gaussian-mixture image pair (three blobs holding half of 120k keypoints,
+    peak density > 20x the mean): the largest radius subset holds more than 10 000 rows, the largest cell thousands --
+    device loop == host loop == oracle, no run handed back to the host."""
+    q, t = synth.image_pair((2000, 1500), 120000, seed=4100, p=0.15, n_thumb=1200, clusters=3, cluster_sigma=60.0,
+                            cluster_frac=0.5)
+    qpos = q["positions"]
+    # (a keypoint near the densest point: the count inside its radius-100 disc)
+    dens = max(int((((qpos - c) ** 2).sum(axis=1) <= 100.0 ** 2).sum()) for c in qpos[::997])
+    assert dens >= 10000
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], qpos, q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    ds, hs = {}, {}
+    get = fastmatch.match(mc, fi, {"context": ctx, "stats": ds, "return_arrays": True})
+    index, pos, ratio = get(0.7)
+    assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds
+    host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.7)
+    assert ds["rounds"] == hs["rounds"] and ds["pairs"] == hs["pairs"] and len(host) == len(index) > 3000
+    assert index.tolist() == [e[0] for e in host]
+    assert np.array_equal(ratio, np.array([e[1]["ratio"] for e in host]))
+    assert np.array_equal(pos, np.array([e[1]["positions"] for e in host]).reshape(-1, 2, 2))
+    oq = fo.OQuery(q["descriptors"], qpos, q["size"],
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    _same_matches(host, fo.o_match(oq, ot, {})(0.7))
 
 
 def test_device_loop_reruns_in_the_large_capacity_kernel(ctx):
