@@ -20,7 +20,9 @@ FM_BANK_F32 = 2
 
 
 class FastMatchHipError(RuntimeError):
-    """Raised for every failure of the HIP path (the analogue of cv2.error)."""
+    """Raised for every failure of the HIP path (the analogue of cv2.error).  ``code`` = the FM_E* status
+    (-3 = FM_ENOMEM) when the library returned one."""
+    code = None
 
 
 class fm_stats(ctypes.Structure):
@@ -51,7 +53,7 @@ class fm_expand_desc(ctypes.Structure):
                 ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64), ("metric", ctypes.c_int32)]
 
 
-EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "radius subset larger than 4096 rows (2048 for float32 banks)",
+EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "a radius subset the device could not take (see FM_EXPAND_SUBSET_FULL)",
                  3: "target position outside the image", 4: "result list full", 5: "hash table full",
                  6: "float32 round: candidate list full"}
 
@@ -105,6 +107,9 @@ SYMBOLS = {
     "fm_expand_destroy": (_INT, [_P, _P]),
     "fm_expand_run": (_INT, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fm_expand_fetch": (_INT, [_P, _P, _I64, _P, _P, _P]),
+    "fm_expand_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int32)]),
+    "fm_expand_trim": (_INT, [_P, _P, ctypes.c_int32]),
+    "fm_mem_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "fm_comm_unique_id": (_INT, [_P]),
     "fm_comm_init": (_INT, [_P, _INT, _INT, _P]),
     "fm_comm_destroy": (_INT, [_P]),
@@ -260,6 +265,16 @@ class Expander(object):
         self.handle = h
         self._banks = (q_bank, t_bank)            # the banks must outlive the expander
 
+    def info(self):
+        """(bytes of one run state, run states that exist): see fm_expand_info."""
+        b, k = _I64(0), ctypes.c_int32(0)
+        self.ctx._check(self.ctx.lib.fm_expand_info(self.handle, ctypes.byref(b), ctypes.byref(k)))
+        return int(b.value), int(k.value)
+
+    def trim(self, keep=1):
+        """Free the run states from slot ``keep`` on (they are re-created on demand)."""
+        self.ctx._check(self.ctx.lib.fm_expand_trim(self.ctx.handle, self.handle, int(keep)))
+
     def fetch(self, n):
         index = np.empty(n, dtype=np.int32)
         pos = np.empty((n, 2, 2), dtype=np.float64)
@@ -297,7 +312,9 @@ class Context(object):
     def _check(self, rc):
         if rc != 0:
             msg = self.lib.fm_last_error(self.handle) if self.handle is not None else None
-            raise FastMatchHipError("libfastmatch_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            e = FastMatchHipError("libfastmatch_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            e.code = rc
+            raise e
 
     def close(self):
         if self.handle is not None:
@@ -689,6 +706,12 @@ class Context(object):
         a, b = _I64(0), _I64(0)
         self._check(self.lib.fm_f32_filter_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
+
+    def mem_info(self):
+        """(free, total) bytes of the context's device."""
+        f, t = _I64(0), _I64(0)
+        self._check(self.lib.fm_mem_info(self.handle, ctypes.byref(f), ctypes.byref(t)))
+        return int(f.value), int(t.value)
 
     def device_name(self):
         buf = ctypes.create_string_buffer(256)

@@ -36,6 +36,7 @@ METRIC_L2, METRIC_L1, METRIC_LINF = 0, 1, 2
 _METRICS = {"minkowski": METRIC_L2, "euclidean": METRIC_L2, "l2": METRIC_L2,
             "manhattan": METRIC_L1, "cityblock": METRIC_L1, "l1": METRIC_L1,
             "chebyshev": METRIC_LINF, "infinity": METRIC_LINF}
+_METRIC_NAMES = {METRIC_L2: "euclidean", METRIC_L1: "manhattan", METRIC_LINF: "chebyshev"}   # as sklearn knows them
 
 
 def metric_code(metric, p=None):
@@ -565,14 +566,30 @@ class Metric_Cache(object):
                  descriptors=self.original["descriptors"],
                  positions=self.original["positions"],
                  distances=self.original["distances"],
-                 position_tree=np.frombuffer(pickle.dumps(None), dtype=np.uint8),   # rebuilt on load
-                 size=self.original["size"])
+                 position_tree=np.frombuffer(self._tree_pickle(), dtype=np.uint8),
+                 size=self.original["size"],
+                 # (not read by the reference, which finds the metric inside its pickled tree)
+                 fm_metric=np.array(_METRIC_NAMES[self.original["position_tree"].metric]))
         np.savez("%s/%s_thumb" % (dir, data_path),
                  positions=self.thumb["positions"],
                  descriptors=self.thumb["descriptors"],
                  distances=self.thumb["distances"],
                  size=self.thumb["size"])
         return data_path
+
+    def _tree_pickle(self):
+        """What the reference stores under ``position_tree`` (cache.pyx:204: pickle.dumps of its sklearn BallTree) and
+        unpickles at load (cache.pyx:237), so that a file written here opens there: a real BallTree over the positions in
+        this cache's metric when scikit-learn is importable, else a pickled None (this package rebuilds its own index
+        from the positions and never reads the entry)."""
+        try:
+            from sklearn.neighbors import BallTree
+            pos = self.original["positions"]
+            if len(pos) == 0:
+                return pickle.dumps(None)
+            return pickle.dumps(BallTree(pos, metric=_METRIC_NAMES[self.original["position_tree"].metric]))
+        except Exception:
+            return pickle.dumps(None)
 
     def load(self, dir="data/image_data"):
         """ Loads file to Cache; False when no file exists for this path """
@@ -587,8 +604,12 @@ class Metric_Cache(object):
         self.thumb["size"] = tuple(int(v) for v in data_thumb["size"])
         self.original = {k: data[k] for k in ("descriptors", "positions", "distances")}
         self.original["size"] = tuple(int(v) for v in data["size"])
-        # the reference pickles its sklearn BallTree (which carries the metric it was built with); ours is
-        # rebuilt from the positions in the metric of THIS cache's options
+        # The reference pickles its sklearn BallTree, which carries the metric it was BUILT with (cache.pyx:276), so a
+        # cache saved under "manhattan" answers in Manhattan whatever the options at load time say.  Files written
+        # here carry the metric's name (fm_metric) and are reloaded in it; files without it (written by the reference:
+        # the pickle is not opened) take the metric of this cache's options.
+        if "fm_metric" in data.files:
+            self._metric = (str(data["fm_metric"]), None)
         self.original["position_tree"] = Position_Index(self.original["positions"], metric=self._metric[0], p=self._metric[1])
         self._bank = None
         self._thumb_bank = None

@@ -39,11 +39,14 @@ template <bool SRC_F32>
 __global__ __launch_bounds__(256)
 void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
                       int8_t* __restrict__ rows8, int32_t* __restrict__ norm,
-                      int32_t* __restrict__ aux, int* __restrict__ nonint)
+                      int32_t* __restrict__ aux, int* __restrict__ nonint, int64_t ntiles)
 {
     const int tid = threadIdx.x;
     const int r = tid >> 3, c = tid & 7;
-    const int64_t tile = blockIdx.x;
+    // A workgroup walks tiles blockIdx.x, + gridDim.x, ...: a refill (fm_bank_refill_u8_async) runs beside the distance
+    // kernels with a small grid of long-lived workgroups -- thousands of one-tile workgroups each took a CU slot a
+    // distance-kernel workgroup was waiting for (r04: 0.27 ms per 100k-row bank beside K1, 0.18 ms per image pair lost).
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row = tile * kTileRows + r;
     unsigned w[4] = {0, 0, 0, 0};
     int sumsq = 0, usq = 0;
@@ -141,6 +144,7 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
         // valued would otherwise send one atomic per element to the same address)
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (tid & 63) == 0 && *(volatile int*)nonint == 0) atomicOr(nonint, 1);
     }
+  }
 }
 
 // float32 bank for the general (non-integer) route: zero-padded copy [n_pad][128].
@@ -240,7 +244,7 @@ static const OptionDef kOptions[] = {
     {"f32_lpc", &Tuning::f32_lpc, 0, 64, "FM_F32_LPC"},
     {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
-    {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"},
+    {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"}, {"refill_grid", &Tuning::refill_grid, 1, 1 << 20, "FM_REFILL_GRID"},
     {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_huge", &Tuning::expand_huge, 0, 1, nullptr}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
 };
 
@@ -665,10 +669,10 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     const int ntiles = (int)(b->n_pad / kTileRows);
     if (f32)
         hipLaunchKernelGGL(bank_prep_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream,
-                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag);
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles);
     else
         hipLaunchKernelGGL(bank_prep_kernel<false>, dim3(ntiles), dim3(256), 0, ctx->stream,
-                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag);
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles);
     BTRY(hipGetLastError());
     int flags[2] = {0, 0};
     BTRY(hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -750,9 +754,11 @@ extern "C" int fm_bank_refill_u8_async(fm_ctx* ctx, fm_bank* bank, const uint8_t
     if (!bank->stage) HIP_TRY(ctx, hipMalloc(&bank->stage, (size_t)bank->cap_pad * kDim + 64));
     int* d_flag = (int*)((char*)bank->stage + (size_t)bank->cap_pad * kDim);
     if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(bank->stage, rows, (size_t)n * bank->dim, hipMemcpyHostToDevice, ctx->upload));
-    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 8, ctx->upload));
-    hipLaunchKernelGGL(bank_prep_kernel<false>, dim3((unsigned)(n_pad / kTileRows)), dim3(256), 0, ctx->upload,
-                       (const void*)bank->stage, n, bank->dim, bank->rows8, bank->norm, bank->aux, d_flag);
+    // (the flag words are scratch here: the largest row norm is not read back, see below -- no fill in front of the kernel)
+    const int64_t ntiles = n_pad / kTileRows;
+    const int64_t grid = ntiles < ctx->tune.refill_grid ? ntiles : ctx->tune.refill_grid;
+    hipLaunchKernelGGL(bank_prep_kernel<false>, dim3((unsigned)grid), dim3(256), 0, ctx->upload,
+                       (const void*)bank->stage, n, bank->dim, bank->rows8, bank->norm, bank->aux, d_flag, ntiles);
     HIP_TRY(ctx, hipGetLastError());
     bank->n = n;
     bank->n_pad = n_pad;

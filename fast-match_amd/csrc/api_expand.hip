@@ -205,6 +205,42 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     return FM_OK;
 }
 
+// Bytes one run state of the pair takes at its first capacities (stack + tables + result arrays), and how many
+// states exist: a caller that puts pairs x thresholds into one launch sizes the launch against free memory with it.
+extern "C" int fm_expand_info(const fm_expand* ex, int64_t* state_bytes, int32_t* n_slots)
+{
+    if (!ex) return fail(nullptr, FM_EINVAL, "fm_expand_info: NULL pair");
+    if (state_bytes) {
+        const int64_t found_cap = pow2_at_least(4 * ex->match_cap);
+        *state_bytes = (int64_t)(al256((size_t)ex->stack_cap * 32) + al256((size_t)ex->seen_cap * 8) + al256((size_t)found_cap * 16) +
+                                 al256((size_t)ex->match_cap * 4) + al256((size_t)ex->match_cap * 32) + al256((size_t)ex->match_cap * 8) + 256);
+    }
+    if (n_slots) *n_slots = (int32_t)ex->runs.size();
+    return FM_OK;
+}
+
+// Free the run states from slot `keep` on (keep >= 1: slot 0 exists as long as the pair does).
+extern "C" int fm_expand_trim(fm_ctx* ctx, fm_expand* ex, int32_t keep)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_trim: NULL argument");
+    if (keep < 1) return fail(ctx, FM_EINVAL, "fm_expand_trim: keep < 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    while ((int32_t)ex->runs.size() > keep) { expand_run_free(ex->runs.back()); ex->runs.pop_back(); }
+    return FM_OK;
+}
+
+extern "C" int fm_mem_info(fm_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_mem_info: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return FM_OK;
+}
+
 extern "C" int fm_expand_destroy(fm_ctx* ctx, fm_expand* ex)
 {
     if (!ex) return FM_OK;

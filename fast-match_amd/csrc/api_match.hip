@@ -598,8 +598,9 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
         int64_t nmax = 0;
         for (int j = 0; j < g; ++j) {
             bk[j] = banks[i + j];
-            part[j] = (unsigned long long*)((char*)ctx->ws_partial + (size_t)j * (pbytes + bbytes));
-            bnd[j] = coop ? (int*)((char*)part[j] + pbytes) : nullptr;
+            // (partials first, then the g bound arrays back to back: one fill re-arms them all)
+            part[j] = (unsigned long long*)((char*)ctx->ws_partial + (size_t)j * pbytes);
+            bnd[j] = coop ? (int*)((char*)ctx->ws_partial + (size_t)g * pbytes + (size_t)j * bbytes) : nullptr;
             m.partial[j] = part[j];
             m.out[j] = d_out[i + j];
             nmax = bk[j]->n > nmax ? bk[j]->n : nmax;
@@ -607,7 +608,7 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
             ctx->pending_bytes += bank_bytes(bk[j]);
         }
         if (coop && !ablate_keep_bounds())
-            for (int j = 0; j < g; ++j) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[j], (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[0], (int)0x80000000, (size_t)g * (bbytes / 4), ctx->stream));
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
         if (g > 1) HIP_TRY(ctx, launch_rowreduce_batch(g, bk, bk, pl, part, bnd, ctx->stream, true));
         else       HIP_TRY(ctx, launch_rowreduce_self(*bk[0], pl, part[0], bnd[0], (ctx->tune.glds != 0), ctx->stream));

@@ -244,6 +244,11 @@ void filter_kernel(FParams p)
                 tmax[j] = fmax3(fmax3(acc[1][j][2], acc[1][j][3], m0), m1, m1);
                 any |= tmax[j] >= thr[j];
             }
+#ifdef FM_ABLATE_F32_NOEXACT
+            // ablation build only (scripts/README.md): what the filter costs when NO unit takes the exact path -- the
+            // ceiling of anything a different lane mapping could save there.  Results are wrong in this build.
+            any = false;
+#endif
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 const int row0 = (st * (kFStageRows / 16) + 2 * u) * 16 + 4 * g;
 #pragma unroll

@@ -77,6 +77,7 @@ struct Tuning {
     int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a
                                       // state four times as large (0 = never: the status goes to the caller)
     int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
+    int refill_grid = 128;            // fm_bank_refill_u8_async: workgroups of the preparation kernel (each walks its share of the tiles)
     int k1_order = 0;                 // K1: workgroup -> (chunk, split) mapping (rowreduce.hip, map_block): 0 split major,
                                       // 1 an XCD owns output chunks, 2 an XCD owns a contiguous share of the split-major order
 };

@@ -128,32 +128,90 @@ def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_
         return False
 
 
-def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):
-    """One launch of the device-resident loop for several independent runs: (expander, seeds, tau)
-    triples, an expander may appear several times (several thresholds of one pair).  Returns, per
-    run, the match list in do_iter's format (or (index, positions, ratio) arrays), or None
-    where the device gave up (caller falls back to the host loop)."""
-    out = []
-    results = context.expand_run(expanders, seeds, taus)
+def _launch_plan(context, expanders, mem_fraction=0.5):
+    """Cut a list of runs into launches that fit the device's memory.  fm_expand_run gives every run of a launch a run
+    state of its own (the k-th run naming an expander uses its slot k; ~210 MB each for a 300k-keypoint pair) and keeps
+    it: a dataset of pairs x 15 thresholds in ONE launch can ask for more than the device has.  A launch is closed when
+    the NEW states it would create exceed ``mem_fraction`` of the free memory; the next launch re-uses slots 0..k.
+    Returns a list of index lists (order preserved)."""
+    try:
+        free, _ = context.mem_info()
+    except Exception:
+        return [list(range(len(expanders)))]
+    budget = mem_fraction * free
+    info = {}
+    launches, cur, used, new_bytes = [], [], {}, 0.0
+    for i, ex in enumerate(expanders):
+        if id(ex) not in info:
+            info[id(ex)] = ex.info()
+        state_bytes, n_slots = info[id(ex)]
+        k = used.get(id(ex), 0)
+        need = state_bytes if k >= n_slots else 0
+        if cur and need and new_bytes + need > budget:
+            launches.append(cur)
+            for e in {id(expanders[j]): expanders[j] for j in cur}.values():    # what that launch created exists now
+                info[id(e)] = (info[id(e)][0], max(info[id(e)][1], sum(1 for j in cur if expanders[j] is e)))
+            cur, used, new_bytes = [], {}, 0.0
+            k = 0
+            need = state_bytes if k >= info[id(ex)][1] else 0
+        cur.append(i)
+        used[id(ex)] = k + 1
+        new_bytes += need
+    if cur:
+        launches.append(cur)
+    return launches
+
+
+def _expand_launch(context, expanders, seeds, taus):
+    """One fm_expand_run launch + fetch; a launch the device has no memory for is halved (down to single runs, whose
+    failure is reported as status -1: the caller's host loop takes them)."""
+    from . import _ffi
+    try:
+        results = context.expand_run(expanders, seeds, taus)
+    except _ffi.FastMatchHipError as e:
+        if getattr(e, "code", None) != -3:                 # FM_ENOMEM
+            raise
+        for ex in set(expanders):                          # give back what the earlier launches hold beyond slot 0
+            ex.trim(1)
+        if len(expanders) == 1:
+            return [(0, 0, 0, -1)], {}
+        h = len(expanders) // 2
+        r1, f1 = _expand_launch(context, expanders[:h], seeds[:h], taus[:h])
+        r2, f2 = _expand_launch(context, expanders[h:], seeds[h:], taus[h:])
+        f1.update({k + h: v for k, v in f2.items()})
+        return r1 + r2, f1
     slots = context.expand_slots(expanders)
     ok = [i for i, r in enumerate(results) if r[3] == 0]
     fetched = dict(zip(ok, context.expand_fetch_many([expanders[i] for i in ok], [results[i][0] for i in ok],
                                                      slots=[slots[i] for i in ok])))
-    for i, (ex, (n_matches, n_rounds, n_pairs, status)) in enumerate(zip(expanders, results)):
-        if status != 0:
+    return results, fetched
+
+
+def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):
+    """The device-resident loop for several independent runs: (expander, seeds, tau) triples, an expander may appear
+    several times (several thresholds of one pair).  All runs go into ONE launch when the run states fit the device's
+    memory, else into as few launches as do (``_launch_plan``).  Returns, per run, the match list in do_iter's format
+    (or (index, positions, ratio) arrays), or None where the device gave up (caller falls back to the host loop)."""
+    out = [None] * len(expanders)
+    plan = _launch_plan(context, expanders)
+    if stats is not None and len(plan) > 1:
+        stats["device_launches"] = stats.get("device_launches", 0) + len(plan)
+    for idx in plan:
+        results, fetched = _expand_launch(context, [expanders[i] for i in idx], [seeds[i] for i in idx], [taus[i] for i in idx])
+        for j, (i, (n_matches, n_rounds, n_pairs, status)) in enumerate(zip(idx, results)):
+            if status != 0:
+                if stats is not None:
+                    stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
+                continue
             if stats is not None:
-                stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
-            out.append(None)
-            continue
-        if stats is not None:
-            stats["device_loops"] = stats.get("device_loops", 0) + 1
-            stats["rounds"] = stats.get("rounds", 0) + n_rounds
-            stats["pairs"] = stats.get("pairs", 0) + n_pairs
-        index, pos, ratio = fetched[i]
-        if as_arrays:
-            out.append((index, pos, ratio))
-        else:
-            out.append([(int(i), {"positions": p, "ratio": float(r)}) for i, p, r in zip(index, pos, ratio)])
+                stats["device_loops"] = stats.get("device_loops", 0) + 1
+                stats["rounds"] = stats.get("rounds", 0) + n_rounds
+                stats["pairs"] = stats.get("pairs", 0) + n_pairs
+            index, pos, ratio = fetched[j]
+            if as_arrays:
+                out[i] = (index, pos, ratio)
+            else:
+                out[i] = [(int(a), {"positions": p, "ratio": float(r)}) for a, p, r in zip(index, pos, ratio)]
     return out
 
 

@@ -230,32 +230,42 @@ class MatchGatherer(object):
         self.two_phase = bool(two_phase)
         self.rows_shipped = 0                      # rows per rank of the last collective (capacity unless two_phase)
         self._packed = None
+        self._phase2 = None                        # two_phase: slot whose counts are under way and whose rows are still to ship
 
     def _wait(self):
         for w in self.pending:
             w.wait()
         self.pending = []
+        if self._phase2 is not None:
+            # Second half of a counts-first gather, deferred to the NEXT submit (or finish): the host reads the counts
+            # only after the caller has enqueued the following step, so the step pipeline stays two deep (r03 read
+            # them inside submit_device and stalled the host on the step it had just enqueued).  The slot's send
+            # buffer is not handed out again before this point (double buffering).
+            k, self._phase2 = self._phase2, None
+            dist = self.dist
+            m = min(int(self.counts[k].max().item()), self.capacity)          # (the host waits for the counts here)
+            send = self.buf[k].view(self.pps, self.capacity, 3)[:, :m].contiguous().view(self.pps * m, 3)
+            recv = self.allbuf[k].view(-1)[:self.world * self.pps * m * 3].view(self.world * self.pps * m, 3)
+            if m:
+                if self.on_cpu:
+                    parts = [self.torch.empty_like(send) for _ in range(self.world)]
+                    dist.all_gather(parts, send, group=self.group)
+                    recv.copy_(self.torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(recv, send, group=self.group)
+                    self.torch.cuda.current_stream().synchronize()
+            self._packed = (recv, m, send)
+            self.rows_shipped = self.pps * m
 
     def _start(self, k):
         dist = self.dist
         self._packed = None
         if self.two_phase:
-            torch = self.torch
             if self.on_cpu:
-                dist.all_gather(list(self.counts[k].split(self.pps)), self.mine[k], group=self.group)
+                self.pending = [dist.all_gather(list(self.counts[k].split(self.pps)), self.mine[k], group=self.group, async_op=True)]
             else:
-                dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group)
-            m = min(int(self.counts[k].max().item()), self.capacity)          # (the host waits for the counts here)
-            send = self.buf[k].view(self.pps, self.capacity, 3)[:, :m].contiguous().view(self.pps * m, 3)
-            recv = torch.zeros((self.world * self.pps * m, 3), dtype=torch.int32, device=self.buf[k].device)
-            self.pending = []
-            if m:
-                if self.on_cpu:
-                    self.pending = [dist.all_gather(list(recv.split(self.pps * m)), send, group=self.group, async_op=True)]
-                else:
-                    self.pending = [dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)]
-            self._packed = (recv, m, send)
-            self.rows_shipped = self.pps * m
+                self.pending = [dist.all_gather_into_tensor(self.counts[k], self.mine[k], group=self.group, async_op=True)]
+            self._phase2 = k                       # the rows follow at the next submit / finish (_wait)
             self.last = k
             return
         self.rows_shipped = self.pps * self.capacity

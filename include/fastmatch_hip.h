@@ -84,7 +84,10 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "k1_order"     0..2   K1: how workgroups map to (output chunk, split of the reduction range): 0 split major,
  *                         1 the workgroups of one XCD own a set of output chunks for all splits, 2 they own a
  *                         contiguous share of the split-major order (the guide's XCD remap); see rowreduce.hip
+ *   "refill_grid"  1..    fm_bank_refill_u8_async: workgroups of its preparation kernel (128: few, long-lived ones beside
+ *                         the distance kernels)
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
+ *   "expand_huge"  0|1    K7: ... and those that still do in the variant that takes a radius subset of any size in chunks (1)
  *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
  *                         repeated in a run state four times as large (2)
  *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
@@ -349,8 +352,11 @@ typedef struct fm_expand_desc {
 
 #define FM_EXPAND_OK            0
 #define FM_EXPAND_STACK_FULL    1
-#define FM_EXPAND_SUBSET_FULL   2  /* a radius subset exceeded 4096 query rows (2048 for float32 banks):
-                                      * pairs that exceed 2048 are re-run by fm_expand_run in a larger-capacity kernel */
+#define FM_EXPAND_SUBSET_FULL   2  /* a radius subset the device could not take.  Integer-route pairs that exceed the first
+                                      * kernel's 2048 rows are re-run by fm_expand_run in a 4096-row kernel and then in one that
+                                      * takes a subset of ANY size in chunks (options expand_big / expand_huge); what is left:
+                                      * float32 banks beyond 2048 rows, pairs under the float32-root guard beyond 4096, more than
+                                      * 2048 keypoints at one distance, more than 2048 ACCEPTED matches in a single round      */
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
 #define FM_EXPAND_MATCH_FULL    4  /* 1, 4, 5: reported only when the run state could not grow any further */
 #define FM_EXPAND_TABLE_FULL    5
@@ -369,6 +375,14 @@ int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
 int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
                    const int64_t* n_seeds, const double* tau, int64_t* n_matches,
                    int64_t* n_rounds, int64_t* n_pairs, int32_t* status);
+/* Memory of the run states: fm_expand_info reports the bytes ONE run state of the pair takes (pending stack, seen /
+ * found tables, result arrays: ~210 MB for a 300k-keypoint pair) and how many exist; fm_expand_trim frees the states
+ * from slot `keep` (>= 1) on; fm_mem_info is hipMemGetInfo of the context's device.  fm_expand_run creates a state for
+ * every run of a launch and keeps it, so a caller that puts pairs x thresholds into one launch (turntable.py:59-60)
+ * sizes its launches with these (fastmatch.run_device_loops does) instead of meeting FM_ENOMEM.                    */
+int  fm_expand_info(const fm_expand* ex, int64_t* state_bytes, int32_t* n_slots);
+int  fm_expand_trim(fm_ctx* ctx, fm_expand* ex, int32_t keep);
+int  fm_mem_info(fm_ctx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 /* Copy the first n results of the last run in slot 0 of `ex`: query row index, positions [n][2][2]
  * (query x,y then target x,y) and ratio -- the tuples do_iter appends (fastmatch.pyx:86). */
 int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index,

@@ -232,6 +232,100 @@ static void xcheck(const orc_mat* Q, int64_t nq, const orc_mat* T, int64_t nt,
     free(rq); free(rd);
 }
 
+/* ---- the same cross-check, vectorised (a second CPU baseline; results identical) ----------------------
+ * The loops above are the faithful restatement: one pair at a time, ~1 multiply-add per cycle and thread, every
+ * output row streaming the whole other bank through the caches.  A CPU would not be programmed that way either, so
+ * bench.py reports a second figure from this form: uint8 rows widened to int16, differences squared and summed with
+ * vpmaddwd (AVX2: 16 products per instruction), eight output rows per pass over the other bank.  Same semantics,
+ * bit for bit: candidates in ascending index order, compared on the float32 root with a strict '<' (the integer test
+ * d2 <= best d2 in front of it only skips pairs that cannot pass: sqrtf is monotone).                                */
+#if defined(__AVX2__)
+#include <immintrin.h>
+#define ORC_SIMD_BLOCK 8
+static void knn1_rows_u8_simd(const uint8_t* A, int64_t na, const uint8_t* B, int64_t nb, int dim,
+                              int32_t* idx, float* dist, int threads)
+{
+    const int dpad = (dim + 15) & ~15;
+    {
+        int64_t cap = (na * nb) / 400000 + 1;
+        if (cap < threads) threads = (int)cap;
+        if (threads < 1) threads = 1;
+    }
+    const int64_t nblk = (na + ORC_SIMD_BLOCK - 1) / ORC_SIMD_BLOCK;
+#pragma omp parallel num_threads(threads)
+    {
+        int16_t* a16 = (int16_t*)aligned_alloc(32, sizeof(int16_t) * (size_t)ORC_SIMD_BLOCK * (size_t)dpad);
+        int16_t* b16 = (int16_t*)aligned_alloc(32, sizeof(int16_t) * (size_t)dpad);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t blk = 0; blk < nblk; blk++) {
+            const int64_t i0 = blk * ORC_SIMD_BLOCK;
+            const int rows = (int)((na - i0) < ORC_SIMD_BLOCK ? (na - i0) : ORC_SIMD_BLOCK);
+            float bd[ORC_SIMD_BLOCK];
+            int32_t bi[ORC_SIMD_BLOCK], b2[ORC_SIMD_BLOCK];
+            for (int r = 0; r < ORC_SIMD_BLOCK; r++) {
+                bd[r] = FLT_MAX; bi[r] = -1; b2[r] = INT32_MAX;
+                for (int k = 0; k < dpad; k++)
+                    a16[r * dpad + k] = (r < rows && k < dim) ? (int16_t)A[(i0 + r) * dim + k] : 0;
+            }
+            for (int64_t j = 0; j < nb; j++) {
+                for (int k = 0; k < dpad; k++) b16[k] = k < dim ? (int16_t)B[j * dim + k] : 0;
+                for (int r = 0; r < rows; r++) {
+                    __m256i acc = _mm256_setzero_si256();
+                    for (int k = 0; k < dpad; k += 16) {
+                        const __m256i d = _mm256_sub_epi16(_mm256_load_si256((const __m256i*)(a16 + r * dpad + k)),
+                                                           _mm256_load_si256((const __m256i*)(b16 + k)));
+                        acc = _mm256_add_epi32(acc, _mm256_madd_epi16(d, d));
+                    }
+                    __m128i s = _mm_add_epi32(_mm256_castsi256_si128(acc), _mm256_extracti128_si256(acc, 1));
+                    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4e));
+                    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xb1));
+                    const int32_t d2 = _mm_cvtsi128_si32(s);
+                    if (d2 <= b2[r]) {
+                        const float d = sqrtf((float)d2);
+                        if (d < bd[r]) { bd[r] = d; bi[r] = (int32_t)j; b2[r] = d2; }
+                    }
+                }
+            }
+            for (int r = 0; r < rows; r++) { idx[i0 + r] = bi[r]; dist[i0 + r] = bi[r] < 0 ? INFINITY : bd[r]; }
+        }
+        free(a16); free(b16);
+    }
+}
+#endif
+
+ORC_API int orc_have_simd(void)
+{
+#if defined(__AVX2__)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+/* orc_bf_xcheck1_u8 through the vectorised reverse-NN scan; -2 where the build has no AVX2. */
+ORC_API int orc_bf_xcheck1_u8_simd(const uint8_t* Q, int64_t nq, const uint8_t* T, int64_t nt, int dim,
+                                   int32_t* tidx_out, float* dist_out, int threads)
+{
+#if defined(__AVX2__)
+    if (dim < 1) return -1;
+    int32_t* rq = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+    float* rd = (float*)malloc(sizeof(float) * (size_t)(nt > 0 ? nt : 1));
+    knn1_rows_u8_simd(T, nt, Q, nq, dim, rq, rd, nthreads(threads));
+    for (int64_t q = 0; q < nq; q++) { dist_out[q] = FLT_MAX; tidx_out[q] = -1; }
+    for (int64_t i = 0; i < nt; i++) {
+        const int32_t q = rq[i];
+        if (q < 0) continue;
+        if (rd[i] < dist_out[q]) { dist_out[q] = rd[i]; tidx_out[q] = (int32_t)i; }
+    }
+    for (int64_t q = 0; q < nq; q++) if (tidx_out[q] < 0) dist_out[q] = INFINITY;
+    free(rq); free(rd);
+    return 0;
+#else
+    (void)Q; (void)nq; (void)T; (void)nt; (void)dim; (void)tidx_out; (void)dist_out; (void)threads;
+    return -2;
+#endif
+}
+
 ORC_API int orc_bf_xcheck1_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim,
                                int order, int32_t* tidx, float* dist, int threads)
 {

@@ -8,8 +8,11 @@ configs[3]  batch of 64 independent 1-MP pairs (1000 x 1000, 12 500 keypoints pe
             FM_C4_ORACLE_PAIRS (default 8) of them.
 
 The oracle's radius and cell look-ups are O(N) NumPy scans (~4 ms per round at 300k
-keypoints), so the full config-2 run costs the oracle a few minutes of host time;
-FM_C3_ORACLE_ROUNDS=<n> caps it (the capped match list is a prefix of the full one).
+keypoints), so the full config-2 run costs the oracle 4.5 minutes of host time.  By default (r04:
+the driver's limit for the whole GPU suite is 20 minutes) the replay stops after 12 000 of the
+41 704 rounds -- its match list is then a prefix of the full one, compared as such; the device loop
+and the host-driven loop are still compared over ALL rounds.  FM_C3_ORACLE_ROUNDS=0 replays everything
+(r02 / r03 ran it in full: equal), FM_C3_ORACLE_ROUNDS=<n> picks another cap.
 """
 import os
 
@@ -71,10 +74,10 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
     _same_matches(dev, host)
     assert len(dev) > 20000
 
-    cap = os.environ.get("FM_C3_ORACLE_ROUNDS")
-    oget = fo.o_match(oq, ot, {"max_rounds": int(cap)} if cap else {})
+    cap = int(os.environ.get("FM_C3_ORACLE_ROUNDS", "12000"))
+    oget = fo.o_match(oq, ot, {"max_rounds": cap} if cap else {})
     exp = oget(0.7)
-    if cap and oget.rounds >= int(cap):
+    if cap and oget.rounds >= cap:
         assert len(exp) > 0
         _same_matches(dev[:len(exp)], exp)
     else:

@@ -321,6 +321,35 @@ def test_evaluate_many_thresholds_reuses_state(ctx):
     assert dev[2]["precision"] > 0.7
 
 
+def test_many_runs_are_cut_into_launches_that_fit_the_memory(ctx, monkeypatch):
+    """every (pair, threshold) run of a launch gets a run state of its own and keeps it; when the states a
+    launch would create exceed the free memory the run list is cut into several launches that re-use the slots
+    (fastmatch._launch_plan), an FM_ENOMEM launch is halved, and slots can be given back (Expander.trim)."""
+    mcs = [_build((640, 480), 2500, seed=610 + k, ctx=ctx) for k in range(2)]
+    gets = [fastmatch.match(mc, fi, {"context": ctx, "return_arrays": True}) for mc, fi, _, _ in mcs]
+    taus = [0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+    exs = [g.expander() for g in gets for _ in taus]
+    sds = [g.seeds_for(t) for g in gets for t in taus]
+    tts = [t for _ in gets for t in taus]
+    st0 = {}
+    ref = fastmatch.run_device_loops(ctx, exs, sds, tts, stats=st0, as_arrays=True)
+    assert "device_launches" not in st0 and st0["device_loops"] == 12
+    state_bytes, slots = exs[0].info()
+    assert slots == 6 and state_bytes > 1 << 20
+    for ex in set(exs):
+        ex.trim(1)
+    assert exs[0].info()[1] == 1
+    real = ctx.mem_info()
+    assert real[0] > 1 << 30 and real[1] >= real[0]
+    monkeypatch.setattr(ctx, "mem_info", lambda: (int(4.5 * state_bytes), real[1]))     # room for two new states per launch
+    st1 = {}
+    got = fastmatch.run_device_loops(ctx, exs, sds, tts, stats=st1, as_arrays=True)
+    assert st1.get("device_launches", 0) >= 3 and st1["device_loops"] == 12 and st1["rounds"] == st0["rounds"]
+    for a, b in zip(got, ref):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert max(ex.info()[1] for ex in set(exs)) <= 3
+
+
 def test_many_thresholds_of_one_pair_in_one_launch(ctx, monkeypatch):
     """get_matches([taus]) runs every threshold of the pair in ONE launch of the device loop (one
     workgroup and one run state each): each list equals the single-threshold call and the oracle, in

@@ -14,5 +14,6 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("seed0", [1000, 777000, 20261003])
 def test_fixed_fuzz_slice_equals_oracle(ctx, seed0):
     import gpu_fuzz
-    n, counts = gpu_fuzz.run(budget=120.0, seed0=seed0, max_problems=24, context=ctx)
+    # (no wall-clock budget: only the fixed seed slice decides, a loaded host cannot end it early)
+    n, counts = gpu_fuzz.run(budget=float("inf"), seed0=seed0, max_problems=24, context=ctx)
     assert n == 24 and counts.get("match", 0) == 6 and len(counts) >= 4

@@ -83,8 +83,15 @@ def test_metric_cache_save_load_roundtrip(tmp_path):
     assert name == cache._ripemd160(b"images/graf/img4.ppm")
     assert os.path.isfile(os.path.join(str(tmp_path), name + ".npz"))
     assert os.path.isfile(os.path.join(str(tmp_path), name + "_thumb.npz"))
-    with np.load(os.path.join(str(tmp_path), name + ".npz")) as z:   # the reference's key set
-        assert set(z.files) == {"descriptors", "positions", "distances", "position_tree", "size"}
+    with np.load(os.path.join(str(tmp_path), name + ".npz")) as z:   # the reference's key set (+ the metric's name)
+        assert set(z.files) == {"descriptors", "positions", "distances", "position_tree", "size", "fm_metric"}
+        # what the reference does with the file at load (cache.pyx:237): unpickle the tree and query it
+        import pickle
+        tree = pickle.loads(z["position_tree"].tobytes())
+        if tree is not None:                                          # (scikit-learn present: a real BallTree)
+            ind, dist = tree.query_radius(np.array([[100.0, 100.0]]), r=50, return_distance=True, sort_results=True)
+            got, d2 = mc.original["position_tree"].radius(100, 100, 50)
+            assert sorted(ind[0].tolist()) == sorted(got.tolist()) and np.allclose(np.sort(dist[0]), np.sqrt(np.sort(d2)))
     mc2 = cache.Metric_Cache(None)
     mc2.path = b"images/graf/img4.ppm"
     assert mc2.load(str(tmp_path))
@@ -96,6 +103,16 @@ def test_metric_cache_save_load_roundtrip(tmp_path):
     mc3 = cache.Metric_Cache(None)
     mc3.path = b"some/other/path"
     assert mc3.load(str(tmp_path)) is False
+    # the metric travels with the file (the reference's pickled tree keeps the metric it was built with, cache.pyx:276)
+    mm = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], distances=sd, thumb_distances=tsd,
+                                        path=b"manhattan/img", options={"metric": "manhattan"})
+    mm.save(str(tmp_path))
+    back = cache.Metric_Cache(None)                                    # (default options: "minkowski")
+    back.path = b"manhattan/img"
+    assert back.load(str(tmp_path))
+    assert np.array_equal(back.get(100, 100, 50)[3], mm.get(100, 100, 50)[3])
+    assert not np.array_equal(back.get(100, 100, 50)[3], mc.get(100, 100, 50)[3])
 
 
 def test_matches_from_arrays_drops_missing():
@@ -156,3 +173,36 @@ def test_homography_and_planted_scorers(tmp_path):
     p = np.array([[[0, 0], [7.0, 8.0]], [[0, 0], [5.0, 5.0]], [[0, 0], [9.0, 9.0]]])
     assert sc(np.array([0, 1, 2]), p, None).tolist() == [True, False, False]
     assert sc(np.array([], dtype=int), np.zeros((0, 2, 2)), None).shape == (0,)
+
+
+def test_launch_plan_keeps_new_run_states_inside_the_memory_budget():
+    """fastmatch._launch_plan: pairs x thresholds in one launch create one run state per run; the plan cuts
+    the list where the NEW states would exceed the budget, keeps the order, and counts states that already exist as free."""
+    from fastmatch_amd import fastmatch
+
+    class Ex(object):
+        def __init__(self, state_bytes, slots):
+            self.b, self.k = state_bytes, slots
+
+        def info(self):
+            return self.b, self.k
+
+    class Ctx(object):
+        def __init__(self, free):
+            self.free = free
+
+        def mem_info(self):
+            return self.free, 10 * self.free
+
+    a, b, c = Ex(100, 1), Ex(100, 1), Ex(100, 1)
+    runs = [a] * 5 + [b] * 5 + [c] * 5
+    # budget = 0.5 * free; 15 runs need 12 new states of 100
+    assert fastmatch._launch_plan(Ctx(10 ** 9), runs) == [list(range(15))]
+    plan = fastmatch._launch_plan(Ctx(800), runs)                  # 400 of budget: 4 new states per launch
+    assert [i for l in plan for i in l] == list(range(15)) and len(plan) > 1
+    for l in plan:
+        assert len(l) >= 1
+    # states that exist are free: an expander with 5 slots adds nothing
+    assert fastmatch._launch_plan(Ctx(2), [Ex(100, 5)] * 5) == [list(range(5))]
+    # a single run that does not fit still gets a launch of its own (the launch then reports FM_ENOMEM -> host loop)
+    assert fastmatch._launch_plan(Ctx(2), [Ex(100, 0), Ex(100, 0)]) == [[0], [1]]

@@ -122,3 +122,24 @@ def test_far_banks_separate_float_order_from_integer_order():
     # and the oracle is the float32 order: stable sort on the float32 roots
     by_f32 = np.argsort(np.sqrt(d2.astype(np.float32)), axis=1, kind="stable")[:, :2]
     assert np.array_equal(idx, by_f32)
+
+
+def test_vectorised_baseline_equals_the_faithful_scan():
+    """oracle.bf_xcheck1_simd (bench.py's second CPU baseline: int16 differences + vpmaddwd, eight output rows per pass)
+    returns what the one-pair-at-a-time restatement returns, bit for bit -- sizes around the block of eight, dim < 128,
+    duplicates, empty banks and the float32-root tie range."""
+    import oracle as orc
+    if not orc._lib().orc_have_simd():
+        pytest.skip("liboracle.so was built without AVX2")
+    rng = np.random.default_rng(31)
+
+    def same(Q, T):
+        a, b = orc.bf_xcheck1(Q, T), orc.bf_xcheck1_simd(Q, T)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    for nq, nt, dim in [(1, 1, 128), (7, 9, 128), (8, 8, 128), (9, 17, 128), (300, 200, 128), (200, 300, 100), (50, 64, 3), (0, 5, 128), (5, 0, 128)]:
+        Q = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+        T = rng.integers(0, 256, (nt, dim), dtype=np.uint8)
+        if nq > 20 and nt > 20:
+            T[3] = Q[5]; T[11] = Q[5]; Q[17] = Q[5]
+        same(Q, T)
+    same(*far_banks(300, 200, rng))

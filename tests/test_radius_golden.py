@@ -167,8 +167,14 @@ def test_metric_cache_save_round_trips_in_the_reference_layout(tmp_path, monkeyp
     assert name == cache._ripemd160(NPZ_PATH.encode())
     a = np.load(str(out / (name + ".npz")), allow_pickle=False)
     b = np.load(str(out / (name + "_thumb.npz")), allow_pickle=False)
-    assert sorted(a.files) == ["descriptors", "distances", "position_tree", "positions", "size"]
+    # the reference's keys (cache.pyx:199-210) + the name of the metric (the reference reads its keys by name)
+    assert sorted(a.files) == ["descriptors", "distances", "fm_metric", "position_tree", "positions", "size"]
     assert sorted(b.files) == ["descriptors", "distances", "positions", "size"]
+    # what the reference does with the file (cache.pyx:237: pickle.loads(position_tree), then query_radius at the first
+    # get): a real sklearn BallTree is in there, answering like the tree the fixture was written with
+    tree = pickle.loads(a["position_tree"].tobytes())
+    ind, dist = tree.query_radius(np.array([[400.0, 320.0]]), r=100, return_distance=True, sort_results=True)
+    assert np.array_equal(ind[0], mc.get(400, 320, 100)[3]) and len(ind[0]) > 3
     for k in ("descriptors", "positions", "distances"):
         assert np.array_equal(a[k], mc.original[k]) and np.array_equal(b[k], mc.thumb[k])
     assert a["size"].tolist() == [800, 640] and b["size"].tolist() == [600, 480]
