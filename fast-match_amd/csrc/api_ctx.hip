@@ -244,7 +244,7 @@ static const OptionDef kOptions[] = {
     {"f32_lpc", &Tuning::f32_lpc, 0, 64, "FM_F32_LPC"},
     {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
-    {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"}, {"refill_grid", &Tuning::refill_grid, 1, 1 << 20, "FM_REFILL_GRID"},
+    {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"}, {"bound_every", &Tuning::bound_every, 1, 1024, "FM_BOUND_EVERY"}, {"refill_grid", &Tuning::refill_grid, 1, 1 << 20, "FM_REFILL_GRID"},
     {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_huge", &Tuning::expand_huge, 0, 1, nullptr}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
 };
 

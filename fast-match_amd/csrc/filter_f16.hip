@@ -247,7 +247,7 @@ void filter_kernel(FParams p)
 #ifdef FM_ABLATE_F32_NOEXACT
             // ablation build only (scripts/README.md): what the filter costs when NO unit takes the exact path -- the
             // ceiling of anything a different lane mapping could save there.  Results are wrong in this build.
-            any = false;
+            any = any && p.nstages < 0;         // (never true; a constant would let the compiler drop the MFMAs with the path)
 #endif
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 const int row0 = (st * (kFStageRows / 16) + 2 * u) * 16 + 4 * g;

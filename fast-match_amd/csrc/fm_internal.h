@@ -77,6 +77,9 @@ struct Tuning {
     int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a
                                       // state four times as large (0 = never: the status goes to the caller)
     int expand_prof = 0;              // K7: per-phase timers of pair 0 on stderr
+    int bound_every = 16;             // K1 / K2: re-read the shared bounds every n-th stage once a sweep is 8 stages old (a power of
+                                      // two; r04 A/B on two boxes, ms per pair in the 12-pair launch: 1 -> 0.8356 / 0.8501, 8 -> 0.8290 /
+                                      // 0.8399, 32 -> 0.8277, 1024 -> 0.8340: profiles/r04c_k1_bound_every_*)
     int refill_grid = 128;            // fm_bank_refill_u8_async: workgroups of the preparation kernel (each walks its share of the tiles)
     int k1_order = 0;                 // K1: workgroup -> (chunk, split) mapping (rowreduce.hip, map_block): 0 split major,
                                       // 1 an XCD owns output chunks, 2 an XCD owns a contiguous share of the split-major order
@@ -97,6 +100,7 @@ struct RowReducePlan {
     int nbuf = 0;      // stage buffers (0 = rule: 3 for top-1, 2 for top-2)
     int prio = 1;      // s_setprio around the MFMA burst
     int order = 0;     // Tuning::k1_order
+    int bound_every = 1;   // Tuning::bound_every
     size_t partial_bytes(int ktop) const { return (size_t)nsplit * ncols_alloc * ktop * 8; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 4 * 2; }   // (top-2 launches keep two arrays)
 };

@@ -66,6 +66,8 @@ struct RRParams {
     unsigned long long* partial;
     int*           bound;         // [ncols_alloc] shared K-th-best bounds (INT32_MIN filled) or null
     int            order;         // workgroup -> (chunk, split) mapping, see map_block
+    int            bound_mask;    // shared bounds are re-read at every stage of a sweep's first 8 and then at the stages
+                                  // whose number & bound_mask == 0 (0: every stage; option "bound_every" 1 | 2 | 4 | 8)
 };
 
 // Accumulator value of a masked (output row == reduced row) pair in the SELF kernels: below the padding
@@ -295,7 +297,10 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         if constexpr (NBUF == 2) {
             if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
         }
-        if (p.bound) {
+        // (a bound that is a few stages old is merely weaker; late in a sweep the bounds hardly move, and each of these loads
+        // is an agent-scope read that goes past the XCD's L2: 5e6 of them per 100k x 100k pair were 3/4 of the kernel's
+        // fabric traffic -- r04: re-read at every stage only while the sweep is young)
+        if (p.bound && (st - st0 < 8 || ((st - st0) & p.bound_mask) == 0)) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int n = cb + 16 * j + c16;
@@ -501,6 +506,8 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& 
     pl.nbuf = (tn.nbuf == 2 || tn.nbuf == 3) ? tn.nbuf : 0;
     pl.prio = tn.prio;
     pl.order = (tn.k1_order >= 0 && tn.k1_order <= 2) ? tn.k1_order : 0;
+    pl.bound_every = 1;
+    for (int b = 2; b <= 1024; b <<= 1) if (tn.bound_every == b) pl.bound_every = b;      // (powers of two: the test is a mask)
     const int64_t nstages = nred_pad / kStageRows;
     // nb = blocks of 16 output rows per wave: 4 (64 rows, ~110 VGPRs, 4 waves/SIMD) by default,
     // 8 via FM_NB; nw = waves per workgroup sharing the staged tiles: 8 for big problems,
@@ -610,6 +617,7 @@ static void fill_params(RRParams& p, const Bank& cols, const Bank& red, const Ro
     p.ncols_alloc = plan.ncols_alloc;
     p.partial = partial;
     p.order = plan.order;
+    p.bound_mask = plan.bound_every > 1 ? plan.bound_every - 1 : 0;
 }
 
 int rowreduce_grid(const RowReducePlan& plan) { return blocks_per_pair(plan.nchunks, plan.nsplit, plan.order); }

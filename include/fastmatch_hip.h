@@ -84,6 +84,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "k1_order"     0..2   K1: how workgroups map to (output chunk, split of the reduction range): 0 split major,
  *                         1 the workgroups of one XCD own a set of output chunks for all splits, 2 they own a
  *                         contiguous share of the split-major order (the guide's XCD remap); see rowreduce.hip
+ *   "bound_every"  1..1024  K1 / K2: workgroups re-read the shared K-th-best bounds at every stage of a sweep's first
+ *                         eight and then at every n-th (a power of two; 16).  A stale bound is merely weaker
  *   "refill_grid"  1..    fm_bank_refill_u8_async: workgroups of its preparation kernel (128: few, long-lived ones beside
  *                         the distance kernels)
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)

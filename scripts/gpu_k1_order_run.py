@@ -6,12 +6,13 @@ import numpy as np
 import fastmatch_amd as fm
 from fastmatch_amd import synth
 
-order, launches = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 4
+order, launches = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4       # "2" or "bound_every=4,k1_order=0"
 NP = 12
 ctx = fm.Context(0)
 ctx.set_option("batch_group", 16)
 ctx.set_option("batch_tail", 0)
-ctx.set_option("k1_order", order)
+for kv in (order if "=" in order else "k1_order=%s" % order).split(","):
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 Q, T, _ = synth.planted_pair(100000, 100000, 20250002)
 rng = np.random.default_rng(1)
 banks = []

@@ -15,7 +15,9 @@ from fastmatch_amd import synth, _ffi
 
 NP = int(os.environ.get("FM_AB_PAIRS", "12"))
 ROUNDS = int(os.environ.get("FM_AB_ROUNDS", "5"))
-ORDERS = [int(x) for x in (sys.argv[1:] or ["0", "1", "2"])]
+# variants: a bare number = k1_order, or option lists "bound_every=4,k1_order=2" (fm_ctx_set_option names)
+ORDERS = [x if "=" in x else "k1_order=%s" % x for x in (sys.argv[1:] or ["0", "1", "2"])]
+BASE = {"k1_order": 0, "bound_every": 1}
 ctx = fm.Context(0)
 ctx.set_option("batch_group", 16)
 ctx.set_option("batch_tail", 0)
@@ -68,7 +70,10 @@ res = {o: {"batch_k": [], "batch_wall": [], "k1": [], "self": [], "clk": []} for
 ref = None
 for rnd in range(ROUNDS + 1):
     for o in ORDERS:
-        ctx.set_option("k1_order", o)
+        for k, v in BASE.items():
+            ctx.set_option(k, v)
+        for kv in o.split(","):
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         k, w = batch_run()
         clk = clock_mhz()
         qb, tb = banks[0]
@@ -93,7 +98,7 @@ for rnd in range(ROUNDS + 1):
 for o in ORDERS:
     r = res[o]
     med = lambda v: float(np.median(v))
-    print("k1_order %d: batched launch %.4f ms kernel / %.4f ms wall per image pair (min %.4f / %.4f) | one pair per launch %.4f ms | "
+    print("%s: batched launch %.4f ms kernel / %.4f ms wall per image pair (min %.4f / %.4f) | one pair per launch %.4f ms | "
           "self sweep %.4f ms | in-kernel clock %s MHz"
           % (o, med(r["batch_k"]), med(r["batch_wall"]), min(r["batch_k"]), min(r["batch_wall"]), med(r["k1"]), med(r["self"]),
              ("%.0f" % med([c for c in r["clk"] if c])) if any(r["clk"]) else "n/a (build with -DFM_CLOCK_STAMP)"), flush=True)

@@ -8,20 +8,24 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 RUN="$PWD/scripts/gpu_k1_order_run.py"
 cd /tmp
-for O in ${ORDERS:-0 1 2}; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/o${O}_trace -- python3 $RUN $O 6 > $OUT/o${O}_trace.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/o${O}_fetch -- python3 $RUN $O 3 > /dev/null 2> $OUT/o${O}_fetch.err
-  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/o${O}_write -- python3 $RUN $O 3 > /dev/null 2> $OUT/o${O}_write.err
-  timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/o${O}_tcc -- python3 $RUN $O 3 > /dev/null 2> $OUT/o${O}_tcc.err
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/o${O}_sq -- python3 $RUN $O 3 > /dev/null 2> $OUT/o${O}_sq.err
+I=0
+: > $OUT/variants.txt
+for V in ${ORDERS:-0 1 2}; do      # a bare number = k1_order, or an option list like bound_every=4,k1_order=0
+  O=v$I; I=$((I+1)); echo "$O $V" >> $OUT/variants.txt
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/o${O}_trace -- python3 $RUN $V 6 > $OUT/o${O}_trace.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/o${O}_fetch -- python3 $RUN $V 3 > /dev/null 2> $OUT/o${O}_fetch.err
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/o${O}_write -- python3 $RUN $V 3 > /dev/null 2> $OUT/o${O}_write.err
+  timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/o${O}_tcc -- python3 $RUN $V 3 > /dev/null 2> $OUT/o${O}_tcc.err
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/o${O}_sq -- python3 $RUN $V 3 > /dev/null 2> $OUT/o${O}_sq.err
 done
 cd $OUT
 python3 - <<'PY'
 import csv, glob, os, collections
 rows = []
-for d in sorted(glob.glob("o*_*")):
+names = dict(l.split() for l in open("variants.txt") if l.strip())
+for d in sorted(glob.glob("ov*_*")):
     if not os.path.isdir(d): continue
-    order, what = d[1], d.split("_", 1)[1]
+    order, what = names.get(d.split("_")[0][1:], d.split("_")[0][1:]), d.split("_", 1)[1]
     if what == "trace":
         for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
             dur = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -38,7 +42,7 @@ for d in sorted(glob.glob("o*_*")):
         for k, (s, n) in sorted(agg.items()):
             rows.append((order, k, s / n, n))
 with open("k1_xcd_summary.csv", "w") as w:
-    w.write("k1_order,counter,mean_per_12_pair_launch,launches\n")
+    w.write("variant,counter,mean_per_12_pair_launch,launches\n")
     for r in rows: w.write("%s,%s,%.1f,%d\n" % r)
 print(open("k1_xcd_summary.csv").read())
 PY

@@ -880,7 +880,7 @@ def test_results_do_not_depend_on_the_options():
     oi, od = oracle.bf_knn(Q, T, 2)
     assert _eq(ref[0], oi) and _eq(ref[1], od)
     domains = {"nsplit": [0, 1, 2, 5, 12], "nb": [0, 4, 8], "nw": [0, 4, 8], "nbuf": [0, 2, 3], "prio": [0, 1],
-               "glds": [0, 1], "coop": [0, 1], "async_time_every": [0, 1, 4]}
+               "glds": [0, 1], "coop": [0, 1], "async_time_every": [0, 1, 4], "bound_every": [1, 2, 8, 64, 1024], "k1_order": [0, 1, 2]}
     defaults = {k: c.get_option(k) for k in domains}
     rng = np.random.default_rng(7)
     settings = [{k: v} for k, vs in domains.items() for v in vs]
