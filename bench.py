@@ -874,10 +874,14 @@ def main():
                          "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms * pairs_per_launch,
                          "image_pairs_per_launch": pairs_per_launch,
                          "kernel_launches_timed": st["kernel_launches"],
+                         "algorithmic_bytes_per_launch": st.get("bytes_moved", 0) / max(st["kernel_launches"], 1),
+                         "algorithmic_gbps": st.get("bytes_moved", 0) / max(st["kernel_ms"], 1e-9) / 1e6,
                          "hbm_gbps": (traffic / (k_ms * pairs_per_launch * 1e-3) / 1e9) if traffic else None,
                          "hbm_frac_of_8tbps": (traffic / (k_ms * pairs_per_launch * 1e-3) / 8e12) if traffic else None,
                          "mfma_pipe_busy_frac": busy,
                          "note": "int8 ops: 256 per descriptor pair x 1e10 descriptor pairs per image pair x image_pairs_per_launch; "
+                                 "algorithmic_bytes_per_launch = fm_stats_ex.bytes_moved / launches (every bank row of a launch read once: "
+                                 "2 x 100k x 128 B per image pair) -- 0.03 TB/s, the path is MFMA-bound by a factor of 270; "
                                  "kernel_ms = HIP-event time of the distance-kernel launches of the timed region (events on the "
                                  "library's own stream) per image pair, kernel_ms_per_launch = per launch; traffic / hbm_gbps = PMC HBM bytes "
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "

@@ -259,11 +259,22 @@ void filter_kernel(FParams p)
                         // P-step insertion costs ~6 VALU per step, so it runs only for the rows
                         // that some lane actually wants (wave-uniform skip; a row below the lane's
                         // threshold leaves its list unchanged either way).
+                        // (r04: the eight wave-wide tests first, back to back, as scalar masks -- the loop below then branches
+                        // on SGPRs.  Written as "compare, ballot, branch" per row the compiler emitted v_cmp -> vcc ->
+                        // s_cbranch_vccz eight times in a row, every branch waiting for the vector compare in front of it.)
+                        unsigned long long wm[8];
+#ifndef FM_K8_OLD_VISIT
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) wm[r] = __builtin_amdgcn_ballot_w64(acc[r >> 2][j][r & 3] >= thr[j]);
+#endif
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {                   // ascending row order
+#ifdef FM_K8_OLD_VISIT
+                            wm[r] = __builtin_amdgcn_ballot_w64(acc[r >> 2][j][r & 3] >= thr[j]);      // (A/B builds only: r01 - r03's form)
+#endif
+                            if (wm[r] == 0ull) continue;
                             const float av = acc[r >> 2][j][r & 3];
                             const bool want = av >= thr[j];
-                            if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
                             float a = want ? av : -INFINITY;
                             int id = row0 + 16 * (r >> 2) + (r & 3);
 #pragma unroll
