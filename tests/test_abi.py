@@ -48,3 +48,16 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src, f
+
+
+def test_abi_revision_of_header_library_and_binding_agree():
+    """fm_abi_version() (a signature changed without a version to check): the header's FM_ABI_VERSION, what the
+    built library returns and what the ctypes binding was written for are one number, and the size-checked statistics
+    struct of the binding has the header's layout."""
+    hdr = open(os.path.join(ROOT, "include", "fastmatch_hip.h")).read()
+    ver = int(re.search(r"#define\s+FM_ABI_VERSION\s+(\d+)", hdr).group(1))
+    lib = _ffi.load_library()
+    assert lib.fm_abi_version() == ver == _ffi.FM_ABI_VERSION
+    fields = re.search(r"typedef struct fm_stats_ex \{(.*?)\} fm_stats_ex;", hdr, flags=re.S).group(1)
+    names = re.findall(r"\b([a-z_]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
+    assert names == [f[0] for f in _ffi.fm_stats_ex._fields_]

@@ -51,7 +51,8 @@ def banks(rng):
 def fuzz_operators(rng):
     kind, Q, T = banks(rng)
     for k, v in (("nsplit", int(rng.choice([0, 0, 1, 3, 8, 13]))), ("nbuf", int(rng.choice([0, 2, 3]))),
-                 ("coop", int(rng.integers(0, 2))), ("f32_filter", int(rng.choice([0, 0, 1, 2])))):
+                 ("coop", int(rng.integers(0, 2))), ("f32_filter", int(rng.choice([0, 0, 1, 2]))),
+                 ("k1_order", int(rng.choice([0, 0, 1, 2]))), ("bound_every", int(rng.choice([1, 2, 16, 16, 64, 1024])))):
         ctx.set_option(k, v)
     qb, tb = ctx.bank(Q), ctx.bank(T)
     order = 1 if kind == "nonint" else 0                 # the device's fixed float32 accumulation order
@@ -68,6 +69,18 @@ def fuzz_operators(rng):
             assert eq(t, ot) and eq(x, ox), tag
     elif what == "selfdist":
         assert eq(ctx.self_dist(qb), oracle.self_dist(Q, order=order)), tag
+        # r04: the batched form (both banks + a copy of the first: banks of one size share a launch) and a refill
+        qc = ctx.bank(Q)
+        for g, M in zip(ctx.self_dist_batch([qb, tb, qc]), (Q, T, Q)):
+            assert eq(g, oracle.self_dist(M, order=order)), tag
+        if Q.dtype == np.uint8 and Q.shape[0] > 1:
+            m = int(rng.integers(1, Q.shape[0] + 1))
+            src = ctx.pinned_empty((m, Q.shape[1]), np.uint8)
+            src[:] = Q[rng.permutation(Q.shape[0])[:m]]
+            qc.refill_async(src)
+            ctx.upload_fence()
+            (g,) = ctx.self_dist_batch([qc])
+            assert eq(g, oracle.self_dist(np.array(src), order=order)), tag + ("refill", m)
     else:
         sd = oracle.self_dist(Q, order=order)
         qb.set_selfdist(sd)
@@ -102,10 +115,15 @@ def fuzz_match(rng):
         opts["grid_margin"] = int(rng.integers(0, 45))
     if rng.integers(0, 2):
         opts["radius"] = int(rng.integers(20, 160))
+    elif rng.integers(0, 4) == 0:
+        opts["radius"] = int(rng.integers(160, 400))          # subsets beyond the LDS tables: the 4096-row and the chunked kernel
     if rng.integers(0, 3) == 0:
         opts["metric"] = str(rng.choice(["euclidean", "chebyshev", "manhattan"]))
     seed = int(rng.integers(1 << 30))
-    q, t = synth.image_pair((w, h), n, seed, n_thumb=min(600, n))
+    kw = {}
+    if rng.integers(0, 3) == 0:                               # r04: clustered keypoints
+        kw = {"clusters": int(rng.integers(1, 5)), "cluster_sigma": float(rng.uniform(8.0, 60.0)), "cluster_frac": float(rng.uniform(0.2, 0.9))}
+    q, t = synth.image_pair((w, h), n, seed, n_thumb=min(600, n), **kw)
     mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
                                         q["thumb_positions"], q["thumb_size"], options=dict(opts, context=ctx))
     fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
@@ -119,7 +137,7 @@ def fuzz_match(rng):
     get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4))))
     oget = fo.o_match(oq, ot, dict(opts))
     taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
-    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus)
+    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()))
     if rng.integers(0, 2) and len(taus) > 1:
         got_all = get(taus)
     else:
@@ -137,7 +155,7 @@ def run(budget, seed0, max_problems=None, context=None):
     Returns (problems, counts by kind); raises AssertionError at the first difference."""
     global ctx
     ctx = context if context is not None else fm.Context(0)
-    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter")}
+    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter", "k1_order", "bound_every")}
     counts = {}
     t0, it = time.time(), 0
     try:
