@@ -313,30 +313,35 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // the int8 and the float32 pairs are different kernels, and so are the capacity tiers of the int8 one (a pair starts
     // in the tier its last complete run needed): descriptors grouped by kernel, one launch each
     std::vector<char> big((size_t)n, 0);          // capacity tier of the run's last launch (launch_expand)
+    auto huge_ok = [&](int i) { return ctx->tune.expand_huge != 0 && (host[i].f32 || !host[i].tie_guard); };
     for (int i = 0; i < n; ++i) {
-        if (host[i].f32) continue;
         int t = pairs[i]->tier_hint;
-        if (t == 2 && (host[i].tie_guard || !ctx->tune.expand_huge || expand_run_huge(ctx, pairs[i], *run[(size_t)i]) != FM_OK)) t = 1;
-        if (t == 1 && !ctx->tune.expand_big) t = 0;
+        if (t == 2 && (!huge_ok(i) || expand_run_huge(ctx, pairs[i], *run[(size_t)i]) != FM_OK)) t = 1;
+        if (t == 1 && (host[i].f32 || !ctx->tune.expand_big)) t = 0;
         big[(size_t)i] = (char)t;
         if (t == 2) expand_bind_run(host[i], *run[(size_t)i], pairs[i]);
     }
-    std::vector<ExpandPair> grouped;
-    grouped.reserve((size_t)n);
-    int n_tier[4] = {0, 0, 0, 0};
-    for (int v = 0; v < 3; ++v)
-        for (int i = 0; i < n; ++i) if (!host[i].f32 && (int)big[(size_t)i] == v) { grouped.push_back(host[i]); ++n_tier[v]; }
-    for (int i = 0; i < n; ++i) if (host[i].f32) { grouped.push_back(host[i]); ++n_tier[3]; }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), (size_t)n * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    {
+    // kernel of a run: int8 tiers 0 / 1 / 2, float32 tiers 0 / 2
+    auto group_of = [&](int i) { return host[i].f32 ? (big[(size_t)i] == 2 ? 4 : 3) : (int)big[(size_t)i]; };
+    auto launch_groups = [&](const std::vector<int>& idx) -> int {
+        std::vector<ExpandPair> grouped;
+        grouped.reserve(idx.size());
+        int cnt[5] = {0, 0, 0, 0, 0};
+        for (int g = 0; g < 5; ++g)
+            for (int i : idx) if (group_of(i) == g) { grouped.push_back(host[i]); ++cnt[g]; }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), grouped.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
         size_t at = 0;
-        for (int v = 0; v < 4; ++v) {
-            if (n_tier[v] > 0)
-                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + at * sizeof(ExpandPair), n_tier[v], v == 3, v == 3 ? 0 : v, ctx->stream));
-            at += (size_t)n_tier[v];
+        for (int g = 0; g < 5; ++g) {
+            if (cnt[g] > 0)
+                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + at * sizeof(ExpandPair), cnt[g], g >= 3, g == 4 ? 2 : (g == 3 ? 0 : g), ctx->stream));
+            at += (size_t)cnt[g];
         }
-    }
+        return FM_OK;
+    };
+    std::vector<int> all_runs((size_t)n);
+    for (int i = 0; i < n; ++i) all_runs[(size_t)i] = i;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    if ((rc = launch_groups(all_runs)) != FM_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
     std::vector<long long> res((size_t)n * 4);
@@ -355,7 +360,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
             const long long st = res[(size_t)i * 4 + 3];
             ExpandRun* r = run[(size_t)i];
             if (st == 2 && !host[i].f32 && ctx->tune.expand_big && big[(size_t)i] == 0) { big[(size_t)i] = 1; redo.push_back(i); continue; }
-            if (st == 2 && !host[i].f32 && !host[i].tie_guard && ctx->tune.expand_huge && big[(size_t)i] <= 1) {
+            if (st == 2 && huge_ok(i) && big[(size_t)i] <= 1) {
                 if (expand_run_huge(ctx, pairs[i], *r) == FM_OK) {
                     big[(size_t)i] = 2;
                     expand_bind_run(host[i], *r, pairs[i]);
@@ -378,25 +383,14 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
             }
         }
         if (redo.empty()) break;
-        for (int v = 0; v < 3; ++v) {                   // the three int8 capacity variants (float32 pairs: the small one)
-            grouped.clear();
-            std::vector<int> idx;
-            for (int i : redo) if ((int)big[(size_t)i] == v && !host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
-            const int n8 = (int)idx.size();
-            if (v == 0) for (int i : redo) if (host[i].f32) { grouped.push_back(host[i]); idx.push_back(i); }
-            if (idx.empty()) continue;
-            for (int i : idx)
-                HIP_TRY(ctx, hipMemsetAsync(run[(size_t)i]->seen, 0xff, (size_t)((char*)run[(size_t)i]->found - (char*)run[(size_t)i]->seen) +
-                                            (size_t)run[(size_t)i]->found_cap * 16, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, grouped.data(), grouped.size() * sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
-            if (n8 > 0) HIP_TRY(ctx, launch_expand(ctx->ws_in, n8, false, v, ctx->stream));
-            if ((int)idx.size() > n8)
-                HIP_TRY(ctx, launch_expand((const char*)ctx->ws_in + (size_t)n8 * sizeof(ExpandPair), (int)idx.size() - n8, true, 0, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-            for (int i : idx)
-                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // (ws_in is reused by the next variant)
-        }
+        for (int i : redo)
+            HIP_TRY(ctx, hipMemsetAsync(run[(size_t)i]->seen, 0xff, (size_t)((char*)run[(size_t)i]->found - (char*)run[(size_t)i]->seen) +
+                                        (size_t)run[(size_t)i]->found_cap * 16, ctx->stream));
+        if ((rc = launch_groups(redo)) != FM_OK) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        for (int i : redo)
+            HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // (ws_in is reused by the next pass)
     }
     for (int i = 0; i < n; ++i) {
         ctx->pending_pairs += res[(size_t)i * 4 + 2];

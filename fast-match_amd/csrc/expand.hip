@@ -346,7 +346,7 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 // F32: the pairs of the launch hold float32 banks (float32 round) -- a kernel of its own, so that
 // the int8 kernel does not carry the float32 round's registers (inlined together they spill).
 // CAND: capacity variant (ExpCfg); the big one exists for int8 banks only.
-// HUGE (int8 banks, no float32-root guard): a round whose radius subset exceeds CAND rows -- denser keypoints than a
+// HUGE (int8 banks without the float32-root guard, float32 banks): a round whose radius subset exceeds CAND rows -- denser keypoints than a
 // uniform image has, or a larger `radius` option; the reference has no limit (cache.pyx:173-188) -- is processed in
 // chunks of at most CAND rows instead of ending the run: the subset's histogram over the sort's buckets cuts it into
 // ranges of the sort key, every range is selected by a radius query of its own, sorted (ranges are disjoint and
@@ -362,7 +362,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
     using C = ExpCfg<CAND>;
     static_assert(!F32 || CAND == kExpCand, "the float32 round needs the 512-row stage buffer");
-    static_assert(!HUGE || (!F32 && CAND == kExpCand), "the chunked round exists for the int8 round of the first variant");
+    static_assert(!HUGE || CAND == kExpCand, "the chunked round exists for the first capacity variant");
     // dynamic LDS (C::kLdsBytes): the gather stage, the sort keys / qbest table, the
     // candidate rows, and two scratch arrays
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
@@ -693,11 +693,21 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int nc = sh_i[4];
                 block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, (double)b1 / bscale, (double)b0 / bscale);
                 for (int i = tid; i < nc; i += kExpThreads) P.h_cand[base + i] = cand[i];
-                x1_round_wsplit<C::kSR, kExpThreads, true>(P.q_rows8, P.q_norm, cand, nc, P.t_rows8, P.t_norm, t0, nt, smem,
-                                        (unsigned long long*)nullptr, (unsigned long long*)(hist + 2 * kSortBuckets + 16), 0,
-                                        nullptr, nullptr, nullptr, P.h_tbest, base);
+                if constexpr (F32) {
+                    // (the candidate list aliases the sort scratch, free until the next chunk's sort)
+                    lds_barrier();
+                    const bool okc = x1_round_f32<kExpThreads, true>(RF, cand, nc, t0, nt, smem, (unsigned long long*)nullptr, (unsigned*)nkey,
+                                                 C::kClistCap, (unsigned long long*)(hist + 2 * kSortBuckets + 16), sh_rf,
+                                                 nullptr, nullptr, P.h_tbest, base);
+                    if (!okc) { status = kExpListFull; break; }
+                } else {
+                    x1_round_wsplit<C::kSR, kExpThreads, true>(P.q_rows8, P.q_norm, cand, nc, P.t_rows8, P.t_norm, t0, nt, smem,
+                                            (unsigned long long*)nullptr, (unsigned long long*)(hist + 2 * kSortBuckets + 16), 0,
+                                            nullptr, nullptr, nullptr, P.h_tbest, base);
+                }
                 base += (unsigned)nc;
             }
+            if (status != kExpOk) break;      // (a float32 chunk whose candidate list overflowed)
             // (b) election: train row t elects the slot its minimum names; the slot keeps its closest train row
             __syncthreads();                  // the fill of h_qbest and the copies of h_cand have reached memory
             if (tid < 128)
@@ -996,7 +1006,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 }
 
-// tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8, no float32-root guard)
+// tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8 without the float32-root guard, float32)
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream)
 {
     static bool attr_set = false;
@@ -1004,12 +1014,17 @@ hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, h
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCandBig>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCandBig>::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (f32 && tier != 0) return hipErrorInvalidValue;
+    if (f32 && tier == 1) return hipErrorInvalidValue;
+    if (tier == 2 && f32) {
+        hipLaunchKernelGGL((expand_kernel<true, kExpCand, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+        return hipGetLastError();
+    }
     if (tier == 2) {
         hipLaunchKernelGGL((expand_kernel<false, kExpCand, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
         return hipGetLastError();

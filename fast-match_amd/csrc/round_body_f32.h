@@ -64,11 +64,16 @@ __device__ __forceinline__ float rf_max3(float a, float b, float c)
 // clist: LDS scratch for clist_cap candidates (u32 each: slot | column << 12); tbest: LDS u64[128];
 // sh: LDS int[NT / 64].  NT = threads of the workgroup (256 in round_f32_kernel, 512 in expand_kernel).
 // Returns false (uniformly) if the candidate list overflowed: the round's result is then invalid.
-template <int NT = 256>
+// MERGE (K7's chunked rounds, expand.hip): the query slots are one chunk (slots slot_base .. slot_base + nq of a radius
+// subset that does not fit LDS); the function stops at the reverse-NN step and folds its per-train-row minimum
+// (distance bits << 32 | global slot) -- exact within the chunk, margin and all -- into tb_all[0 .. nt) (global; row
+// cb0 + tid belongs to thread tid, as in x1_round_wsplit).  qbest is not touched.
+template <int NT = 256, bool MERGE = false>
 __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_rows, int nq, int64_t t0, int nt,
                                              char* smem, unsigned long long* qbest, unsigned* clist, int clist_cap,
                                              unsigned long long* tbest, int* sh,
-                                             long long* pt = nullptr, long long* ts = nullptr)
+                                             long long* pt = nullptr, long long* ts = nullptr,
+                                             gptr<unsigned long long> tb_all = nullptr, unsigned slot_base = 0)
 {
 #define RF_STAMP(k) do { if (pt && threadIdx.x == 0) { const long long _n = wall_clock64(); pt[k] += _n - *ts; *ts = _n; } } while (0)
     const int tid  = threadIdx.x;
@@ -295,8 +300,14 @@ __device__ __forceinline__ bool x1_round_f32(const RoundF32G& R, const int* q_ro
         RF_STAMP(11);
         if (tid < 128 && cb0 + tid < nt) {
             const unsigned long long tb = tbest[tid];
-            if (tb != ~0ull)
-                atomicMin(&qbest[(unsigned)tb], (tb & 0xffffffff00000000ull) | (unsigned)(cb0 + tid));
+            if (tb != ~0ull) {
+                if constexpr (MERGE) {
+                    const unsigned long long g = tb + slot_base;
+                    if (g < tb_all[cb0 + tid]) tb_all[cb0 + tid] = g;
+                } else {
+                    atomicMin(&qbest[(unsigned)tb], (tb & 0xffffffff00000000ull) | (unsigned)(cb0 + tid));
+                }
+            }
         }
         lds_barrier();
     }

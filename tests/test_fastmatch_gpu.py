@@ -235,6 +235,45 @@ def test_device_loop_chunks_radius_subsets_of_any_size(ctx):
             assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"] and len(got) > 300
 
 
+def test_device_loop_chunks_radius_subsets_of_float32_banks(ctx, monkeypatch):
+    """RootSIFT-style float32 banks with radius subsets far beyond the float32 round's 2048 rows: the chunked variant of
+    the float32 kernel (fp16 filter + exact chain per chunk, per-train-row (distance bits, slot) minimum merged across the
+    chunks) == the host loop == the oracle in the device's accumulation order; with the variant off: host loop."""
+    from fastmatch_amd import _ffi
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    q, t = synth.image_pair((400, 300), 6000, 78)
+
+    def root(d):
+        d = d.astype(np.float32)
+        return np.sqrt(d / np.maximum(d.sum(1, keepdims=True), 1)).astype(np.float32)
+
+    qd, td, qtd, ttd = root(q["descriptors"]), root(t["descriptors"]), root(q["thumb_descriptors"]), root(t["thumb_descriptors"])
+    mc = cache.Metric_Cache.from_arrays(qd, q["positions"], q["size"], qtd, q["thumb_positions"], q["thumb_size"],
+                                        options={"context": ctx})
+    assert mc.bank(ctx).kind == _ffi.FM_BANK_F32
+    fi = cache.Feature_Image(t["size"], t["positions"], td, t["thumb_positions"], ttd, t["thumb_size"])
+    oq = fo.OQuery(qd, q["positions"], q["size"],
+                   thumb={"descriptors": qtd, "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
+          "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    exp = fo.o_match(oq, ot, {"radius": 200})(0.9)
+    stats, hs = {}, {}
+    got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.9)
+    assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats
+    _same_matches(got, exp)
+    host = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": hs, "device_loop": False})(0.9)
+    _same_matches(host, exp)
+    assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"] and len(got) > 100
+    ctx.set_option("expand_huge", 0)
+    try:
+        fb = {}
+        again = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": fb})(0.9)
+    finally:
+        ctx.set_option("expand_huge", 1)
+    assert fb.get("device_fallbacks") == 1
+    _same_matches(again, exp)
+
+
 def test_device_loop_on_clustered_keypoints(ctx):
     """Real SIFT keypoints crowd on texture.  A Gaussian-mixture image pair (three blobs holding half of 120k keypoints,
     peak density > 20x the mean): the largest radius subset holds more than 10 000 rows, the largest cell thousands --
