@@ -37,7 +37,7 @@ class fm_stats_ex(ctypes.Structure):
                 ("bytes_moved", ctypes.c_int64)]
 
 
-FM_ABI_VERSION = 4          # include/fastmatch_hip.h: the revision this binding was written against
+FM_ABI_VERSION = 5          # include/fastmatch_hip.h: the revision this binding was written against
 
 
 class fm_expand_desc(ctypes.Structure):
@@ -50,12 +50,13 @@ class fm_expand_desc(ctypes.Structure):
                 ("cell_w", ctypes.c_int32), ("cell_h", ctypes.c_int32),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
                 ("margin", ctypes.c_int32), ("radius", ctypes.c_int32),
-                ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64), ("metric", ctypes.c_int32)]
+                ("match_cap", ctypes.c_int64), ("stack_cap", ctypes.c_int64), ("metric", ctypes.c_int32),
+                ("lazy", ctypes.c_int32)]
 
 
 EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "a radius subset the device could not take (see FM_EXPAND_SUBSET_FULL)",
                  3: "target position outside the image", 4: "result list full", 5: "hash table full",
-                 6: "float32 round: candidate list full"}
+                 6: "float32 round: candidate list full", 7: "lazy target: a cell is wanted"}
 
 # name -> (restype, argtypes); every symbol include/fastmatch_hip.h declares
 _P = ctypes.c_void_p
@@ -83,6 +84,11 @@ SYMBOLS = {
     "fm_bank_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_INT), ctypes.POINTER(_INT)]),
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
     "fm_bank_refill_u8_async": (_INT, [_P, _P, _P, _I64]),
+    "fm_bank_create_u8_cap": (_INT, [_P, _P, _I64, _INT, _I64, ctypes.POINTER(_P)]),
+    "fm_bank_append_u8": (_INT, [_P, _P, _P, _I64, ctypes.POINTER(_I64)]),
+    "fm_expand_set_cell": (_INT, [_P, _P, ctypes.c_int32, _I64, _I64, _P]),
+    "fm_expand_run_lazy": (_INT, [_P, _P, _P, _I64, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                           ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "fm_upload_fence": (_INT, [_P]),
     "fm_self_dist_batch": (_INT, [_P, ctypes.c_int32, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
@@ -224,6 +230,18 @@ class Bank(object):
         self.has_selfdist = False
         self._refill_src = a          # (the copy is asynchronous: keep the source alive)
 
+    def append(self, rows):
+        """More uint8 rows into a bank made with room for them (``Context.bank_with_capacity``), placed at the next
+        multiple of 32 rows; returns the index of the first one."""
+        a = np.ascontiguousarray(rows)
+        if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != self.dim:
+            raise ValueError("rows must be [n, %d] uint8" % self.dim)
+        first = _I64(0)
+        self.ctx._check(self.ctx.lib.fm_bank_append_u8(self.ctx.handle, self.handle, _ptr(a), a.shape[0], ctypes.byref(first)))
+        if a.shape[0]:
+            self.n = int(first.value) + a.shape[0]
+        return int(first.value)
+
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             self.ctx.lib.fm_bank_destroy(self.ctx.handle, self.handle)
@@ -240,15 +258,18 @@ class Expander(object):
     """Device-resident expansion state of one image pair (fm_expand)."""
 
     def __init__(self, ctx, q_bank, q_pos, index, t_bank, cell_off, t_pos, grid, radius,
-                 match_cap=0, stack_cap=0):
+                 match_cap=0, stack_cap=0, lazy=False):
+        """``lazy``: the target's cells are added one by one (``set_cell``) as the loop asks for them (``run_lazy``);
+        ``t_bank`` is then a bank from ``Context.bank_with_capacity`` and ``cell_off`` / ``t_pos`` are None."""
         self.ctx = ctx
         self.handle = None
+        self.lazy = bool(lazy)
         # keep every host array alive until fm_expand_create has copied it
         q_pos = np.ascontiguousarray(q_pos, dtype=np.float64).reshape(-1, 2)
         order = np.ascontiguousarray(index.order, dtype=np.int32)
         start = np.ascontiguousarray(index.start, dtype=np.int32)
-        cell_off = np.ascontiguousarray(cell_off, dtype=np.int64)
-        t_pos = np.ascontiguousarray(t_pos, dtype=np.float64).reshape(-1, 2)
+        cell_off = None if lazy else np.ascontiguousarray(cell_off, dtype=np.int64)
+        t_pos = None if lazy else np.ascontiguousarray(t_pos, dtype=np.float64).reshape(-1, 2)
         d = fm_expand_desc()
         d.query, d.query_pos = q_bank.handle, _ptr(q_pos)
         d.index_bucket, d.index_x0, d.index_y0 = index.bucket, index.x0, index.y0
@@ -260,10 +281,28 @@ class Expander(object):
         d.rows, d.cols, d.margin, d.radius = grid["rows"], grid["cols"], grid["margin"], int(radius)
         d.match_cap, d.stack_cap = int(match_cap), int(stack_cap)
         d.metric = int(getattr(index, "metric", 0))         # Position_Index.metric = FM_METRIC_*
+        d.lazy = 1 if lazy else 0
         h = _P()
         ctx._check(ctx.lib.fm_expand_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
         self.handle = h
         self._banks = (q_bank, t_bank)            # the banks must outlive the expander
+
+    def set_cell(self, cell, first_row, positions):
+        """Register a computed cell of a lazy target: rows [first_row, first_row + len(positions)) of the target bank."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
+        self.ctx._check(self.ctx.lib.fm_expand_set_cell(self.ctx.handle, self.handle, int(cell), int(first_row), pos.shape[0],
+                                                        _ptr(pos) if pos.shape[0] else None))
+
+    def run_lazy(self, seeds, tau, resume):
+        """One launch of a lazy pair: (n_matches, n_rounds, n_pairs, status, need_cell); status 7 = compute ``need_cell``
+        (col * rows + row), ``set_cell`` it and call again with ``resume=True``."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.float64).reshape(-1, 2, 2)
+        nm, nr, npairs = _I64(0), _I64(0), _I64(0)
+        st, need = ctypes.c_int32(0), ctypes.c_int32(-1)
+        self.ctx._check(self.ctx.lib.fm_expand_run_lazy(self.ctx.handle, self.handle, _ptr(seeds) if seeds.shape[0] else None,
+                                                        seeds.shape[0], float(tau), 1 if resume else 0, ctypes.byref(nm),
+                                                        ctypes.byref(nr), ctypes.byref(npairs), ctypes.byref(st), ctypes.byref(need)))
+        return int(nm.value), int(nr.value), int(npairs.value), int(st.value), int(need.value)
 
     def info(self):
         """(bytes of one run state, run states that exist): see fm_expand_info."""
@@ -373,6 +412,18 @@ class Context(object):
         else:
             a = np.ascontiguousarray(a, dtype=np.float32)
             self._check(self.lib.fm_bank_create_f32(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
+        n, dim, kind = _I64(), _INT(), _INT()
+        self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
+        return Bank(self, h, n.value, dim.value, kind.value)
+
+    def bank_with_capacity(self, rows, capacity):
+        """A uint8 bank with room for ``capacity`` rows (``Bank.append``): the growing target bank of a lazy pair."""
+        a = np.ascontiguousarray(rows, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("descriptor bank must be 2-D [n, dim]")
+        h = _P()
+        self._check(self.lib.fm_bank_create_u8_cap(self.handle, _ptr(a) if a.shape[0] else None, a.shape[0], a.shape[1],
+                                                   int(max(capacity, a.shape[0])), ctypes.byref(h)))
         n, dim, kind = _I64(), _INT(), _INT()
         self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
         return Bank(self, h, n.value, dim.value, kind.value)

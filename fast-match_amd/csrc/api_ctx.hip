@@ -627,7 +627,8 @@ static void bank_free(Bank* b)
     b->rowsh = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
 
-static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out, bool keep_f32 = false)
+static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out, bool keep_f32 = false,
+                       int64_t capacity = 0)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_bank_create: ctx is NULL");
     if (!out) return fail(ctx, FM_EINVAL, "fm_bank_create: bank out pointer is NULL");
@@ -643,6 +644,11 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     b->n_pad = ((n + kStageRows - 1) / kStageRows) * kStageRows;
     if (b->n_pad == 0) b->n_pad = kStageRows;
     b->cap_pad = b->n_pad;
+    if (capacity > n) {
+        // room to grow (fm_bank_append_u8): the arrays are sized, and every tile prepared as padding, for `capacity` rows
+        if (capacity > (int64_t)INT32_MAX - 2 * kStageRows) { delete b; return fail(ctx, FM_EUNSUPPORTED, "fm_bank_create: capacity too large"); }
+        b->cap_pad = ((capacity + kStageRows - 1) / kStageRows) * kStageRows;
+    }
     b->kind = FM_BANK_I8;
     const size_t elt = f32 ? 4 : 1;
     const size_t src_bytes = (size_t)n * dim * elt;
@@ -661,12 +667,12 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
                              std::string(#expr " failed: ") + hipGetErrorString(_e)));           \
         }                                                                                        \
     } while (0)
-    BTRY(hipMalloc((void**)&b->rows8, (size_t)b->n_pad * kDim));
-    BTRY(hipMalloc((void**)&b->norm, (size_t)b->n_pad * 4));
-    BTRY(hipMalloc((void**)&b->aux, (size_t)(b->n_pad / kTileRows) * kAuxPerTile * 4));
+    BTRY(hipMalloc((void**)&b->rows8, (size_t)b->cap_pad * kDim));
+    BTRY(hipMalloc((void**)&b->norm, (size_t)b->cap_pad * 4));
+    BTRY(hipMalloc((void**)&b->aux, (size_t)(b->cap_pad / kTileRows) * kAuxPerTile * 4));
     if (src_bytes) BTRY(hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
     BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-    const int ntiles = (int)(b->n_pad / kTileRows);
+    const int ntiles = (int)(b->cap_pad / kTileRows);
     if (f32)
         hipLaunchKernelGGL(bank_prep_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream,
                            (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles);
@@ -724,6 +730,43 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
 extern "C" int fm_bank_create_u8(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, fm_bank** bank)
 {
     return bank_create(ctx, rows, n, dim, false, bank);
+}
+
+extern "C" int fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank)
+{
+    if (capacity < n) return fail(ctx, FM_EINVAL, "fm_bank_create_u8_cap: capacity < n");
+    return bank_create(ctx, rows, n, dim, false, bank, false, capacity);
+}
+
+// Rows appended to a bank created with room for them, at the next multiple of 32 rows (whole MFMA tiles: the rows
+// of the tile an earlier append ended in stay what they are, padding).  Synchronous.
+extern "C" int fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t n, int64_t* first_row)
+{
+    if (!ctx || !bank) return fail(ctx, FM_EINVAL, "fm_bank_append_u8: NULL argument");
+    if (bank->kind != FM_BANK_I8 || !bank->rows8) return fail(ctx, FM_EINVAL, "fm_bank_append_u8: not an integer-route bank");
+    if (n < 0 || (n > 0 && !rows)) return fail(ctx, FM_EINVAL, "fm_bank_append_u8: bad rows / n");
+    const int64_t off = ((bank->n + kTileRows - 1) / kTileRows) * kTileRows;
+    if (first_row) *first_row = off;
+    if (n == 0) return FM_OK;
+    if (off + n > bank->cap_pad) return fail(ctx, FM_EINVAL, "fm_bank_append_u8: the bank's capacity is used up");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t src_bytes = (size_t)n * bank->dim, flag_off = (src_bytes + 15) & ~(size_t)15;
+    int rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 32);
+    if (rc != FM_OK) return rc;
+    int* d_flag = (int*)((char*)ctx->ws_in + flag_off);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(bank_prep_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const void*)ctx->ws_in, n, bank->dim,
+                       bank->rows8 + (size_t)off * kDim, bank->norm + off, bank->aux + (off / kTileRows) * kAuxPerTile, d_flag, ntiles);
+    HIP_TRY(ctx, hipGetLastError());
+    int flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[1] > bank->usq_max) bank->usq_max = flags[1];
+    bank->n = off + n;
+    bank->n_pad = ((bank->n + kStageRows - 1) / kStageRows) * kStageRows;
+    return FM_OK;
 }
 
 extern "C" int fm_bank_create_f32(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank)

@@ -35,6 +35,13 @@ struct fm_expand {
     int64_t nq = 0;
     int64_t tmax = 0;              // rows of the largest cell
     int tier_hint = 0;             // capacity tier (launch_expand) the pair's last complete run needed: the next run starts there
+    // lazy targets (fm_expand_desc.lazy): the target bank grows as the host adds cells
+    bool lazy = false;
+    fm_bank* lazy_target = nullptr;    // (borrowed) the capacity bank whose arrays dev.t_rows8 / t_norm point into
+    const fm_bank* query = nullptr;
+    void* lazy_blob = nullptr;     // cell_start i64[ncells] | cell_cnt i32[ncells] | cell_ready i32[ncells] | resume state
+    int64_t ncells = 0, t_cap = 0;
+    double* d_tpos = nullptr;      // (inside blob) [t_cap][2]
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0;       // defaults of a new run state
     std::vector<ExpandRun> runs;   // run slot k = the k-th run of this pair inside one launch
 };
@@ -133,14 +140,18 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (d->metric < FM_METRIC_EUCLIDEAN || d->metric > FM_METRIC_CHEBYSHEV) return fail(ctx, FM_EINVAL, "fm_expand_create: unknown metric");
     if (d->rows > 65535 || d->cols > 65535 || d->width > 65535 || d->height > 65535)
         return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: image or grid too large for 16-bit cell keys");
-    if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || !d->cell_off || (nt > 0 && !d->target_pos))
+    const bool lazy = d->lazy != 0;
+    if (lazy && (f32 || d->target->cap_pad <= 0)) return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: lazy targets need an integer-route target bank (fm_bank_create_u8_cap)");
+    if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || (!lazy && (!d->cell_off || (nt > 0 && !d->target_pos))))
         return fail(ctx, FM_EINVAL, "fm_expand_create: NULL array");
     const int64_t nb = (int64_t)d->index_nbx * d->index_nby;
     if (d->index_nbx < 0 || d->index_nby < 0 || d->index_start[nb] != nq || !(d->index_bucket > 0.0))
         return fail(ctx, FM_EINVAL, "fm_expand_create: inconsistent position index");
-    if (d->cell_off[0] != 0 || d->cell_off[ncells] != nt) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off must cover the target bank");
-    for (int64_t c = 0; c < ncells; ++c)
-        if (d->cell_off[c + 1] < d->cell_off[c]) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off not monotonic");
+    if (!lazy) {
+        if (d->cell_off[0] != 0 || d->cell_off[ncells] != nt) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off must cover the target bank");
+        for (int64_t c = 0; c < ncells; ++c)
+            if (d->cell_off[c + 1] < d->cell_off[c]) return fail(ctx, FM_EINVAL, "fm_expand_create: cell_off not monotonic");
+    }
     for (int64_t i = 0; i < nq; ++i) {
         if (d->index_order[i] < 0 || d->index_order[i] >= nq) return fail(ctx, FM_EINVAL, "fm_expand_create: index_order out of range");
         const double x = d->query_pos[2 * i], y = d->query_pos[2 * i + 1];
@@ -157,7 +168,9 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     fm_expand* ex = new (std::nothrow) fm_expand();
     if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
     ex->nq = nq;
-    for (int64_t c = 0; c < ncells; ++c) ex->tmax = std::max<int64_t>(ex->tmax, d->cell_off[c + 1] - d->cell_off[c]);
+    if (!lazy) for (int64_t c = 0; c < ncells; ++c) ex->tmax = std::max<int64_t>(ex->tmax, d->cell_off[c + 1] - d->cell_off[c]);
+    ex->lazy = lazy; ex->lazy_target = lazy ? const_cast<fm_bank*>(d->target) : nullptr; ex->query = d->query;
+    ex->ncells = ncells; ex->t_cap = lazy ? d->target->cap_pad : nt;
     ex->match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
     ex->stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
     ex->seen_cap = pow2_at_least(16 * ncells > 65536 ? 16 * ncells : 65536);
@@ -165,7 +178,9 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al256(bytes > 0 ? bytes : 1); return o; };
     const size_t o_qpos = carve((size_t)nq * 16), o_order = carve((size_t)nq * 4), o_start = carve((size_t)(nb + 1) * 4);
-    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)nt * 16), o_qord = carve((size_t)nq * 16);
+    const size_t o_coff = carve((size_t)(ncells + 1) * 8), o_tpos = carve((size_t)(lazy ? d->target->cap_pad : nt) * 16), o_qord = carve((size_t)nq * 16);
+    const size_t o_cstart = carve(lazy ? (size_t)ncells * 8 : 0), o_ccnt = carve(lazy ? (size_t)ncells * 4 : 0), o_cready = carve(lazy ? (size_t)ncells * 4 : 0);
+    const size_t o_resume = carve(lazy ? 128 : 0);
     hipError_t e = hipMalloc(&ex->blob, off);
     if (e != hipSuccess) { (void)hipGetLastError(); delete ex; return fail(ctx, FM_ENOMEM, std::string("fm_expand_create: hipMalloc: ") + hipGetErrorString(e)); }
     char* b = (char*)ex->blob;
@@ -176,8 +191,13 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (nq) ETRY(hipMemcpyAsync(b + o_order, d->index_order, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nq) ETRY(hipMemcpyAsync(b + o_qord, pos_ord.data(), (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
     ETRY(hipMemcpyAsync(b + o_start, d->index_start, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    ETRY(hipMemcpyAsync(b + o_coff, d->cell_off, (size_t)(ncells + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (nt) ETRY(hipMemcpyAsync(b + o_tpos, d->target_pos, (size_t)nt * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (!lazy) {
+        ETRY(hipMemcpyAsync(b + o_coff, d->cell_off, (size_t)(ncells + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (nt) ETRY(hipMemcpyAsync(b + o_tpos, d->target_pos, (size_t)nt * 16, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        // no cell is there yet: start 0, count 0, not ready
+        ETRY(hipMemsetAsync(b + o_cstart, 0, (o_resume + 128) - o_cstart, ctx->stream));
+    }
     ETRY(hipStreamSynchronize(ctx->stream));
 #undef ETRY
     ExpandPair& P = ex->dev;
@@ -193,6 +213,10 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     P.rf = RoundF32{};
     if (f32) fill_round_f32(&P.rf, *d->query, *d->target);
     P.cell_off = (const int64_t*)(b + o_coff); P.t_pos = (const double*)(b + o_tpos);
+    P.cell_start = lazy ? (const int64_t*)(b + o_cstart) : nullptr; P.cell_cnt = lazy ? (const int32_t*)(b + o_ccnt) : nullptr;
+    P.cell_ready = lazy ? (const int32_t*)(b + o_cready) : nullptr; P.resume_state = lazy ? (long long*)(b + o_resume) : nullptr;
+    P.resume = 0;
+    ex->d_tpos = (double*)(b + o_tpos);
     P.width = d->width; P.height = d->height; P.cell_w = d->cell_w; P.cell_h = d->cell_h;
     P.rows = d->rows; P.cols = d->cols; P.margin = d->margin; P.radius = d->radius;
     P.seeds = nullptr; P.n_seeds = 0; P.tau = 0.0;
@@ -202,6 +226,73 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (rc != FM_OK) return bail(rc);
     expand_bind_run(P, ex->runs[0]);
     *out = ex;
+    return FM_OK;
+}
+
+// A computed cell of a lazy target: its rows [first_row, first_row + n_rows) of the target bank (fm_bank_append_u8) and their
+// full-image positions; n_rows may be 0 (a cell without features, fastmatch.pyx:155-156).  The cell is ready afterwards.
+extern "C" int fm_expand_set_cell(fm_ctx* ctx, fm_expand* ex, int32_t cell, int64_t first_row, int64_t n_rows, const double* pos)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_set_cell: NULL argument");
+    if (!ex->lazy) return fail(ctx, FM_EINVAL, "fm_expand_set_cell: the pair was not created with lazy targets");
+    if (cell < 0 || cell >= ex->ncells || first_row < 0 || n_rows < 0 || n_rows > INT32_MAX || first_row + n_rows > ex->lazy_target->n ||
+        first_row + n_rows > ex->t_cap || (n_rows > 0 && !pos))
+        return fail(ctx, FM_EINVAL, "fm_expand_set_cell: cell or row range out of bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int32_t cnt = (int32_t)n_rows, one = 1;
+    if (n_rows) HIP_TRY(ctx, hipMemcpyAsync(ex->d_tpos + 2 * first_row, pos, (size_t)n_rows * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync((void*)(ex->dev.cell_start + cell), &first_row, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync((void*)(ex->dev.cell_cnt + cell), &cnt, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync((void*)(ex->dev.cell_ready + cell), &one, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ex->tmax = std::max<int64_t>(ex->tmax, n_rows);
+    return FM_OK;
+}
+
+// One run of a lazy pair (run slot 0): from the start (resume == 0: tables cleared, seeds uploaded) or from where the last
+// launch parked (resume != 0, after fm_expand_set_cell of the cell it asked for).  status FM_EXPAND_NEED_CELL: *need_cell is
+// the cell (col * rows + row) to compute; 0: done, fetch with fm_expand_fetch; anything else: the device gave up (a
+// capacity of the first kernel: lazy runs are not repeated in larger variants -- host loop).
+extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seeds, int64_t n_seeds, double tau, int32_t resume,
+                                  int64_t* n_matches, int64_t* n_rounds, int64_t* n_pairs, int32_t* status, int32_t* need_cell)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: NULL argument");
+    if (!ex->lazy) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: the pair was not created with lazy targets");
+    if (n_seeds < 0 || (n_seeds > 0 && !seeds)) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: bad seeds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = expand_ensure_run(ctx, ex, 0);
+    if (rc != FM_OK) return rc;
+    ExpandRun* r = &ex->runs[0];
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, sizeof(ExpandPair) + 64)) != FM_OK) return rc;
+    CallScope cs(ctx);
+    if (!resume) {
+        if (n_seeds > r->seeds_cap) {
+            if (r->d_seeds) { HIP_TRY(ctx, hipFree(r->d_seeds)); r->d_seeds = nullptr; r->seeds_cap = 0; }
+            const int64_t cap = n_seeds + n_seeds / 2 + 64;
+            HIP_TRY(ctx, hipMalloc((void**)&r->d_seeds, (size_t)cap * 32));
+            r->seeds_cap = cap;
+        }
+        if (n_seeds) HIP_TRY(ctx, hipMemcpyAsync(r->d_seeds, seeds, (size_t)n_seeds * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
+    }
+    ExpandPair host = ex->dev;
+    expand_bind_run(host, *r);
+    host.seeds = r->d_seeds; host.n_seeds = n_seeds; host.tau = tau; host.prof = 0;
+    host.resume = resume ? 1 : 0;
+    host.tie_guard = sqrt_tie_possible(*ex->query, *ex->lazy_target) ? 1 : 0;     // (the target bank has grown since the pair was made)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, false, 3, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    long long res[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = cs.finish()) != FM_OK) return rc;
+    if (n_matches) *n_matches = res[0];
+    if (n_rounds) *n_rounds = res[1];
+    if (n_pairs) *n_pairs = res[2];
+    if (status) *status = (int32_t)res[3];
+    if (need_cell) *need_cell = (int32_t)res[4];
     return FM_OK;
 }
 
@@ -277,6 +368,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         for (int i = 0; i < n; ++i) {
             fm_expand* ex = pairs[i];
             if (!ex) return fail(ctx, FM_EINVAL, "fm_expand_run: NULL pair");
+            if (ex->lazy) return fail(ctx, FM_EINVAL, "fm_expand_run: a lazy pair is driven with fm_expand_run_lazy");
             if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
             const int slot = seen_pairs[ex]++;
             if ((rc = expand_ensure_run(ctx, ex, (size_t)slot)) != FM_OK) return rc;

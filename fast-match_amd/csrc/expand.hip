@@ -53,7 +53,7 @@ struct ExpCfg {
 };
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
-       kExpListFull = 6 };
+       kExpListFull = 6, kExpNeedCell = 7 };
 static_assert(kRF_StageBytes <= ExpCfg<kExpCand>::kStageBytes, "the float32 round's gather image must fit the stage buffer");
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -356,10 +356,17 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 // other variants unchanged.  Still given up (status 2 -> host loop): a single bucket of more than CAND keypoints
 // (thousands at one distance), more than CAND ACCEPTED matches in one round, more than kHugeChunks chunks.
 constexpr int kHugeChunks = 640;
-template <bool F32, int CAND = kExpCand, bool HUGE = false>
+// LAZY (r04; the reference's own mode, cache.pyx:102-106, 124-138: a cell's features are computed -- SIFT on the crop -- when the
+// loop first reaches the cell): cells carry a `ready` flag and their own (first row, row count) in a target bank that grows as
+// the host adds cells.  A round that needs a cell which is not there SAVES the loop's state (counters, pending-stack height, seed
+// cursor, the popped entry -- its key is already in the seen set) and ends the launch with status kExpNeedCell + the cell id; the host
+// computes the cell (fm_bank_append_u8 + fm_expand_set_cell) and launches again with `resume`, which restores the state and takes the
+// saved entry instead of popping one.  Everything between two such stops runs at the device loop's pace.
+template <bool F32, int CAND = kExpCand, bool HUGE = false, bool LAZY = false>
 __global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
+    static_assert(!LAZY || (!F32 && !HUGE && CAND == kExpCand), "the lazy-target variant exists for the first int8 kernel");
     using C = ExpCfg<CAND>;
     static_assert(!F32 || CAND == kExpCand, "the float32 round needs the 512-row stage buffer");
     static_assert(!HUGE || CAND == kExpCand, "the chunked round exists for the first capacity variant");
@@ -408,6 +415,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<int32_t> m_index; gptr<double> m_pos, m_ratio; int64_t match_cap;
         gptr<long long> result; int prof;
         gptr<int32_t> h_cand; gptr<unsigned long long> h_qbest, h_tbest;
+        gptr<const int64_t> cell_start; gptr<const int32_t> cell_cnt, cell_ready; gptr<long long> resume_state; int resume;
     } P;
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
     P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos; P.q_pos_ord = (gptr<const double>)M.q_pos_ord;
@@ -424,6 +432,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.m_index = (gptr<int32_t>)M.m_index; P.m_pos = (gptr<double>)M.m_pos; P.m_ratio = (gptr<double>)M.m_ratio;
     P.match_cap = M.match_cap; P.result = (gptr<long long>)M.result; P.prof = M.prof;
     P.h_cand = (gptr<int32_t>)M.h_cand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest;
+    P.cell_start = (gptr<const int64_t>)M.cell_start; P.cell_cnt = (gptr<const int32_t>)M.cell_cnt; P.cell_ready = (gptr<const int32_t>)M.cell_ready;
+    P.resume_state = (gptr<long long>)M.resume_state; P.resume = M.resume;
     const RoundF32G RF(M.rf);
     const int tid = threadIdx.x;
 
@@ -438,8 +448,29 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     if (tid == 0) { for (int k = 0; k < 12; ++k) pt[k] = 0; tstamp = P.prof ? wall_clock64() : 0; }
 #define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
 
+    bool skip_pop = false;        // (uniform) LAZY: the first round of a resumed run takes the saved entry
+    int need_cell = -1;
+    if constexpr (LAZY) {
+        if (P.resume) {
+            top = P.resume_state[0]; seed_i = P.resume_state[1]; n_matches = P.resume_state[2];
+            n_rounds = P.resume_state[3]; n_pairs = P.resume_state[4]; seen_n = P.resume_state[5];
+            if (tid == 0) for (int k = 0; k < 4; ++k) cur[k] = __longlong_as_double(P.resume_state[6 + k]);
+            skip_pop = true;
+        }
+    }
+
     for (;;) {
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
+        if (LAZY && skip_pop) {
+            skip_pop = false;
+            if (tid == 0) {
+                nxt_valid = 0;
+                sh_i[0] = 1; sh_i[1] = blk(cur[3], P.cell_h); sh_i[2] = blk(cur[2], P.cell_w);
+                sh_i[3] = status; sh_i[4] = 0; sh_i[7] = 0;
+                sh_top = top; sh_seed = seed_i;
+            }
+            lds_barrier();
+        } else {
         if (tid == 0) {
             int have = 0;
             if (nxt_valid && top > 0 && 2 * (seen_n + 1) <= P.seen_cap) {
@@ -517,6 +548,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
             lds_barrier();
         }
+        }
         // (the barrier behind the pop block, or the one that ends the last pass of the loop, is in front of these reads)
         status = sh_i[3];
         if (!sh_i[0] || status != kExpOk) break;
@@ -528,12 +560,28 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (tx > P.width || ty > P.height) { status = kExpOutOfBounds; break; }     // cache.pyx:56-57
         // the cell actually fetched is the one of the TRUNCATED target position (target.get)
         const int gcol = blk((double)ty, P.cell_h), grow = blk((double)tx, P.cell_w);
-        ++n_rounds;
         // the cell's row range is needed only after the radius query and the sort: fetch it now, so the
         // load's latency is not on the critical path in front of the cross-check
         const int cell = gcol * P.rows + grow;
-        const int64_t t0 = P.cell_off[cell];
-        const int64_t t1 = P.cell_off[cell + 1];
+        int64_t t0, t1;
+        if constexpr (LAZY) {
+            t0 = P.cell_start[cell];
+            t1 = t0 + P.cell_cnt[cell];
+            if (P.cell_ready[cell] == 0) {             // (uniform) not computed yet: park the round and hand back to the host
+                if (tid == 0) {
+                    P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
+                    P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
+                    for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
+                }
+                need_cell = cell;
+                status = kExpNeedCell;
+                break;
+            }
+        } else {
+            t0 = P.cell_off[cell];
+            t1 = P.cell_off[cell + 1];
+        }
+        ++n_rounds;
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
         block_sort_clear(hist);          // (for the sort behind the radius query: the barrier in between is the query's own)
@@ -1003,10 +1051,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[2] = n_pairs;
         P.result[3] = status;
         if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
+        if constexpr (LAZY) P.result[4] = need_cell;
     }
 }
 
-// tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8 without the float32-root guard, float32)
+// tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8 without the float32-root guard, float32),
+// 3 = the lazy-target variant of tier 0 (int8)
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream)
 {
     static bool attr_set = false;
@@ -1015,12 +1065,18 @@ hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, h
         hipError_t e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCandBig>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCandBig>::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (f32 && tier == 1) return hipErrorInvalidValue;
+    if (tier == 3) {           // lazy targets (int8, first capacity)
+        if (f32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((expand_kernel<false, kExpCand, false, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+        return hipGetLastError();
+    }
     if (tier == 2 && f32) {
         hipLaunchKernelGGL((expand_kernel<true, kExpCand, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
         return hipGetLastError();

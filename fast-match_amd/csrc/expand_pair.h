@@ -47,7 +47,13 @@ struct ExpandPair {
     int32_t* h_cand;               // [nq] the round's sorted query rows, all slots
     unsigned long long* h_qbest;   // [nq] cross-check table of the round, all slots
     unsigned long long* h_tbest;   // [largest cell] per train row: running (d2 << 32 | slot) minimum over the chunks
-    long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers
+    // lazy targets (expand.hip, LAZY): cells arrive one by one; per cell its first row, row count and a ready flag
+    const int64_t* cell_start;     // [cols*rows]
+    const int32_t* cell_cnt;       // [cols*rows]
+    const int32_t* cell_ready;     // [cols*rows] 0 = not computed yet
+    long long* resume_state;       // [10] loop state of a parked run (top, seed cursor, counters, the popped entry)
+    int        resume;             // non-zero: restore resume_state and take its entry first
+    long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers (lazy: [4] = the cell wanted)
     int        prof;               // non-zero: thread 0 accumulates per-phase 100 MHz ticks
 };
 

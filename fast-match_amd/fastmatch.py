@@ -58,7 +58,11 @@ def match(query_cache, target_img, options={}):
     # logging) the host replays the loop and only each round's arithmetic runs on the device.
     use_device_loop = (isinstance(target_img, Feature_Image) and log is None
                        and options.get("device_loop", True))
-    state = {"expander": None}
+    # r04: a pixel target (cells computed on demand, the reference's own mode: cache.pyx:102-106, 124-138) runs the loop on
+    # the device too -- the kernel parks when it reaches a cell that has not been computed, the host computes it (SIFT on the
+    # crop), adds it to the growing target bank and resumes (lazy_device_loop below)
+    use_lazy_loop = (not isinstance(target_img, Feature_Image) and log is None and options.get("device_loop", True))
+    state = {"expander": None, "lazy": None}
 
     def seeds_for(tau):
         return thumb_positions[thumb_ratios < thumb_strategy(tau)]
@@ -75,6 +79,58 @@ def match(query_cache, target_img, options={}):
         return do_iter(iter(seeds_for(tau)), query_cache, target_cache, tau=tau, thumb_tau=thumb_strategy(tau),
                        radius=radius, log=log, context=context, stats=stats)
 
+    def lazy_device_loop(tau):
+        """The device-resident loop on a target whose cells are computed on demand; None = not possible (float
+        descriptors, a capacity of the device loop, the target bank's room used up): the host loop takes the run."""
+        if not use_lazy_loop or state["lazy"] is False:
+            return None
+        if state["lazy"] is None:
+            state["lazy"] = make_lazy_expander(query_cache, target_cache, radius, context, options.get("lazy_capacity"))
+            if state["lazy"] is False:
+                return None
+        ex, t_bank = state["lazy"]
+        seeds, resume, added = seeds_for(tau), False, 0
+        from . import _ffi
+        while True:
+            n_matches, n_rounds, n_pairs, status, need = ex.run_lazy(seeds, tau, resume)
+            if status == 7:                                    # FM_EXPAND_NEED_CELL
+                col, row = divmod(need, target_cache.rows)
+                value = target_cache.get_cell(col, row)        # the caching function runs here (SIFT on the crop)
+                kp, ds = value if isinstance(value, tuple) else (None, None)
+                try:
+                    if ds is None or len(ds) == 0:
+                        ex.set_cell(need, 0, np.zeros((0, 2)))
+                    else:
+                        ds = np.asarray(ds)
+                        if ds.dtype != np.uint8:
+                            u8 = ds.astype(np.uint8)
+                            if not np.array_equal(u8.astype(ds.dtype), ds):     # not integer valued: no int8 route
+                                state["lazy"] = False
+                                return None
+                            ds = u8
+                        off = np.array([row * target_cache.cell_width - target_cache.margin,
+                                        col * target_cache.cell_height - target_cache.margin], dtype=np.float64)
+                        ex.set_cell(need, t_bank.append(ds), keypoint_positions(kp) + off)
+                except _ffi.FastMatchHipError:                 # the bank's capacity is used up
+                    state["lazy"] = False
+                    return None
+                resume, added = True, added + 1
+                continue
+            if stats is not None:
+                stats["lazy_cells"] = stats.get("lazy_cells", 0) + added
+            if status != 0:
+                if stats is not None:
+                    stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
+                return None
+            if stats is not None:
+                stats["device_loops"] = stats.get("device_loops", 0) + 1
+                stats["rounds"] = stats.get("rounds", 0) + n_rounds
+                stats["pairs"] = stats.get("pairs", 0) + n_pairs
+            index, pos, ratio = ex.fetch(n_matches)
+            if options.get("return_arrays", False):
+                return index, pos, ratio
+            return [(int(a), {"positions": p, "ratio": float(r)}) for a, p, r in zip(index, pos, ratio)]
+
     # A function where tau can be varied to get different results.  Addition: a LIST of thresholds
     # (the reference's driver asks one pair for many, turntable.py:59-60) returns the list of their
     # results from ONE launch of the device loop -- the runs are independent, one workgroup each.
@@ -86,7 +142,13 @@ def match(query_cache, target_img, options={}):
             if ex is not None and taus:
                 res = run_device_loops(context, [ex] * len(taus), [seeds_for(t) for t in taus], taus, stats=stats,
                                        as_arrays=options.get("return_arrays", False))
+            elif use_lazy_loop:
+                res = [lazy_device_loop(t) for t in taus]      # (one after the other: they share the cells computed so far)
             return [r if r is not None else host_loop(t) for r, t in zip(res, taus)]
+        if use_lazy_loop:
+            res = lazy_device_loop(tau)
+            if res is not None:
+                return res
         ex = expander()
         if ex is not None:
             res = run_device_loops(context, [ex], [seeds_for(tau)], [tau], stats=stats,
@@ -185,6 +247,29 @@ def _expand_launch(context, expanders, seeds, taus):
     fetched = dict(zip(ok, context.expand_fetch_many([expanders[i] for i in ok], [results[i][0] for i in ok],
                                                      slots=[slots[i] for i in ok])))
     return results, fetched
+
+
+def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None):
+    """(expander, growing target bank) for a target whose cells are computed on demand, or False (float32 query bank,
+    oversize geometry).  ``capacity``: rows the target bank has room for; default 6 x the query's keypoints (a cell's
+    crop includes its margins: a keypoint lands in up to four cells) + 32 per cell (cells start at multiples of 32 rows)."""
+    from . import _ffi
+    q_bank = query_cache.bank(context)
+    if q_bank.kind != _ffi.FM_BANK_I8:
+        return False
+    ncells = target_grid.rows * target_grid.cols
+    if capacity is None:
+        capacity = 6 * max(q_bank.n, 4096) + 32 * ncells + 4096
+    grid = {"width": target_grid.width, "height": target_grid.height, "cell_w": target_grid.cell_width,
+            "cell_h": target_grid.cell_height, "rows": target_grid.rows, "cols": target_grid.cols,
+            "margin": target_grid.margin}
+    try:
+        t_bank = context.bank_with_capacity(np.zeros((0, q_bank.dim), dtype=np.uint8), int(capacity))
+        ex = _ffi.Expander(context, q_bank, query_cache.original["positions"], query_cache.original["position_tree"],
+                           t_bank, None, None, grid, radius, lazy=True)
+    except _ffi.FastMatchHipError:
+        return False
+    return ex, t_bank
 
 
 def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):

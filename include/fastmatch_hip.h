@@ -40,9 +40,10 @@ typedef struct fm_ctx  fm_ctx;
 typedef struct fm_bank fm_bank;
 
 /* ABI revision of this header.  It changes whenever an existing signature or struct layout does (revision 3, r03:
- * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only).  A binding
+ * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only; revision 5, r04:
+ * fm_expand_desc gained the trailing `lazy`).  A binding
  * compares fm_abi_version() with the FM_ABI_VERSION it was written against before its first call.            */
-#define FM_ABI_VERSION 4
+#define FM_ABI_VERSION 5
 int  fm_abi_version(void);
 
 typedef struct fm_stats {
@@ -346,6 +347,11 @@ typedef struct fm_expand_desc {
                                    /* repeats a run that fills one in a state 4x as large   */
     int32_t        metric;         /* radius query metric: the reference builds its BallTree with
                                     * options["metric"] (cache.pyx:160, 276): FM_METRIC_*    */
+    int32_t        lazy;           /* non-zero: LAZY TARGET -- the reference's own mode (cache.pyx:102-106, 124-138: a cell's
+                                    * features are computed when the loop first reaches it).  `target` is a bank made with
+                                    * fm_bank_create_u8_cap (possibly empty), cell_off / target_pos are ignored; cells are
+                                    * added with fm_bank_append_u8 + fm_expand_set_cell and the pair is driven with
+                                    * fm_expand_run_lazy.  Integer-route banks.                                         */
 } fm_expand_desc;
 
 #define FM_METRIC_EUCLIDEAN 0      /* "minkowski" (p = 2), "euclidean": dx^2 + dy^2 <= r^2     */
@@ -363,6 +369,7 @@ typedef struct fm_expand_desc {
 #define FM_EXPAND_MATCH_FULL    4  /* 1, 4, 5: reported only when the run state could not grow any further */
 #define FM_EXPAND_TABLE_FULL    5
 #define FM_EXPAND_LIST_FULL     6  /* float32 round: more candidates inside the fp16 margin than fit  */
+#define FM_EXPAND_NEED_CELL     7  /* lazy target: the loop reached a cell that has not been added yet (fm_expand_run_lazy) */
 
 int  fm_expand_create(fm_ctx* ctx, const fm_expand_desc* desc, fm_expand** out);
 int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
@@ -377,6 +384,23 @@ int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
 int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double* const* seeds,
                    const int64_t* n_seeds, const double* tau, int64_t* n_matches,
                    int64_t* n_rounds, int64_t* n_pairs, int32_t* status);
+/* ---- lazy targets: the device loop with cells computed on demand (r04) ---------------------------------------------
+ * fastmatch.pyx:154 -> cache.pyx:102-106, 124-138: a grid cell's features are computed (SIFT on the cell's crop) the first
+ * time the expansion reaches it, so most cells of a large image are never computed.  With a lazy pair the loop still runs on
+ * the device: a round that needs a missing cell parks the loop's state and ends the launch with FM_EXPAND_NEED_CELL; the host
+ * computes that cell, appends its descriptors to the target bank, registers it and resumes.
+ *   fm_bank_create_u8_cap : a bank with room for `capacity` rows (n of them now, possibly 0).
+ *   fm_bank_append_u8     : n more rows at the next multiple of 32 rows (*first_row); FM_EINVAL when the capacity is used up.
+ *   fm_expand_set_cell    : cell (= col * rows + row) := rows [first_row, first_row + n_rows) with their full-image positions;
+ *                           n_rows = 0 for a cell without features.
+ *   fm_expand_run_lazy    : one run in slot 0, from the start (resume = 0) or from where the last launch parked (resume != 0).
+ *                           status 0: done (fm_expand_fetch); FM_EXPAND_NEED_CELL: *need_cell; else the device gave up.        */
+int  fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank);
+int  fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t n, int64_t* first_row);
+int  fm_expand_set_cell(fm_ctx* ctx, fm_expand* ex, int32_t cell, int64_t first_row, int64_t n_rows, const double* pos /*[n_rows][2]*/);
+int  fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seeds, int64_t n_seeds, double tau, int32_t resume,
+                        int64_t* n_matches, int64_t* n_rounds, int64_t* n_pairs, int32_t* status, int32_t* need_cell);
+
 /* Memory of the run states: fm_expand_info reports the bytes ONE run state of the pair takes (pending stack, seen /
  * found tables, result arrays: ~210 MB for a 300k-keypoint pair) and how many exist; fm_expand_trim frees the states
  * from slot `keep` (>= 1) on; fm_mem_info is hipMemGetInfo of the context's device.  fm_expand_run creates a state for

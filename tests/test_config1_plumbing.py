@@ -158,6 +158,63 @@ def test_readme_flow_on_pixels_equals_oracle(ctx, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_pixel_target_runs_the_loop_on_the_device_with_cells_computed_on_demand(ctx):
+    """The reference's own mode -- fastmatch.match(query_cache, PIXELS): a grid cell's features are computed when the loop
+    first reaches it (cache.pyx:102-106, 124-138).  r04: the loop still runs on the device; a round that needs a missing cell
+    parks, the host computes the cell (one call of the feature function), registers it and resumes.  Same matches, rounds and
+    computed cells as the host-driven loop and the oracle; later thresholds re-use the cells; a target bank that is too
+    small hands the run to the host loop."""
+    from fastmatch_amd import cache, fastmatch
+    from oracle import fastmatch_oracle as fo
+    img1 = texture(800, 640, seed=1)
+    mild = np.array([[1.0, 0.01, 18.0], [-0.008, 1.0, -11.0], [1e-5, -5e-6, 1.0]])
+    img4 = warp(img1, mild)
+    feat = standin.standin_features
+    kq, dq = feat(img4)
+    thumb_q = imaging.get_thumbnail(img4, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    mc = cache.Metric_Cache.from_arrays(dq, pos(kq), (800, 640), dtq, pos(ktq), (thumb_q.shape[1], thumb_q.shape[0]),
+                                        options={"context": ctx})
+    calls = {"dev": [], "host": []}
+
+    def counting(which):
+        def f(data):
+            calls[which].append(data.shape)
+            return feat(data)
+        return f
+    ds, hs = {}, {}
+    dev = fastmatch.match(mc, img1, {"context": ctx, "feature_function": counting("dev"), "stats": ds})
+    host = fastmatch.match(mc, img1, {"context": ctx, "feature_function": counting("host"), "stats": hs, "device_loop": False})
+    oq = fo.OQuery(dq, pos(kq), (800, 640), thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    thumb_t = imaging.get_thumbnail(img1, (400, 400))
+    ktt, dtt = feat(thumb_t)
+    ot = {"size": (800, 640), "image": img1, "feature_function": feat,
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    oget = fo.o_match(oq, ot, {})
+    cells_before = 0
+    for tau in (0.7, 0.9, 0.6):
+        ds.clear(); hs.clear()
+        got, ref, exp = dev(tau), host(tau), oget(tau)
+        assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds
+        assert len(got) == len(ref) == len(exp) > 20
+        for (ia, da), (ib, db), (ic, dc) in zip(got, ref, exp):
+            assert ia == ib == ic and da["ratio"] == db["ratio"] == dc["ratio"]
+            assert np.array_equal(da["positions"], db["positions"]) and np.array_equal(da["positions"], dc["positions"])
+        assert ds["rounds"] == hs["rounds"] == oget.rounds and ds["pairs"] == hs["pairs"]
+        # the same cells were computed, each once, and only the cells the loop reached
+        assert sorted(calls["dev"]) == sorted(calls["host"]) and 10 < len(calls["dev"]) - 1 < 17 * 13
+        assert ds.get("lazy_cells", 0) == len(calls["dev"]) - 1 - cells_before
+        cells_before = len(calls["dev"]) - 1
+    many = dev([0.9, 0.7])
+    assert [len(m) for m in many] == [len(oget(0.9)), len(oget(0.7))]
+    # a target bank with room for 64 rows: the second cell does not fit -> host loop, same result
+    fb = {}
+    small = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": fb, "lazy_capacity": 64})(0.7)
+    assert "device_loops" not in fb and fb["rounds"] == oget.rounds and len(small) == len(oget(0.7))
+
+
+@pytest.mark.gpu
 def test_readme_flow_on_the_graf_pixels(ctx, tmp_path, monkeypatch, capsys):
     """BASELINE.json configs[0] on the reference's OWN pixels (tests/golden/graf: images/graf/img1 and img4,
     re-encoded as PNG; H1to4p): README.md:41-50 with the stand-in extractor in place of cv2 SIFT (absent on

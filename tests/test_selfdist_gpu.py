@@ -143,6 +143,18 @@ def test_self_dist_batch_attaches_and_matches(ctx):
         assert _eq(g, oracle.self_dist(m))
     with pytest.raises(_ffi.FastMatchHipError):
         ctx.self_dist_batch([banks[0], banks[0]])
+    # launches of at most two banks (option batch_group), float32 banks in the enqueue-only form
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    c.set_option("batch_group", 2)
+    five = [c.bank(m) for m in (mats[0], mats[1], mats[8], mats[0], mats[1])] + [c.bank(mats[5])]
+    assert c.self_dist_batch(five, want_host=False) is None
+    c.sync()
+    for m, g in zip((mats[0], mats[1], mats[8], mats[0], mats[1], mats[5]), c.self_dist_batch(five)):
+        assert _eq(g, oracle.self_dist(m, order=1))
+    tq, _, _, _, _ = c.match_ratio(five[5], five[5], 2.0)          # (the float32 bank's attached values are in use)
+    assert tq.shape == (900,)
+    c.close()
 
 
 def test_refill_gives_what_a_fresh_bank_gives(ctx):
