@@ -11,13 +11,17 @@ shapes and log schema):
 * ``match_position`` reference ``fastmatch.pyx:145-169`` -- one expansion round
 * ``log_round``      reference ``fastmatch.pyx:172-180``
 
-What runs where: the descriptor arithmetic of every round -- OpenCV's
-``BFMatcher(NORM_L2, crossCheck=True).knnMatch`` plus the float64 ratio -- is one launch
-of the HIP round kernel on banks that stay resident on the device (the query bank with
-its self distances, one bank per computed grid cell).  Only the query-row indices of the
-radius subset go up and the per-slot (train index, distance, ratio) triples come back.
-The expansion loop itself is replayed on the host in the reference's exact depth-first
-order, because the match set depends on that order.
+What runs where: the whole expansion loop runs on the device (K7, ``fm_expand_*``: one persistent
+workgroup per run replays the reference's exact depth-first order -- the match set depends on it,
+SURVEY.md fact 9): for a ``cache.Feature_Image`` target (every feature known up front) in one
+launch per call, any number of (pair, threshold) runs side by side; for the reference's PIXEL
+target, whose cells are computed when the loop first reaches them (cache.pyx:102-106, 124-138), the
+kernel parks at a missing cell and the host computes it and resumes (``lazy_device_loop``).  Only
+when a per-round ``log`` is wanted, the descriptors are float32 with a pixel target, or a capacity
+of the device loop is exceeded does the host replay the loop (``do_iter``): each round's arithmetic --
+OpenCV's ``BFMatcher(NORM_L2, crossCheck=True).knnMatch`` plus the float64 ratio -- is then one launch
+of the HIP round kernel on banks that stay resident (the query bank with its self distances, one bank
+per computed grid cell); the radius subset's row indices go up, (train index, distance, ratio) come back.
 
 ``target_img`` is either the reference's ``uint8[H, W, 3]`` array (SIFT through OpenCV on
 the host, needs ``cv2``) or a ``cache.Feature_Image`` carrying pre-extracted features.
