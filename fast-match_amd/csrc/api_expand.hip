@@ -98,7 +98,8 @@ static int expand_ensure_run(fm_ctx* ctx, fm_expand* ex, size_t slot)
 static int expand_run_huge(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
 {
     if (r.huge) return FM_OK;
-    const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1), tm = (size_t)(ex->tmax > 0 ? ex->tmax : 1);
+    // (a lazy target's cells are not known yet: room for the whole target bank's capacity)
+    const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1), tm = (size_t)(ex->lazy ? ex->t_cap : (ex->tmax > 0 ? ex->tmax : 1));
     hipError_t e = hipMalloc(&r.huge, al256(nq * 4) + al256(nq * 8) + al256(tm * 8));
     if (e != hipSuccess) { (void)hipGetLastError(); r.huge = nullptr; return fail(ctx, FM_ENOMEM, std::string("fm_expand: chunked-round tables: ") + hipGetErrorString(e)); }
     return FM_OK;
@@ -275,8 +276,9 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
         if (n_seeds) HIP_TRY(ctx, hipMemcpyAsync(r->d_seeds, seeds, (size_t)n_seeds * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
     }
+    if ((rc = expand_run_huge(ctx, ex, *r)) != FM_OK) return rc;       // the chunked rounds' tables (the lazy kernel is the chunked one)
     ExpandPair host = ex->dev;
-    expand_bind_run(host, *r);
+    expand_bind_run(host, *r, ex);
     host.seeds = r->d_seeds; host.n_seeds = n_seeds; host.tau = tau; host.prof = 0;
     host.resume = resume ? 1 : 0;
     host.tie_guard = sqrt_tie_possible(*ex->query, *ex->lazy_target) ? 1 : 0;     // (the target bank has grown since the pair was made)

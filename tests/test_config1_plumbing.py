@@ -208,6 +208,14 @@ def test_pixel_target_runs_the_loop_on_the_device_with_cells_computed_on_demand(
         cells_before = len(calls["dev"]) - 1
     many = dev([0.9, 0.7])
     assert [len(m) for m in many] == [len(oget(0.9)), len(oget(0.7))]
+    # radius 300: subsets of thousands of rows (beyond the LDS tables) -- the lazy kernel is the chunked one
+    big = {}
+    wide = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": big, "radius": 300})(0.7)
+    wexp = fo.o_match(oq, ot, {"radius": 300})(0.7)
+    assert big.get("device_loops") == 1 and "device_fallbacks" not in big and len(wide) == len(wexp) > 20
+    assert big["pairs"] > 50 * 2048 * big["rounds"] / 4            # (subsets really are that large)
+    for (ia, da), (ib, db) in zip(wide, wexp):
+        assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
     # a target bank with room for 64 rows: the second cell does not fit -> host loop, same result
     fb = {}
     small = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": fb, "lazy_capacity": 64})(0.7)
