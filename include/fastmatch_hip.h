@@ -391,6 +391,9 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
  * computes that cell, appends its descriptors to the target bank, registers it and resumes.
  *   fm_bank_create_u8_cap : a bank with room for `capacity` rows (n of them now, possibly 0).
  *   fm_bank_append_u8     : n more rows at the next multiple of 32 rows (*first_row); FM_EINVAL when the capacity is used up.
+ *                           The rows skipped in between are padding rows (never a nearest neighbour); a grown bank is meant for
+ *                           fm_expand (cells name their own row ranges) -- as the TRAIN side of a dense call they would be
+ *                           output rows like any other.
  *   fm_expand_set_cell    : cell (= col * rows + row) := rows [first_row, first_row + n_rows) with their full-image positions;
  *                           n_rows = 0 for a cell without features.
  *   fm_expand_run_lazy    : one run in slot 0, from the start (resume = 0) or from where the last launch parked (resume != 0).

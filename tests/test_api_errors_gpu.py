@@ -155,3 +155,53 @@ def test_batch_calls_reject_bad_arguments_and_the_context_survives(ctx):
         ctx.match_accepted_dev_batch([(qb, tb)], 0.7, np.zeros((600, 3), np.int32).ctypes.data,
                                      np.zeros(1, np.int64).ctypes.data, 600)
     ctx.sync()
+
+
+def test_growing_banks_refills_and_lazy_pairs_reject_misuse(ctx):
+    """r04 entry points: fm_bank_create_u8_cap / fm_bank_append_u8 (rows land on 32-row boundaries, the appended bank matches a
+    bank made of the same rows), fm_bank_refill_u8_async, fm_expand_set_cell / fm_expand_run_lazy argument checks."""
+    rng = np.random.default_rng(8)
+    A, B, C = (synth.synth_sift(n, rng) for n in (100, 37, 64))
+    T = synth.synth_sift(500, rng)
+    tb = ctx.bank(T)
+    g = ctx.bank_with_capacity(A, 400)
+    assert g.n == 100 and g.append(B) == 128 and g.n == 165 and g.append(C) == 192 and g.n == 256
+    assert g.append(np.zeros((0, 128), np.uint8)) == 256 and g.n == 256
+    # the rows between the pieces are padding rows: as the reduced (query) side of a cross-check they are never elected and
+    # come back unmatched, and the real rows behave like the same rows in a bank of their own
+    whole = np.zeros((256, 128), np.uint8)
+    whole[:100], whole[128:165], whole[192:256] = A, B, C
+    real = np.r_[0:100, 128:165, 192:256]
+    gap = np.setdiff1d(np.arange(256), real)
+    t1, d1 = ctx.xcheck1(g, tb)
+    t2, d2 = ctx.xcheck1(ctx.bank(whole[real]), tb)
+    assert np.array_equal(t1[real], t2) and np.array_equal(d1[real], d2) and np.all(t1[gap] == -1) and (t2 >= 0).sum() > 50
+    with pytest.raises(Err):                                   # (a capacity of 400 rows is rounded up to 512)
+        ctx.bank_with_capacity(A, 400).append(synth.synth_sift(600, rng))
+    with pytest.raises(ValueError):
+        g.append(np.zeros((3, 64), np.uint8))
+    f = ctx.bank(A.astype(np.float32) + 0.5)
+    with pytest.raises(Err):                                   # float32-route banks neither grow nor refill
+        ctx._check(ctx.lib.fm_bank_append_u8(ctx.handle, f.handle, A.ctypes.data, 10, None))
+    with pytest.raises(Err):
+        ctx._check(ctx.lib.fm_bank_refill_u8_async(ctx.handle, f.handle, A.ctypes.data, 10))
+    # lazy pairs: a non-lazy expander takes neither set_cell nor run_lazy; a lazy one does not take fm_expand_run
+    q, t = synth.image_pair((300, 200), 400, seed=5)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    from fastmatch_amd import fastmatch
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"], t["thumb_descriptors"], t["thumb_size"])
+    eager = fastmatch.match(mc, fi, {"context": ctx}).expander()
+    with pytest.raises(Err):
+        eager.set_cell(0, 0, np.zeros((0, 2)))
+    with pytest.raises(Err):
+        eager.run_lazy(np.zeros((0, 2, 2)), 0.7, False)
+    grid = fastmatch.Grid_Cache(np.zeros((200, 300, 3), np.uint8), (50, 50), None, margin=25)
+    lazy, tbank = fastmatch.make_lazy_expander(mc, grid, 100, ctx)
+    with pytest.raises(Err):
+        ctx.expand_run([lazy], [np.zeros((0, 2, 2))], [0.7])
+    with pytest.raises(Err):
+        lazy.set_cell(10 ** 6, 0, np.zeros((0, 2)))             # no such cell
+    with pytest.raises(Err):
+        lazy.set_cell(0, 0, np.zeros((5, 2)))                   # rows the target bank does not hold
+    assert lazy.run_lazy(np.zeros((0, 2, 2)), 0.7, False)[3] == 0        # no seeds: done at once
