@@ -372,7 +372,7 @@ class Context(object):
     def set_option(self, name, value):
         """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
         "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
-        "async_time_every", "k1_order", "expand_big", "expand_grow", "expand_prof".  Results never depend on them."""
+        "async_time_every", "k1_order", "bound_every", "refill_grid", "expand_big", "expand_huge", "expand_delegate", "expand_grow", "expand_prof".  Results never depend on them."""
         self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def get_option(self, name):

@@ -20,6 +20,7 @@ struct ExpandRun {
     double* m_pos = nullptr;
     double* m_ratio = nullptr;
     long long* result = nullptr;
+    long long* resume_state = nullptr;   // loop state of a parked run (lazy targets, delegated cross-checks)
     double* d_seeds = nullptr;     // grown on demand
     int64_t seeds_cap = 0;
     // capacities of THIS run state: they start at the pair's defaults and are multiplied by four when a run
@@ -39,6 +40,7 @@ struct fm_expand {
     bool lazy = false;
     fm_bank* lazy_target = nullptr;    // (borrowed) the capacity bank whose arrays dev.t_rows8 / t_norm point into
     const fm_bank* query = nullptr;
+    const fm_bank* target = nullptr;
     void* lazy_blob = nullptr;     // cell_start i64[ncells] | cell_cnt i32[ncells] | cell_ready i32[ncells] | resume state
     int64_t ncells = 0, t_cap = 0;
     double* d_tpos = nullptr;      // (inside blob) [t_cap][2]
@@ -67,7 +69,7 @@ static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
     // (seen and found are neighbours: one fill resets both)
     const size_t o_stack = carve((size_t)r.stack_cap * 32), o_seen = carve((size_t)r.seen_cap * 8), o_found = carve((size_t)r.found_cap * 16);
     const size_t o_mi = carve((size_t)r.match_cap * 4), o_mp = carve((size_t)r.match_cap * 32), o_mr = carve((size_t)r.match_cap * 8);
-    const size_t o_res = carve(256);
+    const size_t o_res = carve(256), o_resume = carve(256);
     hipError_t e = hipMalloc(&r.blob, off);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -78,6 +80,7 @@ static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
     r.stack = (double*)(b + o_stack); r.seen = (unsigned long long*)(b + o_seen); r.found = (unsigned long long*)(b + o_found);
     r.m_index = (int32_t*)(b + o_mi); r.m_pos = (double*)(b + o_mp); r.m_ratio = (double*)(b + o_mr);
     r.result = (long long*)(b + o_res);
+    r.resume_state = (long long*)(b + o_resume);
     return FM_OK;
 }
 
@@ -119,6 +122,7 @@ static void expand_bind_run(ExpandPair& P, const ExpandRun& r, const fm_expand* 
     P.found = r.found; P.found_cap = r.found_cap;
     P.m_index = r.m_index; P.m_pos = r.m_pos; P.m_ratio = r.m_ratio; P.match_cap = r.match_cap;
     P.result = r.result;
+    P.resume_state = r.resume_state;
 }
 
 extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
@@ -170,7 +174,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (!ex) return fail(ctx, FM_ENOMEM, "fm_expand_create: out of host memory");
     ex->nq = nq;
     if (!lazy) for (int64_t c = 0; c < ncells; ++c) ex->tmax = std::max<int64_t>(ex->tmax, d->cell_off[c + 1] - d->cell_off[c]);
-    ex->lazy = lazy; ex->lazy_target = lazy ? const_cast<fm_bank*>(d->target) : nullptr; ex->query = d->query;
+    ex->lazy = lazy; ex->lazy_target = lazy ? const_cast<fm_bank*>(d->target) : nullptr; ex->query = d->query; ex->target = d->target;
     ex->ncells = ncells; ex->t_cap = lazy ? d->target->cap_pad : nt;
     ex->match_cap = d->match_cap > 0 ? d->match_cap : (4 * nq > 1024 ? 4 * nq : 1024);
     ex->stack_cap = d->stack_cap > 0 ? d->stack_cap : (64 * ncells > 65536 ? 64 * ncells : 65536);
@@ -403,6 +407,8 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         host[i].n_seeds = n_seeds[i];
         host[i].tau = tau[i];
         host[i].prof = ctx->tune.expand_prof;
+        host[i].resume = 0;
+        host[i].delegate_min = 0;
     }
     // the int8 and the float32 pairs are different kernels, and so are the capacity tiers of the int8 one (a pair starts
     // in the tier its last complete run needed): descriptors grouped by kernel, one launch each
@@ -415,6 +421,12 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         big[(size_t)i] = (char)t;
         if (t == 2) expand_bind_run(host[i], *run[(size_t)i], pairs[i]);
     }
+    // Chunked int8 runs hand a big round's cross-check to the dense kernels (expand.hip, DELEGATED); phase timers off then
+    // (a parked run's timers would restart)
+    auto set_delegate = [&](int i) {
+        host[i].delegate_min = (big[(size_t)i] == 2 && !host[i].f32 && !host[i].tie_guard && !host[i].prof) ? ctx->tune.expand_delegate : 0;
+    };
+    for (int i = 0; i < n; ++i) set_delegate(i);
     // kernel of a run: int8 tiers 0 / 1 / 2, float32 tiers 0 / 2
     auto group_of = [&](int i) { return host[i].f32 ? (big[(size_t)i] == 2 ? 4 : 3) : (int)big[(size_t)i]; };
     auto launch_groups = [&](const std::vector<int>& idx) -> int {
@@ -442,6 +454,40 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     for (int i = 0; i < n; ++i)
         HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // Parked runs (status 8: a round's cross-check is wanted from the dense kernels): per run the subset's rows are in its
+    // h_cand[], the round's (subset size, first train row, train rows) in its resume state; K1 + the election fill its
+    // h_qbest[] on the whole GPU, then the parked runs are launched again with resume = 2 -- until none parks.
+    int64_t delegated = 0;
+    auto settle_parked = [&](const std::vector<int>& among) -> int {
+        std::vector<int> parked;
+        for (int i : among) if (res[(size_t)i * 4 + 3] == 8) parked.push_back(i);
+        while (!parked.empty()) {
+            std::vector<long long> st(parked.size() * 3);
+            for (size_t k = 0; k < parked.size(); ++k)
+                HIP_TRY(ctx, hipMemcpyAsync(&st[k * 3], run[(size_t)parked[k]]->resume_state + 10, 24, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t k = 0; k < parked.size(); ++k) {
+                const int i = parked[k];
+                int rc2 = round_xcheck_dense(ctx, *pairs[i]->query, host[i].h_cand, st[k * 3], *pairs[i]->target, st[k * 3 + 1], st[k * 3 + 2], host[i].h_qbest);
+                if (rc2 != FM_OK) return rc2;
+                host[i].resume = 2;
+                ++delegated;
+            }
+            int rc2 = launch_groups(parked);
+            if (rc2 != FM_OK) return rc2;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+            for (int i : parked) {
+                host[i].resume = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<int> again;
+            for (int i : parked) if (res[(size_t)i * 4 + 3] == 8) again.push_back(i);
+            parked.swap(again);
+        }
+        return FM_OK;
+    };
+    if ((rc = settle_parked(all_runs)) != FM_OK) return rc;
     // Runs that ended on a capacity run again, from the start: a radius subset beyond the kernel's 2048 rows
     // (status 2, int8 banks) in the 4096-row variant of the kernel and, beyond that, in the variant that takes a
     // subset of any size in chunks (option expand_huge; not for pairs under the float32-root guard); a full pending stack, result list or
@@ -458,6 +504,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 if (expand_run_huge(ctx, pairs[i], *r) == FM_OK) {
                     big[(size_t)i] = 2;
                     expand_bind_run(host[i], *r, pairs[i]);
+                    set_delegate(i);
                     redo.push_back(i);
                 }
                 continue;                                 // (no memory for the tables: the status stands)
@@ -485,6 +532,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         for (int i : redo)
             HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // (ws_in is reused by the next pass)
+        if ((rc = settle_parked(redo)) != FM_OK) return rc;
     }
     for (int i = 0; i < n; ++i) {
         ctx->pending_pairs += res[(size_t)i * 4 + 2];

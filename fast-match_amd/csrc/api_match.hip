@@ -427,6 +427,78 @@ static int enqueue_election(fm_ctx* ctx, hipStream_t s, const fm_bank* q, const 
 }
 
 // ---------------------------------------------------------------------------------------
+// K7's delegated cross-check: one expansion round's X1 on the whole GPU
+// ---------------------------------------------------------------------------------------
+// The rows rows[0 .. nq) of bank q gathered into a bank image of their own (rows, norms, aux words in the layout
+// bank_prep_kernel writes; slots past nq are padding rows).  One 256-thread block per 32-row tile.
+__global__ __launch_bounds__(256)
+void gather_rows_kernel(const int32_t* __restrict__ rows, int64_t nq, const int8_t* __restrict__ src8, const int32_t* __restrict__ srcnorm,
+                        int8_t* __restrict__ dst8, int32_t* __restrict__ dstnorm, int32_t* __restrict__ dstaux)
+{
+    const int tid = threadIdx.x, r = tid >> 3, c = tid & 7;
+    const int64_t tile = blockIdx.x, slot = tile * kTileRows + r;
+    uint4 w = make_uint4(0, 0, 0, 0);
+    int nm = 0;
+    if (slot < nq) {
+        const int64_t qi = rows[slot];
+        w = *(const uint4*)(src8 + qi * kDim + 16 * c);
+        nm = srcnorm[qi];
+    }
+    *(uint4*)(dst8 + slot * kDim + 16 * c) = w;
+    if (c == 0) {
+        const int sub = r >> 4, rr = r & 15, id = 4 * sub + (rr & 3);
+        int32_t* a = dstaux + tile * kAuxPerTile + 32 * sub;
+        if (slot < nq) { dstnorm[slot] = nm; a[rr] = -(nm >> 1); a[16 + rr] = ((1 - (nm & 1)) << 4) | (15 - id); }
+        else           { dstnorm[slot] = 0;  a[rr] = kPadCinit;  a[16 + rr] = 15 - id; }
+    }
+}
+
+// Cross-checked 1-NN of the query subset d_rows[0 .. nq) of bank q against the train rows [t0, t0 + nt) of bank t, the
+// way fm_xcheck1 does it on gathered banks (reverse NN by K1 with the train rows as output rows, election by
+// scatter-min), into d_qbest[slot] = (float32 distance bits << 32 | local train row), ~0 = unmatched.  Enqueued on the
+// context's stream; the workspaces are the context's (ws_out: the gathered bank, ws_partial: K1's partials).  For
+// integer-route pairs outside the float32-root tie range (the caller checks).
+int fm::round_xcheck_dense(fm_ctx* ctx, const Bank& q, const int32_t* d_rows, int64_t nq, const Bank& t, int64_t t0, int64_t nt,
+                           unsigned long long* d_qbest)
+{
+    if (nq <= 0 || nt <= 0) return FM_OK;
+    const int64_t nq_pad = ((nq + kStageRows - 1) / kStageRows) * kStageRows;
+    size_t off = 0;
+    auto carve = [&](size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
+    const size_t o_rows = carve((size_t)nq_pad * kDim), o_norm = carve((size_t)nq_pad * 4), o_aux = carve((size_t)(nq_pad / kTileRows) * kAuxPerTile * 4);
+    int rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, off + 64);
+    if (rc != FM_OK) return rc;
+    char* b = (char*)ctx->ws_out;
+    Bank gq;
+    gq.kind = FM_BANK_I8; gq.n = nq; gq.dim = q.dim; gq.n_pad = nq_pad; gq.cap_pad = nq_pad;
+    gq.rows8 = (int8_t*)(b + o_rows); gq.norm = (int32_t*)(b + o_norm); gq.aux = (int32_t*)(b + o_aux);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nq_pad / kTileRows)), dim3(256), 0, ctx->stream, d_rows, nq,
+                       (const int8_t*)q.rows8, (const int32_t*)q.norm, gq.rows8, gq.norm, gq.aux);
+    HIP_TRY(ctx, hipGetLastError());
+    // the cell's rows as a bank of their own: a view into the target bank (rows past nt are other cells' rows or padding;
+    // what K1 computes for them is never looked at)
+    Bank tv;
+    tv.kind = FM_BANK_I8; tv.n = nt; tv.dim = t.dim;
+    tv.n_pad = ((nt + kStageRows - 1) / kStageRows) * kStageRows;
+    const int64_t room = (t.cap_pad > 0 ? t.cap_pad : t.n_pad) - t0;
+    if (tv.n_pad > room) tv.n_pad = room;
+    tv.cap_pad = tv.n_pad;
+    tv.rows8 = t.rows8 + (size_t)t0 * kDim; tv.norm = t.norm + t0; tv.aux = nullptr;
+    const RowReducePlan pl = plan_rowreduce(tv.n_pad, gq.n_pad, ctx->tune);
+    const size_t pbytes = (pl.partial_bytes(1) + 255) & ~(size_t)255;
+    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pbytes + pl.bound_bytes() + 64)) != FM_OK) return rc;
+    int* d_bound = ((ctx->tune.coop != 0) && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pbytes) : nullptr;
+    if (d_bound) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+    HIP_TRY(ctx, launch_rowreduce(tv, gq, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, (ctx->tune.glds != 0), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
+    const int64_t sthreads = nt * 4;
+    hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, 0u, 0, (int*)nullptr, (unsigned*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // K2 entry points
 // ---------------------------------------------------------------------------------------
 // Device-side knn2 into d_idx/d_dist (device pointers).

@@ -123,6 +123,9 @@ void sync_all_streams(fm_ctx* ctx);
 int check_pair(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, const char* who);
 // Planes and scale terms of a (query = reduced, train = output rows) pair of float32 banks for x1_round_f32.
 void fill_round_f32(fm::RoundF32* r, const fm::Bank& q, const fm::Bank& t);
+// One expansion round's cross-checked 1-NN on the whole GPU (K7's delegated cross-check, api_match.hip).
+int round_xcheck_dense(fm_ctx* ctx, const fm::Bank& q, const int32_t* d_rows, int64_t nq, const fm::Bank& t, int64_t t0, int64_t nt,
+                       unsigned long long* d_qbest);
 }
 
 // Brackets one API call: events for total time, stats accounting after the final sync.

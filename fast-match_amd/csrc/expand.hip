@@ -53,7 +53,7 @@ struct ExpCfg {
 };
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
-       kExpListFull = 6, kExpNeedCell = 7 };
+       kExpListFull = 6, kExpNeedCell = 7, kExpNeedXcheck = 8 };
 static_assert(kRF_StageBytes <= ExpCfg<kExpCand>::kStageBytes, "the float32 round's gather image must fit the stage buffer");
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -416,6 +416,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<long long> result; int prof;
         gptr<int32_t> h_cand; gptr<unsigned long long> h_qbest, h_tbest;
         gptr<const int64_t> cell_start; gptr<const int32_t> cell_cnt, cell_ready; gptr<long long> resume_state; int resume;
+        long long delegate_min;
     } P;
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
     P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos; P.q_pos_ord = (gptr<const double>)M.q_pos_ord;
@@ -433,7 +434,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.match_cap = M.match_cap; P.result = (gptr<long long>)M.result; P.prof = M.prof;
     P.h_cand = (gptr<int32_t>)M.h_cand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest;
     P.cell_start = (gptr<const int64_t>)M.cell_start; P.cell_cnt = (gptr<const int32_t>)M.cell_cnt; P.cell_ready = (gptr<const int32_t>)M.cell_ready;
-    P.resume_state = (gptr<long long>)M.resume_state; P.resume = M.resume;
+    P.resume_state = (gptr<long long>)M.resume_state; P.resume = M.resume; P.delegate_min = M.delegate_min;
     const RoundF32G RF(M.rf);
     const int tid = threadIdx.x;
 
@@ -448,20 +449,22 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     if (tid == 0) { for (int k = 0; k < 12; ++k) pt[k] = 0; tstamp = P.prof ? wall_clock64() : 0; }
 #define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
 
-    bool skip_pop = false;        // (uniform) LAZY: the first round of a resumed run takes the saved entry
+    bool skip_pop = false;        // (uniform) the first round of a resumed run takes the saved entry
+    bool skip_x = false;          // (uniform) ... and, resumed behind a DELEGATED cross-check (P.resume == 2), goes straight to steps 4 / 5
     int need_cell = -1;
-    if constexpr (LAZY) {
+    if constexpr (LAZY || HUGE) {
         if (P.resume) {
             top = P.resume_state[0]; seed_i = P.resume_state[1]; n_matches = P.resume_state[2];
             n_rounds = P.resume_state[3]; n_pairs = P.resume_state[4]; seen_n = P.resume_state[5];
             if (tid == 0) for (int k = 0; k < 4; ++k) cur[k] = __longlong_as_double(P.resume_state[6 + k]);
             skip_pop = true;
+            skip_x = P.resume == 2;
         }
     }
 
     for (;;) {
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
-        if (LAZY && skip_pop) {
+        if ((LAZY || HUGE) && skip_pop) {
             skip_pop = false;
             if (tid == 0) {
                 nxt_valid = 0;
@@ -581,6 +584,19 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             t0 = P.cell_off[cell];
             t1 = P.cell_off[cell + 1];
         }
+        int nq = 0;
+        bool huge_round = false;                            // (uniform)
+        bool fkeys = false;                                 // (uniform) h_qbest holds float32 distance bits (a delegated cross-check's keys)
+        char* const cell_lds = dyn_lds + C::kLdsBytes - kCellStageBytes;
+        const int nt = (int)(t1 - t0);
+        if (HUGE && skip_x) {
+            // resumed behind a delegated cross-check: the subset is in h_cand[], the host's dense kernels left the round's
+            // cross-checked keys in h_qbest[]; the round goes on with steps 4 / 5
+            skip_x = false;
+            nq = (int)P.resume_state[10];
+            huge_round = true;
+            fkeys = true;
+        } else {
         ++n_rounds;
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
@@ -634,8 +650,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
         }
         lds_barrier();
-        const int nq = sh_i[4];
-        bool huge_round = false;                            // (uniform)
+        nq = sh_i[4];
         if (nq > CAND) {
             // (the chunked round has no float32-root repair: a pair under the guard -- re-derived per launch for a growing
             // lazy target -- gives the round back)
@@ -643,8 +658,6 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             else { status = kExpCandFull; break; }
         }
         EXP_STAMP(1);
-        char* const cell_lds = dyn_lds + C::kLdsBytes - kCellStageBytes;
-        const int nt = (int)(t1 - t0);
         if (!huge_round) {
         // The cell's first 128 descriptor rows (int8 round: the MFMA B operand) go to LDS by DMA from here: the sort
         // touches no global memory, so their latency passes under it and no register waits for them (issued in
@@ -725,6 +738,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             lds_barrier();
             const int nch = sh_i[5];
             if (nch < 0) { status = kExpCandFull; break; }
+            // DELEGATED cross-check (r04): a round of this size is minutes of one CU's matrix cores at a fraction of their
+            // rate, and microseconds of the whole chip's.  The round sorts its subset into h_cand[] as always, then PARKS
+            // the run (the state a lazy run saves, + the subset's size); fm_expand_run gathers the subset's rows, runs the
+            // dense reverse-NN kernel (K1) and the election on the whole GPU into h_qbest[] and resumes the run at steps 4 / 5.
+            const bool deleg = !F32 && !LAZY && P.delegate_min > 0 && (long long)nq * nt >= P.delegate_min;
             unsigned base = 0;
             for (int c = 0; c < nch; ++c) {
                 const int b0 = chb[c], b1 = chb[c + 1];
@@ -743,6 +761,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int nc = sh_i[4];
                 block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, (double)b1 / bscale, (double)b0 / bscale);
                 for (int i = tid; i < nc; i += kExpThreads) P.h_cand[base + i] = cand[i];
+                if (deleg) { base += (unsigned)nc; continue; }
                 if constexpr (F32) {
                     // (the candidate list aliases the sort scratch, free until the next chunk's sort)
                     lds_barrier();
@@ -758,6 +777,17 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 base += (unsigned)nc;
             }
             if (status != kExpOk) break;      // (a float32 chunk whose candidate list overflowed)
+            if (deleg) {
+                if (tid == 0) {
+                    P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
+                    P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
+                    for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
+                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt;
+                }
+                need_cell = cell;
+                status = kExpNeedXcheck;
+                break;
+            }
             // (b) election: train row t elects the slot its minimum names; the slot keeps its closest train row
             __syncthreads();                  // the fill of h_qbest and the copies of h_cand have reached memory
             if (tid < 128)
@@ -770,6 +800,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             __syncthreads();
         }
         if constexpr (F32) lds_barrier();
+        }
 
         EXP_STAMP(3);
         // ---- 4./5. accepted matches: neighbours and new results, in slot order ------------------
@@ -873,7 +904,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     else qb = keys[i];
                     if (qb != ~0ull) {
                         // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
-                        const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
+                        const float d = (F32 || (HUGE && fkeys)) ? __uint_as_float((unsigned)(qb >> 32))
+                                                                 : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
                         // the positions step (b) needs ride on the same memory round trip as the self distance
                         if (HUGE && huge_round) qrow = __hip_atomic_load(P.h_cand + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else qrow = cand[i];
@@ -1053,7 +1085,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[2] = n_pairs;
         P.result[3] = status;
         if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
-        if constexpr (LAZY) P.result[4] = need_cell;
+        if constexpr (LAZY || HUGE) P.result[4] = need_cell;
     }
 }
 

@@ -51,8 +51,12 @@ struct ExpandPair {
     const int64_t* cell_start;     // [cols*rows]
     const int32_t* cell_cnt;       // [cols*rows]
     const int32_t* cell_ready;     // [cols*rows] 0 = not computed yet
-    long long* resume_state;       // [10] loop state of a parked run (top, seed cursor, counters, the popped entry)
-    int        resume;             // non-zero: restore resume_state and take its entry first
+    long long* resume_state;       // [13] loop state of a parked run (top, seed cursor, counters, the popped entry; a delegated
+                                   // cross-check: + subset size, first train row, train rows)
+    int        resume;             // 1: restore resume_state and take its entry first; 2: ... and go straight to steps 4 / 5
+                                   // (the round's cross-checked keys are in h_qbest)
+    long long  delegate_min;       // > 0: rounds of at least this many descriptor pairs whose subset does not fit LDS are parked
+                                   // for a dense cross-check on the whole GPU (expand.hip, DELEGATED)
     long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers (lazy: [4] = the cell wanted)
     int        prof;               // non-zero: thread 0 accumulates per-phase 100 MHz ticks
 };

@@ -91,6 +91,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *                         the distance kernels)
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
  *   "expand_huge"  0|1    K7: ... and those that still do in the variant that takes a radius subset of any size in chunks (1)
+ *   "expand_delegate" 0.. K7: a chunked round of at least this many descriptor pairs parks its run; the round's cross-check
+ *                         is run by the dense kernels on the whole GPU and the run resumed (1 500 000; 0 = never)
  *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
  *                         repeated in a run state four times as large (2)
  *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
