@@ -196,12 +196,24 @@ def leg_expand_c3_clustered(ctx, uniform_rounds_per_s, reps=2):
         if best is None or wall < best[0]:
             best = (wall, stats.get("rounds", 0), stats.get("pairs", 0), len(index), stats.get("device_fallbacks", 0))
     wall, rounds, pairs, nm, fb = best
+    # the same run with every round's cross-check done by the run's own workgroup (no delegation to the dense kernels)
+    dmin = ctx.get_option("expand_delegate")
+    ctx.set_option("expand_delegate", 0)
+    try:
+        t0 = time.perf_counter()
+        get(TAU)
+        own_wall = time.perf_counter() - t0
+    finally:
+        ctx.set_option("expand_delegate", dmin)
     return {"workload": "configs[2] geometry, 300k keypoints/side, half of them in 12 Gaussian blobs (sigma 60 px), p 0.15, tau 0.7",
+            "delegate_min_descriptor_pairs": dmin, "wall_s_without_delegation": own_wall,
             "largest_radius_subset_sampled": dens, "wall_s": wall, "first_run_wall_s": first, "rounds": rounds,
             "descriptor_pairs": pairs, "matches": nm, "rounds_per_s": rounds / wall, "pairs_per_s": pairs / wall,
             "device_fallbacks": fb, "uniform_rounds_per_s": uniform_rounds_per_s,
             "note": "first_run_wall_s includes the runs in the 2048- and 4096-row kernels that end at the first oversize subset; "
-                    "later runs of the pair start in the chunked variant (tier hint)"}
+                    "later runs of the pair start in the chunked variant (tier hint).  Rounds of >= delegate_min descriptor pairs park "
+                    "the run: their cross-check is K1 + the election on the whole GPU (fm_expand_run), the run resumes at steps 4 / 5; "
+                    "wall_s_without_delegation = the round's own workgroup does every cross-check in chunks"}
 
 
 def leg_expand_c3_taus(ctx, get, single_wall):

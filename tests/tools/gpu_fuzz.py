@@ -16,6 +16,7 @@ from oracle import fastmatch_oracle as fo
 from kat import far_banks
 
 ctx = None                      # set by run()
+ONLY = os.environ.get("FM_FUZZ_ONLY", "")      # "match": image pairs through fastmatch.match() only
 eq = lambda a, b: a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
@@ -134,6 +135,8 @@ def fuzz_match(rng):
     ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
           "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
     stats = {}
+    # r04: big rounds park for a dense cross-check from this many descriptor pairs on (1 = every chunked round, 0 = never)
+    ctx.set_option("expand_delegate", int(rng.choice([0, 1, 200000, 1500000])))
     get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4))))
     oget = fo.o_match(oq, ot, dict(opts))
     taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
@@ -155,13 +158,13 @@ def run(budget, seed0, max_problems=None, context=None):
     Returns (problems, counts by kind); raises AssertionError at the first difference."""
     global ctx
     ctx = context if context is not None else fm.Context(0)
-    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter", "k1_order", "bound_every")}
+    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter", "k1_order", "bound_every", "expand_delegate")}
     counts = {}
     t0, it = time.time(), 0
     try:
         while time.time() - t0 < budget and (max_problems is None or it < max_problems):
             rng = np.random.default_rng(seed0 + it)
-            fn = fuzz_match if it % 4 == 3 else fuzz_operators
+            fn = fuzz_match if (it % 4 == 3 or ONLY == "match") else fuzz_operators
             try:
                 tag = fn(rng)
             except Exception:
