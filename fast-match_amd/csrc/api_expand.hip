@@ -450,9 +450,10 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     if ((rc = launch_groups(all_runs)) != FM_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
-    std::vector<long long> res((size_t)n * 4);
+    // per run: n_matches, n_rounds, n_pairs, status | (a parked run) cell, subset size, first train row, train rows
+    std::vector<long long> res((size_t)n * 8);
     for (int i = 0; i < n; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 8], run[(size_t)i]->result, 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // Parked runs (status 8: a round's cross-check is wanted from the dense kernels): per run the subset's rows are in its
     // h_cand[], the round's (subset size, first train row, train rows) in its resume state; K1 + the election fill its
@@ -460,15 +461,12 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     int64_t delegated = 0;
     auto settle_parked = [&](const std::vector<int>& among) -> int {
         std::vector<int> parked;
-        for (int i : among) if (res[(size_t)i * 4 + 3] == 8) parked.push_back(i);
+        for (int i : among) if (res[(size_t)i * 8 + 3] == 8) parked.push_back(i);
         while (!parked.empty()) {
-            std::vector<long long> st(parked.size() * 3);
-            for (size_t k = 0; k < parked.size(); ++k)
-                HIP_TRY(ctx, hipMemcpyAsync(&st[k * 3], run[(size_t)parked[k]]->resume_state + 10, 24, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             for (size_t k = 0; k < parked.size(); ++k) {
                 const int i = parked[k];
-                int rc2 = round_xcheck_dense(ctx, *pairs[i]->query, host[i].h_cand, st[k * 3], *pairs[i]->target, st[k * 3 + 1], st[k * 3 + 2], host[i].h_qbest);
+                const long long* pk = &res[(size_t)i * 8 + 5];          // subset size, first train row, train rows (beside the results)
+                int rc2 = round_xcheck_dense(ctx, *pairs[i]->query, host[i].h_cand, pk[0], *pairs[i]->target, pk[1], pk[2], host[i].h_qbest);
                 if (rc2 != FM_OK) return rc2;
                 host[i].resume = 2;
                 ++delegated;
@@ -478,11 +476,11 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
             for (int i : parked) {
                 host[i].resume = 0;
-                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 8], run[(size_t)i]->result, 64, hipMemcpyDeviceToHost, ctx->stream));
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             std::vector<int> again;
-            for (int i : parked) if (res[(size_t)i * 4 + 3] == 8) again.push_back(i);
+            for (int i : parked) if (res[(size_t)i * 8 + 3] == 8) again.push_back(i);
             parked.swap(again);
         }
         return FM_OK;
@@ -497,7 +495,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     for (int pass = 0; pass <= ctx->tune.expand_grow + 2; ++pass) {
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) {
-            const long long st = res[(size_t)i * 4 + 3];
+            const long long st = res[(size_t)i * 8 + 3];
             ExpandRun* r = run[(size_t)i];
             if (st == 2 && !host[i].f32 && ctx->tune.expand_big && big[(size_t)i] == 0) { big[(size_t)i] = 1; redo.push_back(i); continue; }
             if (st == 2 && huge_ok(i) && big[(size_t)i] <= 1) {
@@ -530,14 +528,15 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         if ((rc = launch_groups(redo)) != FM_OK) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         for (int i : redo)
-            HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 4], run[(size_t)i]->result, 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 8], run[(size_t)i]->result, 64, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // (ws_in is reused by the next pass)
         if ((rc = settle_parked(redo)) != FM_OK) return rc;
     }
     for (int i = 0; i < n; ++i) {
-        ctx->pending_pairs += res[(size_t)i * 4 + 2];
-        if (res[(size_t)i * 4 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
+        ctx->pending_pairs += res[(size_t)i * 8 + 2];
+        if (res[(size_t)i * 8 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
     }
+    if (delegated > 0 && getenv("FM_EXPAND_DEBUG")) fprintf(stderr, "[fm_expand_run] %lld cross-checks delegated to the dense kernels\n", (long long)delegated);
     if (ctx->tune.expand_prof) {
         long long pr[16];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
@@ -550,10 +549,10 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     rc = cs.finish();
     if (rc != FM_OK) return rc;
     for (int i = 0; i < n; ++i) {
-        if (n_matches) n_matches[i] = res[(size_t)i * 4 + 0];
-        if (n_rounds) n_rounds[i] = res[(size_t)i * 4 + 1];
-        if (n_pairs) n_pairs[i] = res[(size_t)i * 4 + 2];
-        if (status) status[i] = (int32_t)res[(size_t)i * 4 + 3];
+        if (n_matches) n_matches[i] = res[(size_t)i * 8 + 0];
+        if (n_rounds) n_rounds[i] = res[(size_t)i * 8 + 1];
+        if (n_pairs) n_pairs[i] = res[(size_t)i * 8 + 2];
+        if (status) status[i] = (int32_t)res[(size_t)i * 8 + 3];
     }
     return FM_OK;
 }

@@ -1085,7 +1085,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[2] = n_pairs;
         P.result[3] = status;
         if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
-        if constexpr (LAZY || HUGE) P.result[4] = need_cell;
+        if constexpr (LAZY || HUGE) {
+            P.result[4] = need_cell;
+            if (status == kExpNeedXcheck) { P.result[5] = P.resume_state[10]; P.result[6] = P.resume_state[11]; P.result[7] = P.resume_state[12]; }
+        }
     }
 }
 
