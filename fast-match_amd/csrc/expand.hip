@@ -672,6 +672,22 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
+        if constexpr (HUGE && !F32 && !LAZY) {
+            // a round whose subset fits LDS but whose CELL is large (thousands of train rows: a blob of keypoints) is
+            // delegated like a chunked one: the sorted subset goes to h_cand[], the run parks (see the chunked branch)
+            if (P.delegate_min > 0 && !P.tie_guard && (long long)nq * nt >= 2 * P.delegate_min) {
+                for (int i = tid; i < nq; i += kExpThreads) P.h_cand[i] = cand[i];
+                if (tid == 0) {
+                    P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
+                    P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
+                    for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
+                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt;
+                }
+                need_cell = cell;
+                status = kExpNeedXcheck;
+                break;
+            }
+        }
         for (int i = tid; i < nq; i += kExpThreads) keys[i] = ~0ull;     // keys[] becomes the qbest table
         if constexpr (F32) {
             // descriptors that are not integer valued: fp16 MFMA filter + exact float32 chain (round_body_f32.h)
@@ -815,7 +831,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         }
         unsigned long long* rk = (unsigned long long*)smem;        // result keys (the stage buffer is free now)
         int n_emit = 0, na = 0;
-        if (nq <= kExpThreads) {
+        if (nq <= kExpThreads && !huge_round) {
             // The usual size -- one thread per slot, nothing is compacted: slot order IS the order of the accepted list.
             const int i = tid;
             bool acc = false, known = false;
