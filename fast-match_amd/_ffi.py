@@ -37,7 +37,7 @@ class fm_stats_ex(ctypes.Structure):
                 ("bytes_moved", ctypes.c_int64)]
 
 
-FM_ABI_VERSION = 5          # include/fastmatch_hip.h: the revision this binding was written against
+FM_ABI_VERSION = 6          # include/fastmatch_hip.h: the revision this binding was written against
 
 
 class fm_expand_desc(ctypes.Structure):
@@ -62,6 +62,7 @@ EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "a radius subset the devic
 _P = ctypes.c_void_p
 _I64 = ctypes.c_int64
 _INT = ctypes.c_int
+_I32 = ctypes.c_int32
 SYMBOLS = {
     "fm_ctx_create": (_INT, [_INT, ctypes.POINTER(_P)]),
     "fm_ctx_destroy": (_INT, [_P]),
@@ -85,6 +86,9 @@ SYMBOLS = {
     "fm_bank_set_selfdist": (_INT, [_P, _P, _P]),
     "fm_bank_refill_u8_async": (_INT, [_P, _P, _P, _I64]),
     "fm_bank_create_u8_cap": (_INT, [_P, _P, _I64, _INT, _I64, ctypes.POINTER(_P)]),
+    "fm_grid_pack_cells": (_INT, [_P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _P, ctypes.POINTER(_I64), _P, _P]),
+    "fm_bank_create_u8_gather": (_INT, [_P, _P, _I64, _INT, _P, _I64, ctypes.POINTER(_P)]),
+    "fm_bank_create_f32_gather": (_INT, [_P, _P, _I64, _INT, _INT, _P, _I64, ctypes.POINTER(_P)]),
     "fm_bank_append_u8": (_INT, [_P, _P, _P, _I64, ctypes.POINTER(_I64)]),
     "fm_expand_set_cell": (_INT, [_P, _P, ctypes.c_int32, _I64, _I64, _P]),
     "fm_expand_run_lazy": (_INT, [_P, _P, _P, _I64, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
@@ -174,6 +178,28 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+def grid_pack_cells(positions, width, height, cell_w, cell_h, rows, cols, margin):
+    """fm_grid_pack_cells (host code of the library): (src_row int32[nt], target_pos f64[nt, 2], cell_off int64[rows * cols + 1])
+    for a Grid_Cache over pre-extracted keypoints -- every cell's keypoints, cell after cell (cell id = col * rows + row)."""
+    lib = load_library()
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
+    n = pos.shape[0]
+    cell_off = np.zeros(int(rows) * int(cols) + 1, dtype=np.int64)
+    cap = 5 * n + 16
+    while True:
+        src_row, t_pos, nt = np.empty(cap, dtype=np.int32), np.empty((cap, 2), dtype=np.float64), _I64()
+        rc = lib.fm_grid_pack_cells(_ptr(pos), n, int(width), int(height), int(cell_w), int(cell_h), int(rows), int(cols), int(margin),
+                                    cap, _ptr(cell_off), ctypes.byref(nt), _ptr(src_row), _ptr(t_pos))
+        if rc != 0:
+            msg = lib.fm_last_error(None)
+            e = FastMatchHipError("fm_grid_pack_cells: %s" % (msg.decode() if msg else rc))
+            e.code = rc
+            raise e
+        if nt.value <= cap:
+            return src_row[:nt.value], t_pos[:nt.value], cell_off
+        cap = nt.value
 
 
 def _stream_arg(stream):
@@ -412,6 +438,26 @@ class Context(object):
         else:
             a = np.ascontiguousarray(a, dtype=np.float32)
             self._check(self.lib.fm_bank_create_f32(self.handle, _ptr(a), a.shape[0], a.shape[1], ctypes.byref(h)))
+        n, dim, kind = _I64(), _INT(), _INT()
+        self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
+        return Bank(self, h, n.value, dim.value, kind.value)
+
+    def bank_gather(self, rows, src_row, float_route=False):
+        """The bank ``rows[src_row]`` without building that matrix on the host: the n_src rows are uploaded once and
+        gathered by the upload kernel (fm_bank_create_*_gather).  dtype handling as ``bank``."""
+        a = np.asarray(rows)
+        if a.ndim != 2:
+            raise ValueError("descriptor bank must be 2-D [n, dim]")
+        m = np.ascontiguousarray(src_row, dtype=np.int32).reshape(-1)
+        h = _P()
+        if float_route or a.dtype != np.uint8:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            self._check(self.lib.fm_bank_create_f32_gather(self.handle, _ptr(a), a.shape[0], a.shape[1], 1 if float_route else 0,
+                                                           _ptr(m), m.shape[0], ctypes.byref(h)))
+        else:
+            a = np.ascontiguousarray(a)
+            self._check(self.lib.fm_bank_create_u8_gather(self.handle, _ptr(a), a.shape[0], a.shape[1], _ptr(m), m.shape[0],
+                                                          ctypes.byref(h)))
         n, dim, kind = _I64(), _INT(), _INT()
         self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
         return Bank(self, h, n.value, dim.value, kind.value)

@@ -198,49 +198,21 @@ class Feature_Image(object):
         (x_min, x_max), (y_min, y_max) = bounds
         return self.features_in(x_min, x_max, y_min, y_max)
 
-    def pack_all(self, grid):
-        """All cells of ``grid`` at once, vectorised: the same (descriptors, positions,
-        cell_off) Grid_Cache.pack_cells builds by visiting every cell."""
-        def axis_members(v, cell, margin, n_cells, limit):
-            # (point, cell index) pairs with lo(i) <= v < hi(i), the crop bounds of cache.pyx:128-131
-            span = int(np.ceil(2.0 * margin / cell)) + 2
-            base = np.floor(v / cell).astype(np.int64)
-            pts, idx = [], []
-            for d in range(-span, span + 1):
-                i = base + d
-                ok = (i >= 0) & (i < n_cells)
-                ii = i[ok]
-                lo = ii * cell - margin * (ii > 0)
-                hi = np.where(ii + 1 < n_cells, lo + cell + 2 * margin, limit)
-                vv = v[ok]
-                keep = (vv >= lo) & (vv < hi)
-                pts.append(np.nonzero(ok)[0][keep])
-                idx.append(ii[keep])
-            return np.concatenate(pts), np.concatenate(idx)
+    def pack_plan(self, grid):
+        """All cells of ``grid`` at once: (src_row int32[nt], positions f64[nt, 2], cell_off int64[cols * rows + 1]) --
+        packed row i is keypoint src_row[i], cells one after the other (cell id = col * rows + row), a cell's keypoints in
+        ascending index, positions in full-image coordinates with offset() applied as match_position does
+        (fastmatch.pyx:157-158).  One pass in the library's host code (fm_grid_pack_cells; r04: the NumPy form of this
+        took 6 ms per 12.5k keypoints, 200 ms at 300k -- more than the device loop it prepares)."""
+        from . import _ffi
+        return _ffi.grid_pack_cells(self.positions, grid.width, grid.height, grid.cell_width, grid.cell_height,
+                                    grid.rows, grid.cols, grid.margin)
 
-        n = self.positions.shape[0]
-        px, rx = axis_members(self.positions[:, 0], grid.cell_width, grid.margin, grid.rows, grid.width)
-        py, cy = axis_members(self.positions[:, 1], grid.cell_height, grid.margin, grid.cols, grid.height)
-        # join the two axes per point: every (row, col) combination of a point's memberships
-        ox, oy = np.argsort(px, kind="stable"), np.argsort(py, kind="stable")
-        px, rx, py, cy = px[ox], rx[ox], py[oy], cy[oy]
-        cx, cyc = np.bincount(px, minlength=n), np.bincount(py, minlength=n)
-        sx, sy = np.concatenate([[0], np.cumsum(cx)]), np.concatenate([[0], np.cumsum(cyc)])
-        reps = cx * cyc
-        pt = np.repeat(np.arange(n), reps)
-        within = np.arange(reps.sum()) - np.repeat(np.concatenate([[0], np.cumsum(reps)[:-1]]), reps)
-        ix = sx[pt] + within // np.maximum(cyc[pt], 1)
-        iy = sy[pt] + within % np.maximum(cyc[pt], 1)
-        row, col = rx[ix], cy[iy]
-        cell = col * grid.rows + row
-        order = np.lexsort((pt, cell))                       # cell after cell, ascending keypoint index
-        pt, row, col, cell = pt[order], row[order], col[order], cell[order]
-        cell_off = np.concatenate([[0], np.cumsum(np.bincount(cell, minlength=grid.rows * grid.cols))]).astype(np.int64)
-        x_min = row * grid.cell_width - grid.margin * (row > 0)
-        y_min = col * grid.cell_height - grid.margin * (col > 0)
-        local = self.positions[pt] - np.stack([x_min, y_min], axis=1).astype(np.float64)
-        off = np.stack([row * grid.cell_width - grid.margin, col * grid.cell_height - grid.margin], axis=1)
-        return self.descriptors[pt], local + off.astype(np.float64), cell_off
+    def pack_all(self, grid):
+        """The same (descriptors, positions, cell_off) Grid_Cache.pack_cells builds by visiting every cell (the device
+        path uploads ``descriptors`` once and gathers on the device instead: fastmatch.make_expander)."""
+        src_row, t_pos, cell_off = self.pack_plan(grid)
+        return self.descriptors[src_row], t_pos, cell_off
 
 
 def keypoint_positions(keypoints):

@@ -39,8 +39,11 @@ template <bool SRC_F32>
 __global__ __launch_bounds__(256)
 void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
                       int8_t* __restrict__ rows8, int32_t* __restrict__ norm,
-                      int32_t* __restrict__ aux, int* __restrict__ nonint, int64_t ntiles)
+                      int32_t* __restrict__ aux, int* __restrict__ nonint, int64_t ntiles,
+                      const int32_t* __restrict__ map = nullptr)
 {
+    // map (fm_bank_create_*_gather): bank row i is source row map[i] -- a Grid_Cache over pre-extracted features packs
+    // a keypoint into up to four cells; its descriptor crosses PCIe once and is copied here
     const int tid = threadIdx.x;
     const int r = tid >> 3, c = tid & 7;
     // A workgroup walks tiles blockIdx.x, + gridDim.x, ...: a refill (fm_bank_refill_u8_async) runs beside the distance
@@ -52,13 +55,14 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
     int sumsq = 0, usq = 0;
     bool bad = false;
     if (row < n) {
+        const int64_t srow = map ? (int64_t)map[row] : row;
         // the thread's 16 values; full-width rows (dim = 128: SIFT) come in as 16-byte loads -- byte / float loads
         // one at a time ran the upload kernel at ~80 GB/s
         int uv[16];
         bool have[16];
         if (dim == kDim) {
             if constexpr (SRC_F32) {
-                const float4* sp = (const float4*)((const float*)src + row * kDim + 16 * c);
+                const float4* sp = (const float4*)((const float*)src + srow * kDim + 16 * c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = sp[q];
@@ -73,7 +77,7 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
                     }
                 }
             } else {
-                const uint4 v = *(const uint4*)((const uint8_t*)src + row * kDim + 16 * c);
+                const uint4 v = *(const uint4*)((const uint8_t*)src + srow * kDim + 16 * c);
                 const unsigned ww[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -88,12 +92,12 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
                 have[e] = k < dim;
                 if (k < dim) {
                     if constexpr (SRC_F32) {
-                        const float f = ((const float*)src)[row * dim + k];
+                        const float f = ((const float*)src)[srow * dim + k];
                         const float fr = rintf(f);
                         if (!(f == fr) || f < 0.f || f > 255.f) bad = true;
                         else uv[e] = (int)fr;
                     } else {
-                        uv[e] = ((const uint8_t*)src)[row * dim + k];
+                        uv[e] = ((const uint8_t*)src)[srow * dim + k];
                     }
                 }
             }
@@ -149,13 +153,13 @@ void bank_prep_kernel(const void* __restrict__ src, int64_t n, int dim,
 
 // float32 bank for the general (non-integer) route: zero-padded copy [n_pad][128].
 __global__ void bank_copy_f32_kernel(const float* __restrict__ src, int64_t n, int dim,
-                                     float* __restrict__ dst, int64_t n_pad)
+                                     float* __restrict__ dst, int64_t n_pad, const int32_t* __restrict__ map)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad * kDim) return;
     const int64_t row = i / kDim;
     const int k = (int)(i % kDim);
-    dst[i] = (row < n && k < dim) ? src[row * dim + k] : 0.f;
+    dst[i] = (row < n && k < dim) ? src[(map ? (int64_t)map[row] : row) * dim + k] : 0.f;
 }
 
 // fp16 rows, norms and accumulator inits of a float32 bank for the fp16 filter (filter_f16.hip).
@@ -627,13 +631,19 @@ static void bank_free(Bank* b)
     b->rowsh = nullptr; b->normf = nullptr; b->auxf = nullptr;
 }
 
+// map != nullptr: the bank's row i is rows[map[i]] of the n_src source rows (0 <= map[i] < n_src, checked here).
 static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f32, fm_bank** out, bool keep_f32 = false,
-                       int64_t capacity = 0)
+                       int64_t capacity = 0, const int32_t* map = nullptr, int64_t n_src = 0)
 {
     if (!ctx) return fail(nullptr, FM_EINVAL, "fm_bank_create: ctx is NULL");
     if (!out) return fail(ctx, FM_EINVAL, "fm_bank_create: bank out pointer is NULL");
     *out = nullptr;
     if (n < 0 || dim < 1 || (n > 0 && !rows)) return fail(ctx, FM_EINVAL, "fm_bank_create: bad rows/n/dim");
+    if (map) {
+        if (n_src < 0 || n_src > INT32_MAX) return fail(ctx, FM_EINVAL, "fm_bank_create_*_gather: bad n_src");
+        for (int64_t i = 0; i < n; ++i)
+            if (map[i] < 0 || map[i] >= n_src) return fail(ctx, FM_EINVAL, "fm_bank_create_*_gather: src_row entry outside [0, n_src)");
+    }
     if (dim > kDim) return fail(ctx, FM_EUNSUPPORTED, "fm_bank_create: dim > 128 is not supported");
     if (n > (int64_t)INT32_MAX - 2 * kStageRows) return fail(ctx, FM_EUNSUPPORTED, "fm_bank_create: n too large");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -651,13 +661,14 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     }
     b->kind = FM_BANK_I8;
     const size_t elt = f32 ? 4 : 1;
-    const size_t src_bytes = (size_t)n * dim * elt;
+    const size_t src_bytes = (size_t)(map ? n_src : n) * dim * elt;
     int rc = FM_OK;
     auto bail = [&](int code) { bank_free(b); delete b; return code; };
 
     const size_t flag_off = (src_bytes + 15) & ~(size_t)15;
-    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 32)) != FM_OK) return bail(rc);
+    if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 32 + (map ? (size_t)n * 4 : 0))) != FM_OK) return bail(rc);
     int* d_flag = (int*)((char*)ctx->ws_in + flag_off);
+    const int32_t* d_map = map ? (const int32_t*)((char*)ctx->ws_in + flag_off + 32) : nullptr;
 #define BTRY(expr)                                                                               \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \
@@ -671,14 +682,15 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
     BTRY(hipMalloc((void**)&b->norm, (size_t)b->cap_pad * 4));
     BTRY(hipMalloc((void**)&b->aux, (size_t)(b->cap_pad / kTileRows) * kAuxPerTile * 4));
     if (src_bytes) BTRY(hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (map && n > 0) BTRY(hipMemcpyAsync((void*)d_map, map, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     BTRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
     const int ntiles = (int)(b->cap_pad / kTileRows);
     if (f32)
         hipLaunchKernelGGL(bank_prep_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream,
-                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles);
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles, d_map);
     else
         hipLaunchKernelGGL(bank_prep_kernel<false>, dim3(ntiles), dim3(256), 0, ctx->stream,
-                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles);
+                           (const void*)ctx->ws_in, n, dim, b->rows8, b->norm, b->aux, d_flag, (int64_t)ntiles, d_map);
     BTRY(hipGetLastError());
     int flags[2] = {0, 0};
     BTRY(hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -693,7 +705,7 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
         BTRY(hipMalloc((void**)&b->rowsf, (size_t)b->n_pad * kDim * 4));
         const int64_t tot = b->n_pad * kDim;
         hipLaunchKernelGGL(bank_copy_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float*)ctx->ws_in, n, dim, b->rowsf, b->n_pad);
+                           (const float*)ctx->ws_in, n, dim, b->rowsf, b->n_pad, d_map);
         BTRY(hipGetLastError());
         // rows for the fp16 filter, scaled by the power of two that puts the largest magnitude
         // of the bank in [2^13, 2^14)
@@ -730,6 +742,23 @@ static int bank_create(fm_ctx* ctx, const void* rows, int64_t n, int dim, bool f
 extern "C" int fm_bank_create_u8(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, fm_bank** bank)
 {
     return bank_create(ctx, rows, n, dim, false, bank);
+}
+
+// Banks whose rows are a gather of the caller's rows (a keypoint in several Grid_Cache cells: uploaded once).
+extern "C" int fm_bank_create_u8_gather(fm_ctx* ctx, const uint8_t* rows, int64_t n_src, int dim, const int32_t* src_row, int64_t n,
+                                        fm_bank** bank)
+{
+    if (n > 0 && !src_row) return fail(ctx, FM_EINVAL, "fm_bank_create_u8_gather: src_row is NULL");
+    if (!src_row) return bank_create(ctx, rows, 0, dim, false, bank);
+    return bank_create(ctx, rows, n, dim, false, bank, false, 0, src_row, n_src);
+}
+
+extern "C" int fm_bank_create_f32_gather(fm_ctx* ctx, const float* rows, int64_t n_src, int dim, int float_route, const int32_t* src_row,
+                                         int64_t n, fm_bank** bank)
+{
+    if (n > 0 && !src_row) return fail(ctx, FM_EINVAL, "fm_bank_create_f32_gather: src_row is NULL");
+    if (!src_row) return bank_create(ctx, rows, 0, dim, true, bank, float_route != 0);
+    return bank_create(ctx, rows, n, dim, true, bank, float_route != 0, 0, src_row, n_src);
 }
 
 extern "C" int fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank)

@@ -176,8 +176,13 @@ def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_
     the float32 round -- both banks then take the float32 route."""
     from . import _ffi
     q_bank = query_cache.bank(context)
-    descs, t_pos, cell_off = target_grid.pack_cells()
-    t_bank = context.bank(descs, float_route=(q_bank.kind == _ffi.FM_BANK_F32))
+    if hasattr(target_grid.fun, "pack_plan") and target_grid.fun is target_grid.data:
+        # pre-extracted target: each descriptor crosses PCIe once, the cells' copies are made by the upload kernel
+        src_row, t_pos, cell_off = target_grid.fun.pack_plan(target_grid)
+        t_bank = context.bank_gather(target_grid.fun.descriptors, src_row, float_route=(q_bank.kind == _ffi.FM_BANK_F32))
+    else:
+        descs, t_pos, cell_off = target_grid.pack_cells()
+        t_bank = context.bank(descs, float_route=(q_bank.kind == _ffi.FM_BANK_F32))
     if t_bank.kind != q_bank.kind:                 # integer-valued query bank, target not: pair on the float route
         q_bank = context.bank(query_cache.original["descriptors"], float_route=True)
         q_bank.set_selfdist(query_cache.original["distances"])

@@ -43,7 +43,7 @@ typedef struct fm_bank fm_bank;
  * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only; revision 5, r04:
  * fm_expand_desc gained the trailing `lazy`).  A binding
  * compares fm_abi_version() with the FM_ABI_VERSION it was written against before its first call.            */
-#define FM_ABI_VERSION 5
+#define FM_ABI_VERSION 6
 int  fm_abi_version(void);
 
 typedef struct fm_stats {
@@ -405,6 +405,27 @@ int  fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t 
 int  fm_expand_set_cell(fm_ctx* ctx, fm_expand* ex, int32_t cell, int64_t first_row, int64_t n_rows, const double* pos /*[n_rows][2]*/);
 int  fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seeds, int64_t n_seeds, double tau, int32_t resume,
                         int64_t* n_matches, int64_t* n_rounds, int64_t* n_pairs, int32_t* status, int32_t* need_cell);
+
+/* ---- pre-extracted targets: all cells of a Grid_Cache at once (r04) -------------------------------------------------
+ * The device loop's target bank holds "every cell's descriptors, cell after cell" (fm_expand_desc.target / cell_off /
+ * target_pos).  For a target given as pre-extracted features (keypoint positions + descriptors instead of pixels) a
+ * cell's features are the keypoints inside the crop Grid_Cache hands its caching function (cache.pyx:128-131: x from
+ * row * cell_w - margin, clipped at 0, over cell_w + 2 * margin; same along y) -- a keypoint lands in up to four cells.
+ *   fm_grid_pack_cells       : HOST code, no context: cell_off[rows * cols + 1] (cell id = col * rows + row) and *n_rows
+ *                              always; when `capacity` >= *n_rows also src_row[n_rows] (the keypoint of every packed row,
+ *                              ascending inside a cell) and target_pos[n_rows][2] (crop-local position + the offset
+ *                              match_position adds, fastmatch.pyx:157-158).  A caller whose capacity was too small
+ *                              reads *n_rows and calls again.
+ *   fm_bank_create_u8_gather /
+ *   fm_bank_create_f32_gather: a bank whose row i is rows[src_row[i]] -- the n_src descriptors cross PCIe once and are
+ *                              gathered by the upload kernel.  FM_EINVAL for an entry outside [0, n_src).  float_route
+ *                              as fm_bank_create_f32_route (non-zero: keep the float32 route even if integer valued).  */
+int  fm_grid_pack_cells(const double* positions /*[n][2]*/, int64_t n, int32_t width, int32_t height, int32_t cell_w, int32_t cell_h,
+                        int32_t rows, int32_t cols, int32_t margin, int64_t capacity, int64_t* cell_off, int64_t* n_rows,
+                        int32_t* src_row, double* target_pos);
+int  fm_bank_create_u8_gather(fm_ctx* ctx, const uint8_t* rows, int64_t n_src, int dim, const int32_t* src_row, int64_t n, fm_bank** bank);
+int  fm_bank_create_f32_gather(fm_ctx* ctx, const float* rows, int64_t n_src, int dim, int float_route, const int32_t* src_row,
+                               int64_t n, fm_bank** bank);
 
 /* Memory of the run states: fm_expand_info reports the bytes ONE run state of the pair takes (pending stack, seen /
  * found tables, result arrays: ~210 MB for a 300k-keypoint pair) and how many exist; fm_expand_trim frees the states

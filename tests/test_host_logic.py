@@ -136,7 +136,8 @@ def test_synth_is_deterministic_and_sift_like():
 
 
 @pytest.mark.parametrize("size,cell,margin", [((500, 333), (50, 50), 25), ((611, 389), (64, 48), 0),
-                                              ((800, 640), (75, 75), 40), ((123, 77), (50, 50), 25)])
+                                              ((800, 640), (75, 75), 40), ((123, 77), (50, 50), 25),
+                                              ((200, 150), (10, 12), 40), ((90, 90), (100, 100), 30)])
 def test_vectorised_cell_packing_equals_cell_by_cell(size, cell, margin):
     import time
     _, t = synth.image_pair(size, 3000, seed=size[0])
@@ -148,6 +149,34 @@ def test_vectorised_cell_packing_equals_cell_by_cell(size, cell, margin):
     slow = slow_grid.pack_cells()                               # visits every cell (no pack_all on a lambda)
     for a, b in zip(fast, slow):
         assert a.dtype == b.dtype and np.array_equal(a, b)
+    # keypoints ON the crop bounds (multiples of the cell size +- the margin, the image's last pixel): the planner's
+    # half-open intervals are the per-cell path's
+    xs = sorted({v for i in range(0, size[0] // cell[0] + 2) for v in (i * cell[0] - margin, i * cell[0], i * cell[0] + margin)
+                 if 0 <= v < size[0]} | {size[0] - 1})
+    ys = sorted({v for i in range(0, size[1] // cell[1] + 2) for v in (i * cell[1] - margin, i * cell[1], i * cell[1] + margin)
+                 if 0 <= v < size[1]} | {size[1] - 1})
+    pos = np.array([[x, y] for x in xs for y in ys], dtype=np.float64)
+    desc = (np.arange(len(pos))[:, None] % 251 + np.arange(128)[None, :] % 5).astype(np.uint8)
+    fi2 = cache.Feature_Image(size, pos, desc)
+    fast2 = cache.Grid_Cache(fi2, cell, fi2, margin=margin).pack_cells()
+    g2 = cache.Grid_Cache(fi2, cell, lambda _c, bounds: fi2(None, bounds), margin=margin)
+    g2.fun.wants_bounds = True
+    for a, b in zip(fast2, g2.pack_cells()):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    src_row, t_pos, cell_off = fi2.pack_plan(g2)
+    assert src_row.dtype == np.int32 and np.array_equal(desc[src_row], fast2[0]) and cell_off[-1] == len(src_row)
+
+
+def test_cell_packing_rejects_bad_geometry_and_ignores_stray_keypoints():
+    from fastmatch_amd import _ffi
+    pos = np.array([[10.0, 10.0], [-3.0, 5.0], [5.0, 1e12], [np.nan, 4.0], [99.999, 49.0]])
+    src_row, t_pos, cell_off = _ffi.grid_pack_cells(pos, 100, 50, 50, 50, 3, 2, 25)
+    assert sorted(set(src_row.tolist())) == [0, 4]              # outside / NaN keypoints are in no cell
+    assert cell_off.shape == (7,) and cell_off[-1] == len(src_row) == len(t_pos)
+    with pytest.raises(_ffi.FastMatchHipError):
+        _ffi.grid_pack_cells(pos, 100, 50, 0, 50, 3, 2, 25)
+    with pytest.raises(_ffi.FastMatchHipError):
+        _ffi.grid_pack_cells(pos, 100, 50, 2, 2, 51, 26, 400)
 
 
 def test_homography_and_planted_scorers(tmp_path):
