@@ -55,7 +55,11 @@ def fuzz_operators(rng):
                  ("coop", int(rng.integers(0, 2))), ("f32_filter", int(rng.choice([0, 0, 1, 2]))),
                  ("k1_order", int(rng.choice([0, 0, 1, 2]))), ("bound_every", int(rng.choice([1, 2, 16, 16, 64, 1024])))):
         ctx.set_option(k, v)
-    qb, tb = ctx.bank(Q), ctx.bank(T)
+    if rng.integers(0, 4) == 0 and kind != "far":         # the train bank as a device-side gather of uploaded rows
+        m = rng.integers(0, len(T), size=size(rng, 40000)).astype(np.int32)
+        qb, tb, T = ctx.bank(Q), ctx.bank_gather(T, m), T[m]
+    else:
+        qb, tb = ctx.bank(Q), ctx.bank(T)
     order = 1 if kind == "nonint" else 0                 # the device's fixed float32 accumulation order
     what = rng.choice(["knn2", "xcheck", "accepted", "selfdist", "batch"])
     tag = (what, kind, Q.shape[0], T.shape[0], str(Q.dtype))
