@@ -178,12 +178,14 @@ class Feature_Image(object):
                 "descriptors": np.ascontiguousarray(td if td.dtype == np.uint8 else td.astype(np.float32)),
                 "size": (int(thumb_size[0]), int(thumb_size[1])),
             }
-        self._index = Position_Index(self.positions)
+        self._index = None                 # built at the first per-cell query (the device path plans all cells at once)
 
     def features_in(self, x_min, x_max, y_min, y_max):
         """Keypoints with x_min <= x < x_max and y_min <= y < y_max, crop-local coords."""
         cx, cy = 0.5 * (x_min + x_max), 0.5 * (y_min + y_max)
         rad = 0.5 * float(np.hypot(x_max - x_min, y_max - y_min)) + 1.0
+        if self._index is None:
+            self._index = Position_Index(self.positions)
         idx, _ = self._index.radius(cx, cy, rad)
         if idx.shape[0]:
             p = self.positions[idx]
