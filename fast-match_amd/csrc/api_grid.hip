@@ -5,6 +5,7 @@
 #include "ctx_internal.h"
 
 #include <cmath>
+#include <new>
 #include <vector>
 
 using namespace fm;
@@ -54,6 +55,7 @@ extern "C" int fm_grid_pack_cells(const double* positions, int64_t n, int32_t wi
     if (2.0 * margin / cell_w + 4 > kMaxSpan || 2.0 * margin / cell_h + 4 > kMaxSpan)
         return fail(nullptr, FM_EUNSUPPORTED, "fm_grid_pack_cells: margin more than ~30 cells wide");
     const int64_t ncells = (int64_t)rows * cols;
+  try {
     std::vector<int64_t> cnt((size_t)ncells + 1, 0);
     std::vector<int32_t> member;                  // the cells of keypoint 0, of keypoint 1, ... (pass 2 walks it again)
     std::vector<uint8_t> n_member((size_t)n);
@@ -96,5 +98,8 @@ extern "C" int fm_grid_pack_cells(const double* positions, int64_t n, int32_t wi
             target_pos[2 * at + 1] = ly + (double)((int64_t)col * cell_h - margin);
         }
     }
+  } catch (const std::bad_alloc&) {
+    return fail(nullptr, FM_ENOMEM, "fm_grid_pack_cells: out of host memory");
+  }
     return FM_OK;
 }
