@@ -2,6 +2,8 @@
 // expansion loop (expand.hip) -- pairs, run states, launches, result fetch.
 #include "ctx_internal.h"
 
+#include <chrono>
+
 using namespace fm;
 
 // ---------------------------------------------------------------------------------------
@@ -27,7 +29,7 @@ struct ExpandRun {
     // ends with the matching FM_EXPAND_*_FULL status (fm_expand_run then repeats the run)
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0, found_cap = 0;
     // huge tier: the tables of a round whose radius subset does not fit LDS (created when a run first needs them)
-    void* huge = nullptr;          // h_cand i32[nq] | h_qbest u64[nq] | h_tbest u64[largest cell]
+    void* huge = nullptr;          // h_cand i32[nq] | h_qbest u64[nq] | h_tbest u64[largest cell] | h_ucand i32[nq] | h_pkey u64[nq]
 };
 
 struct fm_expand {
@@ -98,24 +100,28 @@ static int expand_ensure_run(fm_ctx* ctx, fm_expand* ex, size_t slot)
 }
 
 // The global tables of the chunked rounds (expand.hip, HUGE) for one run state.
+// (a lazy target's cells are not known yet: room for the whole target bank's capacity)
+static size_t tm_of(const fm_expand* ex) { return (size_t)(ex->lazy ? ex->t_cap : (ex->tmax > 0 ? ex->tmax : 1)); }
+
 static int expand_run_huge(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
 {
     if (r.huge) return FM_OK;
-    // (a lazy target's cells are not known yet: room for the whole target bank's capacity)
-    const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1), tm = (size_t)(ex->lazy ? ex->t_cap : (ex->tmax > 0 ? ex->tmax : 1));
-    hipError_t e = hipMalloc(&r.huge, al256(nq * 4) + al256(nq * 8) + al256(tm * 8));
+    const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1), tm = tm_of(ex);
+    hipError_t e = hipMalloc(&r.huge, al256(nq * 4) + al256(nq * 8) + al256(tm * 8) + al256(nq * 4) + al256(nq * 8));
     if (e != hipSuccess) { (void)hipGetLastError(); r.huge = nullptr; return fail(ctx, FM_ENOMEM, std::string("fm_expand: chunked-round tables: ") + hipGetErrorString(e)); }
     return FM_OK;
 }
 
 static void expand_bind_run(ExpandPair& P, const ExpandRun& r, const fm_expand* ex = nullptr)
 {
-    P.h_cand = nullptr; P.h_qbest = nullptr; P.h_tbest = nullptr;
+    P.h_cand = nullptr; P.h_qbest = nullptr; P.h_tbest = nullptr; P.h_ucand = nullptr; P.h_pkey = nullptr;
     if (r.huge && ex) {
         const size_t nq = (size_t)(ex->nq > 0 ? ex->nq : 1);
         P.h_cand = (int32_t*)r.huge;
         P.h_qbest = (unsigned long long*)((char*)r.huge + al256(nq * 4));
         P.h_tbest = (unsigned long long*)((char*)r.huge + al256(nq * 4) + al256(nq * 8));
+        P.h_ucand = (int32_t*)((char*)r.huge + al256(nq * 4) + al256(nq * 8) + al256(tm_of(ex) * 8));
+        P.h_pkey = (unsigned long long*)((char*)r.huge + al256(nq * 4) + al256(nq * 8) + al256(tm_of(ex) * 8) + al256(nq * 4));
     }
     P.stack = r.stack; P.stack_cap = r.stack_cap;
     P.seen = r.seen; P.seen_cap = r.seen_cap;
@@ -459,10 +465,14 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // h_cand[], the round's (subset size, first train row, train rows) in its resume state; K1 + the election fill its
     // h_qbest[] on the whole GPU, then the parked runs are launched again with resume = 2 -- until none parks.
     int64_t delegated = 0;
+    const bool dbg = getenv("FM_EXPAND_DEBUG") != nullptr;
+    double t_dense = 0.0, t_launch = 0.0, t_wait = 0.0;      // host seconds: enqueueing the dense kernels / the resumed runs / waiting
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto settle_parked = [&](const std::vector<int>& among) -> int {
         std::vector<int> parked;
         for (int i : among) if (res[(size_t)i * 8 + 3] == 8) parked.push_back(i);
         while (!parked.empty()) {
+            const double t0 = dbg ? now() : 0.0;
             for (size_t k = 0; k < parked.size(); ++k) {
                 const int i = parked[k];
                 const long long* pk = &res[(size_t)i * 8 + 5];          // subset size, first train row, train rows (beside the results)
@@ -471,6 +481,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 host[i].resume = 2;
                 ++delegated;
             }
+            const double t1 = dbg ? now() : 0.0;
             int rc2 = launch_groups(parked);
             if (rc2 != FM_OK) return rc2;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
@@ -478,7 +489,9 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 host[i].resume = 0;
                 HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 8], run[(size_t)i]->result, 64, hipMemcpyDeviceToHost, ctx->stream));
             }
+            const double t2 = dbg ? now() : 0.0;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (dbg) { t_dense += t1 - t0; t_launch += t2 - t1; t_wait += now() - t2; }
             std::vector<int> again;
             for (int i : parked) if (res[(size_t)i * 8 + 3] == 8) again.push_back(i);
             parked.swap(again);
@@ -536,7 +549,17 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         ctx->pending_pairs += res[(size_t)i * 8 + 2];
         if (res[(size_t)i * 8 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
     }
-    if (delegated > 0 && getenv("FM_EXPAND_DEBUG")) fprintf(stderr, "[fm_expand_run] %lld cross-checks delegated to the dense kernels\n", (long long)delegated);
+    if (dbg && getenv("FM_PARK_PROF")) {               // (a library built with -DFM_PARK_PROF: expand.hip)
+        long long pr[16];
+        (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
+        static const char* hn[7] = {"pop + radius walk", "list + histogram + bounds", "partition", "chunk sorts (+ x-check)", "step 4", "step 5", "rounds that fit"};
+        fprintf(stderr, "[fm_expand_run, run 0] %lld rounds beyond the LDS tables; thread 0's clock, ms: ", pr[15]);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.2f  ", hn[k], pr[8 + k] * 1e-5);
+        fprintf(stderr, "\n");
+    }
+    if (delegated > 0 && dbg)
+        fprintf(stderr, "[fm_expand_run] %lld cross-checks delegated to the dense kernels; host seconds: enqueue dense %.4f, enqueue resume %.4f, "
+                        "wait %.4f\n", (long long)delegated, t_dense, t_launch, t_wait);
     if (ctx->tune.expand_prof) {
         long long pr[16];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);

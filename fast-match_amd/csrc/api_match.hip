@@ -433,10 +433,16 @@ static int enqueue_election(fm_ctx* ctx, hipStream_t s, const fm_bank* q, const 
 // bank_prep_kernel writes; slots past nq are padding rows).  One 256-thread block per 32-row tile.
 __global__ __launch_bounds__(256)
 void gather_rows_kernel(const int32_t* __restrict__ rows, int64_t nq, const int8_t* __restrict__ src8, const int32_t* __restrict__ srcnorm,
-                        int8_t* __restrict__ dst8, int32_t* __restrict__ dstnorm, int32_t* __restrict__ dstaux)
+                        int8_t* __restrict__ dst8, int32_t* __restrict__ dstnorm, int32_t* __restrict__ dstaux,
+                        unsigned long long* __restrict__ qbest, int* __restrict__ bound, int64_t nbound)
 {
     const int tid = threadIdx.x, r = tid >> 3, c = tid & 7;
     const int64_t tile = blockIdx.x, slot = tile * kTileRows + r;
+    // (the two fills the round's other kernels want, here instead of two fill launches of their own: the election's table
+    // and K1's shared bounds)
+    if (c == 1 && slot < nq) qbest[slot] = ~0ull;
+    if (bound)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < nbound; i += (int64_t)gridDim.x * 256) bound[i] = (int)0x80000000;
     uint4 w = make_uint4(0, 0, 0, 0);
     int nm = 0;
     if (slot < nq) {
@@ -472,9 +478,6 @@ int fm::round_xcheck_dense(fm_ctx* ctx, const Bank& q, const int32_t* d_rows, in
     Bank gq;
     gq.kind = FM_BANK_I8; gq.n = nq; gq.dim = q.dim; gq.n_pad = nq_pad; gq.cap_pad = nq_pad;
     gq.rows8 = (int8_t*)(b + o_rows); gq.norm = (int32_t*)(b + o_norm); gq.aux = (int32_t*)(b + o_aux);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nq_pad / kTileRows)), dim3(256), 0, ctx->stream, d_rows, nq,
-                       (const int8_t*)q.rows8, (const int32_t*)q.norm, gq.rows8, gq.norm, gq.aux);
-    HIP_TRY(ctx, hipGetLastError());
     // the cell's rows as a bank of their own: a view into the target bank (rows past nt are other cells' rows or padding;
     // what K1 computes for them is never looked at)
     Bank tv;
@@ -488,9 +491,10 @@ int fm::round_xcheck_dense(fm_ctx* ctx, const Bank& q, const int32_t* d_rows, in
     const size_t pbytes = (pl.partial_bytes(1) + 255) & ~(size_t)255;
     if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, pbytes + pl.bound_bytes() + 64)) != FM_OK) return rc;
     int* d_bound = ((ctx->tune.coop != 0) && pl.nsplit > 1) ? (int*)((char*)ctx->ws_partial + pbytes) : nullptr;
-    if (d_bound) HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, (int)0x80000000, (size_t)pl.ncols_alloc, ctx->stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(nq_pad / kTileRows)), dim3(256), 0, ctx->stream, d_rows, nq,
+                       (const int8_t*)q.rows8, (const int32_t*)q.norm, gq.rows8, gq.norm, gq.aux, d_qbest, d_bound, (int64_t)pl.ncols_alloc);
+    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, launch_rowreduce(tv, gq, 1, pl, (unsigned long long*)ctx->ws_partial, d_bound, (ctx->tune.glds != 0), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(d_qbest, 0xff, (size_t)nq * 8, ctx->stream));
     const int64_t sthreads = nt * 4;
     hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, 0u, 0, (int*)nullptr, (unsigned*)nullptr);

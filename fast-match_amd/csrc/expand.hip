@@ -414,7 +414,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<unsigned long long> found; int64_t found_cap;
         gptr<int32_t> m_index; gptr<double> m_pos, m_ratio; int64_t match_cap;
         gptr<long long> result; int prof;
-        gptr<int32_t> h_cand; gptr<unsigned long long> h_qbest, h_tbest;
+        gptr<int32_t> h_cand, h_ucand; gptr<unsigned long long> h_qbest, h_tbest, h_pkey;
         gptr<const int64_t> cell_start; gptr<const int32_t> cell_cnt, cell_ready; gptr<long long> resume_state; int resume;
         long long delegate_min;
     } P;
@@ -432,7 +432,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.found = (gptr<unsigned long long>)M.found; P.found_cap = M.found_cap;
     P.m_index = (gptr<int32_t>)M.m_index; P.m_pos = (gptr<double>)M.m_pos; P.m_ratio = (gptr<double>)M.m_ratio;
     P.match_cap = M.match_cap; P.result = (gptr<long long>)M.result; P.prof = M.prof;
-    P.h_cand = (gptr<int32_t>)M.h_cand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest;
+    P.h_cand = (gptr<int32_t>)M.h_cand; P.h_ucand = (gptr<int32_t>)M.h_ucand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest; P.h_pkey = (gptr<unsigned long long>)M.h_pkey;
     P.cell_start = (gptr<const int64_t>)M.cell_start; P.cell_cnt = (gptr<const int32_t>)M.cell_cnt; P.cell_ready = (gptr<const int32_t>)M.cell_ready;
     P.resume_state = (gptr<long long>)M.resume_state; P.resume = M.resume; P.delegate_min = M.delegate_min;
     const RoundF32G RF(M.rf);
@@ -448,6 +448,18 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     long long& tstamp = pt[12];
     if (tid == 0) { for (int k = 0; k < 12; ++k) pt[k] = 0; tstamp = P.prof ? wall_clock64() : 0; }
 #define EXP_STAMP(k) do { if (P.prof && tid == 0) { const long long _n = wall_clock64(); pt[k] += _n - tstamp; tstamp = _n; } } while (0)
+    // FM_PARK_PROF builds only (make FLAGS_expand=-DFM_PARK_PROF; scripts/README.md): where a round beyond the LDS tables spends
+    // its time -- thread 0's wall clock per phase of such rounds, summed over the launches of a run into result[8 ..]
+    // (0 radius walk, 1 list + histogram + chunk bounds, 2 partition, 3 chunk sorts (+ cross-check when not delegated),
+    // 4 step 4, 5 step 5, 6 everything in rounds that fit, 7 number of such rounds)
+#ifdef FM_PARK_PROF
+    __shared__ long long hp[8];
+    __shared__ long long hstamp;
+    if (tid == 0) { for (int k = 0; k < 8; ++k) hp[k] = 0; hstamp = wall_clock64(); }
+#define HUGE_STAMP(k) do { if (tid == 0) { const long long _n = wall_clock64(); hp[k] += _n - hstamp; hstamp = _n; } } while (0)
+#else
+#define HUGE_STAMP(k) do { } while (0)
+#endif
 
     bool skip_pop = false;        // (uniform) the first round of a resumed run takes the saved entry
     bool skip_x = false;          // (uniform) ... and, resumed behind a DELEGATED cross-check (P.resume == 2), goes straight to steps 4 / 5
@@ -463,6 +475,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 
     for (;;) {
+        HUGE_STAMP(6);
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
         if ((LAZY || HUGE) && skip_pop) {
             skip_pop = false;
@@ -644,6 +657,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                         if (d2 <= lim) {
                             const int slot = atomicAdd(&sh_i[4], 1);
                             if (slot < CAND) { keys[slot] = (unsigned long long)__double_as_longlong(d2); cand[slot] = qi; }
+                            else if constexpr (HUGE) {
+                                // a subset beyond the LDS tables: the rest of the list goes to the run's global tables, so that the
+                                // chunked round below reads the subset back instead of walking the index again per chunk
+                                P.h_qbest[slot] = (unsigned long long)__double_as_longlong(d2);
+                                P.h_ucand[slot] = qi;
+                            }
                         }
                     }
                 }
@@ -657,6 +676,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (HUGE && (F32 || !P.tie_guard)) huge_round = true;
             else { status = kExpCandFull; break; }
         }
+#ifdef FM_PARK_PROF
+        if (huge_round) { HUGE_STAMP(0); if (tid == 0) ++hp[7]; }
+#endif
         EXP_STAMP(1);
         if (!huge_round) {
         // The cell's first 128 descriptor rows (int8 round: the MFMA B operand) go to LDS by DMA from here: the sort
@@ -706,6 +728,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (nt == 0) continue;
             n_pairs += (long long)nq * nt;
             __shared__ int chb[kHugeChunks + 1];            // chunk c = sort buckets [chb[c], chb[c + 1])
+            __shared__ int chrow[kHugeChunks + 1];          // ... = slots [chrow[c], chrow[c + 1]) of the sorted subset
             const double rr = (double)P.radius;
             const double lim_all = P.metric == 0 ? rr * rr : rr;
             const double bscale = lim_all > 0.0 ? (double)kSortBuckets / lim_all : 0.0;
@@ -713,71 +736,123 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int b = (int)(d2 * bscale);
                 return b < kSortBuckets - 1 ? b : kSortBuckets - 1;
             };
-            // every keypoint inside the radius once more (step 2's walk): fn(sort key, keypoint index)
-            auto walk = [&](auto fn) __attribute__((always_inline)) {
-                const double b = P.idx_bucket;
-                int bx0 = (int)floor(((double)qx - rr - P.idx_x0) / b), bx1 = (int)floor(((double)qx + rr - P.idx_x0) / b);
-                int by0 = (int)floor(((double)qy - rr - P.idx_y0) / b), by1 = (int)floor(((double)qy + rr - P.idx_y0) / b);
-                bx0 = max(bx0, 0); by0 = max(by0, 0);
-                bx1 = min(bx1, P.idx_nbx - 1); by1 = min(by1, P.idx_nby - 1);
-                if (!(P.idx_nbx > 0 && bx1 >= bx0)) return;
-                for (int by = by0; by <= by1; ++by) {
-                    const int s0 = P.idx_start[by * P.idx_nbx + bx0], e0 = P.idx_start[by * P.idx_nbx + bx1 + 1];
-                    for (int io = s0 + tid; io < e0; io += kExpThreads) {
-                        const int qi = P.idx_order[io];
-                        const double dx = P.q_pos_ord[2 * io] - (double)qx, dy = P.q_pos_ord[2 * io + 1] - (double)qy;
-                        double d2, lim;
-                        if (P.metric == 0) { d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)); lim = lim_all; }
-                        else if (P.metric == 1) { d2 = __dadd_rn(fabs(dx), fabs(dy)); lim = rr; }
-                        else { d2 = fmax(fabs(dx), fabs(dy)); lim = rr; }
-                        if (d2 <= lim) fn(d2, qi);
+            // The subset as step 2's walk found it, (sort key, keypoint index) in no particular order: slots [0, CAND) are in
+            // the LDS tables, the rest went to global memory -- h_qbest[] holds the keys until the election needs it, h_ucand[]
+            // the indices.  The LDS part joins them, and the list is read back twice with coalesced loads, four entries in
+            // flight per thread: once for the histogram over the sort's buckets, once to PARTITION it by chunk (r04: every
+            // chunk used to walk the position index again -- seven walks for a 10 000-row subset, ~25 us each).
+            // Agent-scope loads: the lines may sit in this CU's vector cache from an earlier round.
+            for (int i = tid; i < CAND; i += kExpThreads) { P.h_qbest[i] = keys[i]; P.h_ucand[i] = cand[i]; }
+            if (tid == 0) sh_i[5] = 0;
+            __syncthreads();
+            auto scan = [&](auto fn) __attribute__((always_inline)) {
+                for (int i0 = tid; i0 < nq; i0 += 4 * kExpThreads) {
+                    unsigned long long kb[4];
+                    int qv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * kExpThreads;
+                        kb[u] = 0; qv[u] = 0;
+                        if (i < nq) {
+                            kb[u] = __hip_atomic_load(P.h_qbest + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            qv[u] = __hip_atomic_load(P.h_ucand + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * kExpThreads < nq) fn(kb[u], qv[u]);
                 }
             };
             // (a) the subset's histogram over the sort's buckets (cleared in front of step 2, untouched since)
-            walk([&](double d2, int) { atomicAdd(&hist[bucket_of(d2)], 1); });
-            for (int i = tid; i < nq; i += kExpThreads) P.h_qbest[i] = ~0ull;
+            scan([&](unsigned long long kb, int) { atomicAdd(&hist[bucket_of(__longlong_as_double((long long)kb))], 1); });
             if (tid < 128) for (int t = tid; t < nt; t += 128) P.h_tbest[t] = ~0ull;      // (row t belongs to thread t % 128 throughout)
             lds_barrier();
-            if (tid == 0) {
-                int c = 0, acc = 0, ok = 1;
-                chb[0] = 0;
-                for (int b = 0; b < kSortBuckets && ok; ++b) {
-                    const int hb = hist[b];
-                    if (hb > CAND) ok = 0;                                   // thousands of keypoints at one distance
-                    else if (acc + hb > CAND) { if (c + 2 > kHugeChunks) ok = 0; else { chb[++c] = b; acc = hb; } }
-                    else acc += hb;
+            // Chunks of <= CAND keypoints, greedy over the buckets (r04: one thread walking the 1024 buckets took 100 us of a
+            // 10 000-row round -- more than everything else in it).  Exclusive prefix of the bucket counts (the sort's scan,
+            // into its cursor words); each boundary is then one binary search: the chunk that starts at bucket s ends in front
+            // of the first bucket whose inclusive prefix exceeds pre[s] + CAND.
+            int* const pre = hist + kSortBuckets + 4;
+            {
+                constexpr int kPer = kSortBuckets / kExpThreads;
+                int cq[kPer], sum = 0;
+                bool big = false;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) { cq[q] = hist[tid * kPer + q]; sum += cq[q]; big |= cq[q] > CAND; }
+                int off;
+                block_exclusive_scan_nosync(sum, &off, hist + 2 * kSortBuckets + 8);
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) { pre[tid * kPer + q] = off; off += cq[q]; }
+                if (big) sh_i[5] = -1;                                       // thousands of keypoints at one distance
+            }
+            lds_barrier();
+            if (tid == 0 && sh_i[5] == 0) {
+                int c = 0, ok = 1, start = 0;
+                chb[0] = 0; chrow[0] = 0;
+                for (;;) {
+                    const int lim = pre[start] + CAND;
+                    int lo = start, hi = kSortBuckets;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const int incl = mid + 1 < kSortBuckets ? pre[mid + 1] : nq;
+                        if (incl > lim) hi = mid; else lo = mid + 1;
+                    }
+                    if (lo >= kSortBuckets) break;                           // the rest fits the chunk
+                    if (c + 2 > kHugeChunks) { ok = 0; break; }
+                    chb[++c] = lo; chrow[c] = pre[lo]; start = lo;
                 }
                 chb[++c] = kSortBuckets;
+                chrow[c] = nq;
                 sh_i[5] = ok ? c : -1;
             }
             lds_barrier();
             const int nch = sh_i[5];
             if (nch < 0) { status = kExpCandFull; break; }
+            // hist[b] becomes the chunk of bucket b; the cursor words, the chunks' entry counters of the partition, are cleared
+            {
+                constexpr int kPer = kSortBuckets / kExpThreads;
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) {
+                    const int bq = tid * kPer + q;
+                    int lo = 0, hi = nch - 1;                                // largest c with chb[c] <= bq
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chb[mid] <= bq) lo = mid; else hi = mid - 1; }
+                    hist[bq] = lo;
+                }
+                for (int i = tid; i < nch; i += kExpThreads) pre[i] = 0;
+            }
+            lds_barrier();
+            HUGE_STAMP(1);
+            // (b) the partition: every entry to its chunk's slot range of h_pkey[] / h_cand[] (the chunk's sorted rows land in
+            // the same range of h_cand[]); the sort's cursor words, zero since block_sort_clear, count the chunks' entries
+            {
+                int* const chcnt = hist + kSortBuckets + 4;
+                scan([&](unsigned long long kb, int qi) {
+                    const int c = hist[bucket_of(__longlong_as_double((long long)kb))];
+                    const int at = chrow[c] + atomicAdd(&chcnt[c], 1);
+                    P.h_pkey[at] = kb;
+                    P.h_cand[at] = qi;
+                });
+            }
+            __syncthreads();
+            HUGE_STAMP(2);
             // DELEGATED cross-check (r04): a round of this size is minutes of one CU's matrix cores at a fraction of their
             // rate, and microseconds of the whole chip's.  The round sorts its subset into h_cand[] as always, then PARKS
             // the run (the state a lazy run saves, + the subset's size); fm_expand_run gathers the subset's rows, runs the
             // dense reverse-NN kernel (K1) and the election on the whole GPU into h_qbest[] and resumes the run at steps 4 / 5.
             const bool deleg = !F32 && !LAZY && P.delegate_min > 0 && (long long)nq * nt >= P.delegate_min;
-            unsigned base = 0;
             for (int c = 0; c < nch; ++c) {
                 const int b0 = chb[c], b1 = chb[c + 1];
-                if (tid == 0) sh_i[4] = 0;
+                const unsigned base = (unsigned)chrow[c];
+                const int nc = chrow[c + 1] - chrow[c];
+                lds_barrier();                          // (everyone has read chrow / chb; the last chunk's tables are done with)
                 block_sort_clear(hist);
+                for (int i = tid; i < nc; i += kExpThreads) {
+                    keys[i] = __hip_atomic_load(P.h_pkey + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cand[i] = __hip_atomic_load(P.h_cand + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 lds_barrier();
-                walk([&](double d2, int qi) {
-                    const int b = bucket_of(d2);
-                    if (b >= b0 && b < b1) {
-                        const int slot = atomicAdd(&sh_i[4], 1);
-                        keys[slot] = (unsigned long long)__double_as_longlong(d2);
-                        cand[slot] = qi;
-                    }
-                });
-                lds_barrier();
-                const int nc = sh_i[4];
                 block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, (double)b1 / bscale, (double)b0 / bscale);
                 for (int i = tid; i < nc; i += kExpThreads) P.h_cand[base + i] = cand[i];
-                if (deleg) { base += (unsigned)nc; continue; }
+                if (deleg) continue;
                 if constexpr (F32) {
                     // (the candidate list aliases the sort scratch, free until the next chunk's sort)
                     lds_barrier();
@@ -790,8 +865,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                                             (unsigned long long*)nullptr, (unsigned long long*)(hist + 2 * kSortBuckets + 16), 0,
                                             nullptr, nullptr, nullptr, P.h_tbest, base);
                 }
-                base += (unsigned)nc;
             }
+            HUGE_STAMP(3);
             if (status != kExpOk) break;      // (a float32 chunk whose candidate list overflowed)
             if (deleg) {
                 if (tid == 0) {
@@ -805,6 +880,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 break;
             }
             // (b) election: train row t elects the slot its minimum names; the slot keeps its closest train row
+            for (int i = tid; i < nq; i += kExpThreads) P.h_qbest[i] = ~0ull;      // (the unsorted keys are done with)
             __syncthreads();                  // the fill of h_qbest and the copies of h_cand have reached memory
             if (tid < 128)
                 for (int t = tid; t < nt; t += 128) {
@@ -954,6 +1030,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (status != kExpOk) break;
             lds_barrier();
             EXP_STAMP(4);
+#ifdef FM_PARK_PROF
+            if (huge_round) HUGE_STAMP(4);
+#endif
             // (b) per accepted match: neighbour key + seen probe, result key + found probe.
             //     keys[k] = neighbour key (or ~0), rk[k] = result key (int-truncated positions)
             for (int k0 = 0; k0 < na; k0 += kExpThreads) {
@@ -1086,6 +1165,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             }
         }
         EXP_STAMP(5);
+#ifdef FM_PARK_PROF
+        if (huge_round) HUGE_STAMP(5);
+#endif
         n_matches += n_emit;
         __threadfence_block();
         __syncthreads();           // table / stack writes visible before the next round reads them
@@ -1101,6 +1183,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[2] = n_pairs;
         P.result[3] = status;
         if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
+#ifdef FM_PARK_PROF
+        HUGE_STAMP(6);
+        for (int k = 0; k < 8; ++k) P.result[8 + k] = (P.resume ? P.result[8 + k] : 0) + hp[k];
+#endif
         if constexpr (LAZY || HUGE) {
             P.result[4] = need_cell;
             if (status == kExpNeedXcheck) { P.result[5] = P.resume_state[10]; P.result[6] = P.resume_state[11]; P.result[7] = P.resume_state[12]; }

@@ -45,6 +45,8 @@ struct ExpandPair {
     int64_t  match_cap;
     // huge tier (a radius subset beyond the LDS tables, expand.hip): per-run scratch in global memory, or null
     int32_t* h_cand;               // [nq] the round's sorted query rows, all slots
+    unsigned long long* h_pkey;    // [nq] the subset's sort keys partitioned by chunk (slot ranges as h_cand)
+    int32_t* h_ucand;              // [nq] the round's subset as the radius query found it (unsorted; its keys sit in h_qbest until the election)
     unsigned long long* h_qbest;   // [nq] cross-check table of the round, all slots
     unsigned long long* h_tbest;   // [largest cell] per train row: running (d2 << 32 | slot) minimum over the chunks
     // lazy targets (expand.hip, LAZY): cells arrive one by one; per cell its first row, row count and a ready flag
