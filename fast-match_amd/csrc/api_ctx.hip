@@ -250,6 +250,7 @@ static const OptionDef kOptions[] = {
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
     {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"}, {"bound_every", &Tuning::bound_every, 1, 1024, "FM_BOUND_EVERY"}, {"refill_grid", &Tuning::refill_grid, 1, 1 << 20, "FM_REFILL_GRID"},
     {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_huge", &Tuning::expand_huge, 0, 1, nullptr}, {"expand_delegate", &Tuning::expand_delegate, 0, 1 << 30, "FM_EXPAND_DELEGATE"}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
+    {"delegated_rounds", &Tuning::delegated_rounds, 0, 0, nullptr},       // a counter: set to 0, read
 };
 
 extern "C" int fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value)

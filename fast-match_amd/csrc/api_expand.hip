@@ -292,13 +292,22 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
     host.seeds = r->d_seeds; host.n_seeds = n_seeds; host.tau = tau; host.prof = 0;
     host.resume = resume ? 1 : 0;
     host.tie_guard = sqrt_tie_possible(*ex->query, *ex->lazy_target) ? 1 : 0;     // (the target bank has grown since the pair was made)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+    // big rounds' cross-checks go to the dense kernels, as in fm_expand_run: the run parks with status 8 and is resumed here
+    host.delegate_min = host.tie_guard ? 0 : ctx->tune.expand_delegate;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, false, 3, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    long long res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (;;) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, false, 3, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (res[3] != 8) break;
+        if ((rc = round_xcheck_dense(ctx, *ex->query, host.h_cand, res[5], *ex->lazy_target, res[6], res[7], host.h_qbest)) != FM_OK) return rc;
+        if (ctx->tune.delegated_rounds < INT32_MAX) ++ctx->tune.delegated_rounds;
+        host.resume = 2;
+    }
     ctx->kernel_timed = true;
-    long long res[5] = {0, 0, 0, 0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = cs.finish()) != FM_OK) return rc;
     if (n_matches) *n_matches = res[0];
     if (n_rounds) *n_rounds = res[1];
@@ -549,6 +558,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         ctx->pending_pairs += res[(size_t)i * 8 + 2];
         if (res[(size_t)i * 8 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
     }
+    ctx->tune.delegated_rounds = (int)std::min<int64_t>((int64_t)INT32_MAX, (int64_t)ctx->tune.delegated_rounds + delegated);
     if (dbg && getenv("FM_PARK_PROF")) {               // (a library built with -DFM_PARK_PROF: expand.hip)
         long long pr[16];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);

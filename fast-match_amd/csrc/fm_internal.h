@@ -74,6 +74,7 @@ struct Tuning {
     int async_time_every = 4;         // async calls: every n-th call carries kernel timing events (0 = none)
     int expand_big = 1;               // K7: re-run pairs that overflow the 2048-row round in the 4096-row variant
     int expand_huge = 1;              // K7: re-run pairs that still overflow in the variant that chunks a radius subset of any size
+    int delegated_rounds = 0;         // (counter, saturating) rounds whose cross-check the dense kernels ran since it was last set to 0
     int expand_delegate = 1500000;    // K7: a chunked round of at least this many descriptor pairs is parked and its cross-check run
                                       // by the dense kernels on the whole GPU (0 = never: the round's own workgroup does it)
     int expand_grow = 2;              // K7: how often a run that fills its stack / result list / table is repeated in a

@@ -93,6 +93,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "expand_huge"  0|1    K7: ... and those that still do in the variant that takes a radius subset of any size in chunks (1)
  *   "expand_delegate" 0.. K7: a chunked round of at least this many descriptor pairs parks its run; the round's cross-check
  *                         is run by the dense kernels on the whole GPU and the run resumed (1 500 000; 0 = never)
+ *   "delegated_rounds" 0  a COUNTER, not a setting: rounds whose cross-check the dense kernels ran (fm_expand_run,
+ *                         fm_expand_run_lazy) since it was last set to 0 -- the only value it accepts
  *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
  *                         repeated in a run state four times as large (2)
  *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
@@ -399,7 +401,8 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
  *   fm_expand_set_cell    : cell (= col * rows + row) := rows [first_row, first_row + n_rows) with their full-image positions;
  *                           n_rows = 0 for a cell without features.
  *   fm_expand_run_lazy    : one run in slot 0, from the start (resume = 0) or from where the last launch parked (resume != 0).
- *                           status 0: done (fm_expand_fetch); FM_EXPAND_NEED_CELL: *need_cell; else the device gave up.        */
+ *                           status 0: done (fm_expand_fetch); FM_EXPAND_NEED_CELL: *need_cell; else the device gave up.
+ *                           (Rounds of >= "expand_delegate" descriptor pairs are cross-checked by the dense kernels inside the call.) */
 int  fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank);
 int  fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t n, int64_t* first_row);
 int  fm_expand_set_cell(fm_ctx* ctx, fm_expand* ex, int32_t cell, int64_t first_row, int64_t n_rows, const double* pos /*[n_rows][2]*/);

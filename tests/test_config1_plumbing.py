@@ -216,6 +216,25 @@ def test_pixel_target_runs_the_loop_on_the_device_with_cells_computed_on_demand(
     assert big["pairs"] > 50 * 2048 * big["rounds"] / 4            # (subsets really are that large)
     for (ia, da), (ib, db) in zip(wide, wexp):
         assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    # ... and with EVERY round's cross-check handed to the dense kernels (expand_delegate = 1: a lazy run parks for them as it
+    # parks for cells; both kinds of park in one run)
+    keep = ctx.get_option("expand_delegate")
+    ctx.set_option("expand_delegate", 1)
+    ctx.set_option("delegated_rounds", 0)
+    exp09 = oget(0.9)
+    oget(0.7)                                                   # (oget.rounds is the last call's: the check further down wants 0.7's)
+    try:
+        for opts, want in (({"radius": 300}, wexp), ({}, exp09)):
+            dl = {}
+            o = {"context": ctx, "feature_function": feat, "stats": dl}
+            o.update(opts)
+            got = fastmatch.match(mc, img1, o)(0.7 if opts else 0.9)
+            assert dl.get("device_loops") == 1 and "device_fallbacks" not in dl and len(got) == len(want)
+            for (ia, da), (ib, db) in zip(got, want):
+                assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    finally:
+        ctx.set_option("expand_delegate", keep)
+    assert ctx.get_option("delegated_rounds") > 500            # (nearly every round of the two runs)
     # a target bank with room for 64 rows: the second cell does not fit -> host loop, same result
     fb = {}
     small = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": fb, "lazy_capacity": 64})(0.7)

@@ -290,8 +290,11 @@ def test_device_loop_on_clustered_keypoints(ctx):
                              t["thumb_descriptors"], t["thumb_size"])
     ds, hs = {}, {}
     get = fastmatch.match(mc, fi, {"context": ctx, "stats": ds, "return_arrays": True})
+    ctx.set_option("delegated_rounds", 0)
     index, pos, ratio = get(0.7)
     assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds
+    n_deleg = ctx.get_option("delegated_rounds")
+    assert n_deleg > 100
     # the big rounds' cross-checks were DELEGATED to the dense kernels (option expand_delegate: rounds of >= 1.5e6 descriptor
     # pairs park the run; K1 + the election on the whole GPU; resume at steps 4 / 5); without delegation the round's own
     # workgroup does them in chunks -- same lists either way
@@ -303,6 +306,7 @@ def test_device_loop_on_clustered_keypoints(ctx):
         i2, p2, r2 = get(0.7)
     finally:
         ctx.set_option("expand_delegate", 1500000)
+    assert ctx.get_option("delegated_rounds") == n_deleg       # (none in the second run)
     assert np.array_equal(index, i2) and np.array_equal(pos, p2) and np.array_equal(ratio, r2) and ds == first
     host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.7)
     assert ds["rounds"] == hs["rounds"] and ds["pairs"] == hs["pairs"] and len(host) == len(index) > 3000
