@@ -436,10 +436,10 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         big[(size_t)i] = (char)t;
         if (t == 2) expand_bind_run(host[i], *run[(size_t)i], pairs[i]);
     }
-    // Chunked int8 runs hand a big round's cross-check to the dense kernels (expand.hip, DELEGATED); phase timers off then
+    // Chunked runs (both descriptor kinds) hand a big round's cross-check to the dense kernels (expand.hip, DELEGATED); phase timers off then
     // (a parked run's timers would restart)
     auto set_delegate = [&](int i) {
-        host[i].delegate_min = (big[(size_t)i] == 2 && !host[i].f32 && !host[i].tie_guard && !host[i].prof) ? ctx->tune.expand_delegate : 0;
+        host[i].delegate_min = (big[(size_t)i] == 2 && !host[i].tie_guard && !host[i].prof) ? ctx->tune.expand_delegate : 0;
     };
     for (int i = 0; i < n; ++i) set_delegate(i);
     // kernel of a run: int8 tiers 0 / 1 / 2, float32 tiers 0 / 2

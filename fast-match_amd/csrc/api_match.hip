@@ -459,6 +459,34 @@ void gather_rows_kernel(const int32_t* __restrict__ rows, int64_t nq, const int8
     }
 }
 
+// The same for a float32 bank: float32 rows, fp16 filter rows, scaled norms and accumulator inits, in the layout
+// bank_copy_f32_kernel / bank_prep_f16_kernel write (padding slots: zero rows, init -3.4e38).  16 rows per 256-thread block.
+__global__ __launch_bounds__(256)
+void gather_rows_f32_kernel(const int32_t* __restrict__ rows, int64_t nq, const float* __restrict__ srcf, const uint16_t* __restrict__ srch,
+                            const float* __restrict__ srcnorm, const float* __restrict__ srcaux, float* __restrict__ dstf,
+                            uint16_t* __restrict__ dsth, float* __restrict__ dstnorm, float* __restrict__ dstaux,
+                            unsigned long long* __restrict__ qbest)
+{
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int64_t slot = (int64_t)blockIdx.x * 16 + r;
+    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+    uint4 h = make_uint4(0, 0, 0, 0);
+    float nm = 0.f, ax = -3.4e38f;
+    if (slot < nq) {
+        const int64_t qi = rows[slot];
+        f0 = *(const float4*)(srcf + qi * kDim + 8 * c);
+        f1 = *(const float4*)(srcf + qi * kDim + 8 * c + 4);
+        h = *(const uint4*)(srch + qi * kDim + 8 * c);
+        nm = srcnorm[qi];
+        ax = srcaux[qi];
+        if (c == 1) qbest[slot] = ~0ull;
+    }
+    *(float4*)(dstf + slot * kDim + 8 * c) = f0;
+    *(float4*)(dstf + slot * kDim + 8 * c + 4) = f1;
+    *(uint4*)(dsth + slot * kDim + 8 * c) = h;
+    if (c == 0) { dstnorm[slot] = nm; dstaux[slot] = ax; }
+}
+
 // Cross-checked 1-NN of the query subset d_rows[0 .. nq) of bank q against the train rows [t0, t0 + nt) of bank t, the
 // way fm_xcheck1 does it on gathered banks (reverse NN by K1 with the train rows as output rows, election by
 // scatter-min), into d_qbest[slot] = (float32 distance bits << 32 | local train row), ~0 = unmatched.  Enqueued on the
@@ -471,6 +499,38 @@ int fm::round_xcheck_dense(fm_ctx* ctx, const Bank& q, const int32_t* d_rows, in
     const int64_t nq_pad = ((nq + kStageRows - 1) / kStageRows) * kStageRows;
     size_t off = 0;
     auto carve = [&](size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
+    if (q.kind == FM_BANK_F32) {
+        // float32 banks: the gathered rows in the float32 layout, then the float32 route's own cross-check (fp16 filter +
+        // exact rescoring, or all pairs for small rounds: rowreduce_f32_route) with the cell's rows as output rows
+        const size_t o_f = carve((size_t)nq_pad * kDim * 4), o_h = carve((size_t)nq_pad * kDim * 2), o_n = carve((size_t)nq_pad * 4),
+                     o_a = carve((size_t)nq_pad * 4);
+        int rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, off + 64);
+        if (rc != FM_OK) return rc;
+        char* b = (char*)ctx->ws_out;
+        fm_bank gq, tv;
+        gq.kind = FM_BANK_F32; gq.n = nq; gq.dim = q.dim; gq.n_pad = nq_pad; gq.cap_pad = nq_pad;
+        gq.rowsf = (float*)(b + o_f); gq.rowsh = (uint16_t*)(b + o_h); gq.normf = (float*)(b + o_n); gq.auxf = (float*)(b + o_a);
+        gq.nm_max = q.nm_max; gq.kscale = q.kscale; gq.filt_ok = q.filt_ok;
+        hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)(nq_pad / 16)), dim3(256), 0, ctx->stream, d_rows, nq,
+                           (const float*)q.rowsf, (const uint16_t*)q.rowsh, (const float*)q.normf, (const float*)q.auxf,
+                           gq.rowsf, gq.rowsh, gq.normf, gq.auxf, d_qbest);
+        HIP_TRY(ctx, hipGetLastError());
+        tv.kind = FM_BANK_F32; tv.n = nt; tv.dim = t.dim;
+        tv.n_pad = ((nt + kStageRows - 1) / kStageRows) * kStageRows;
+        const int64_t room = (t.cap_pad > 0 ? t.cap_pad : t.n_pad) - t0;
+        if (tv.n_pad > room) tv.n_pad = room;
+        tv.cap_pad = tv.n_pad;
+        tv.rowsf = t.rowsf + (size_t)t0 * kDim; tv.rowsh = t.rowsh ? t.rowsh + (size_t)t0 * kDim : nullptr;
+        tv.normf = t.normf ? t.normf + t0 : nullptr; tv.auxf = t.auxf ? t.auxf + t0 : nullptr;
+        tv.nm_max = t.nm_max; tv.kscale = t.kscale; tv.filt_ok = t.filt_ok;
+        RowReducePlan pl;
+        if ((rc = rowreduce_f32_route(ctx, &tv, &gq, 1, &pl)) != FM_OK) return rc;
+        const int64_t sthreads = nt * 4;
+        hipLaunchKernelGGL(xcheck_scatter_kernel, dim3((unsigned)((sthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long*)ctx->ws_partial, pl.nsplit, pl.ncols_alloc, nt, d_qbest, 0u, 1, (int*)nullptr, (unsigned*)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+        return FM_OK;
+    }
     const size_t o_rows = carve((size_t)nq_pad * kDim), o_norm = carve((size_t)nq_pad * 4), o_aux = carve((size_t)(nq_pad / kTileRows) * kAuxPerTile * 4);
     int rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, off + 64);
     if (rc != FM_OK) return rc;

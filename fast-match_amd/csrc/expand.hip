@@ -694,7 +694,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
         if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
         n_pairs += (long long)nq * nt;
-        if constexpr (HUGE && !F32) {
+        if constexpr (HUGE) {
             // a round whose subset fits LDS but whose CELL is large (thousands of train rows: a blob of keypoints) is
             // delegated like a chunked one: the sorted subset goes to h_cand[], the run parks (see the chunked branch)
             if (P.delegate_min > 0 && !P.tie_guard && (long long)nq * nt >= 2 * P.delegate_min) {
@@ -838,7 +838,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             // rate, and microseconds of the whole chip's.  The round sorts its subset into h_cand[] as always, then PARKS
             // the run (the state a lazy run saves, + the subset's size); fm_expand_run gathers the subset's rows, runs the
             // dense reverse-NN kernel (K1) and the election on the whole GPU into h_qbest[] and resumes the run at steps 4 / 5.
-            const bool deleg = !F32 && P.delegate_min > 0 && (long long)nq * nt >= P.delegate_min;
+            const bool deleg = P.delegate_min > 0 && (long long)nq * nt >= P.delegate_min;
             for (int c = 0; c < nch; ++c) {
                 const int b0 = chb[c], b1 = chb[c + 1];
                 const unsigned base = (unsigned)chrow[c];

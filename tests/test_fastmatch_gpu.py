@@ -258,12 +258,29 @@ def test_device_loop_chunks_radius_subsets_of_float32_banks(ctx, monkeypatch):
           "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
     exp = fo.o_match(oq, ot, {"radius": 200})(0.9)
     stats, hs = {}, {}
+    ctx.set_option("delegated_rounds", 0)
     got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(0.9)
     assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats
     _same_matches(got, exp)
+    # (rounds of >= 1.5e6 descriptor pairs had their cross-check DELEGATED: the gathered subset in the float32 layout,
+    # the float32 route's dense cross-check with the cell's rows as output rows, the run resumed at steps 4 / 5)
+    assert ctx.get_option("delegated_rounds") > 0
     host = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": hs, "device_loop": False})(0.9)
     _same_matches(host, exp)
     assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"] and len(got) > 100
+    # every cross-check in the run's own workgroup (chunks), and every one delegated (small rounds take the all-pairs
+    # float32 kernel behind the gather, big ones the fp16 filter): the same lists
+    for dmin in (0, 1):
+        ctx.set_option("expand_delegate", dmin)
+        ctx.set_option("delegated_rounds", 0)
+        try:
+            st2 = {}
+            again = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": st2})(0.9)
+        finally:
+            ctx.set_option("expand_delegate", 1500000)
+        assert st2.get("device_loops") == 1 and "device_fallbacks" not in st2 and st2["rounds"] == stats["rounds"]
+        assert (ctx.get_option("delegated_rounds") > 0) == (dmin == 1)
+        _same_matches(again, exp)
     ctx.set_option("expand_huge", 0)
     try:
         fb = {}
