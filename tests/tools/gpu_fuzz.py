@@ -129,6 +129,13 @@ def fuzz_match(rng):
     if rng.integers(0, 3) == 0:                               # r04: clustered keypoints
         kw = {"clusters": int(rng.integers(1, 5)), "cluster_sigma": float(rng.uniform(8.0, 60.0)), "cluster_frac": float(rng.uniform(0.2, 0.9))}
     q, t = synth.image_pair((w, h), n, seed, n_thumb=min(600, n), **kw)
+    rootsift = rng.integers(0, 5) == 0                        # r04: float32 descriptors (the float32 round, its chunks, its delegation)
+    if rootsift:
+        for side in (q, t):
+            for k in ("descriptors", "thumb_descriptors"):
+                d = side[k].astype(np.float32)
+                side[k] = np.sqrt(d / np.maximum(d.sum(axis=1, keepdims=True), 1.0)).astype(np.float32)
+    fo.FLOAT_ORDER = 1 if rootsift else 0                     # (the oracle in the device's accumulation order for those)
     mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
                                         q["thumb_positions"], q["thumb_size"], options=dict(opts, context=ctx))
     fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
@@ -144,7 +151,7 @@ def fuzz_match(rng):
     get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4))))
     oget = fo.o_match(oq, ot, dict(opts))
     taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
-    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()))
+    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else "u8")
     if rng.integers(0, 2) and len(taus) > 1:
         got_all = get(taus)
     else:
@@ -180,6 +187,7 @@ def run(budget, seed0, max_problems=None, context=None):
     finally:
         for k, v in saved.items():
             ctx.set_option(k, v)
+        fo.FLOAT_ORDER = 0
     return it, counts
 
 
