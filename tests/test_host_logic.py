@@ -235,3 +235,36 @@ def test_launch_plan_keeps_new_run_states_inside_the_memory_budget():
     assert fastmatch._launch_plan(Ctx(2), [Ex(100, 5)] * 5) == [list(range(5))]
     # a single run that does not fit still gets a launch of its own (the launch then reports FM_ENOMEM -> host loop)
     assert fastmatch._launch_plan(Ctx(2), [Ex(100, 0), Ex(100, 0)]) == [[0], [1]]
+
+
+def test_cell_planner_against_the_reference_crop_bounds():
+    """fm_grid_pack_cells against golden vectors from the reference's own Grid_Cache (bak/cache.py `cache()` bounds,
+    tests/golden/grid_golden.json): a keypoint is in a cell's packed rows exactly when it lies inside the crop the reference
+    hands its caching function -- [x_min, x_max) x [y_min, y_max) -- probed at the corners, just inside and just outside."""
+    import json
+    import os
+    from fastmatch_amd import _ffi
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_golden.json")))
+    checked = 0
+    for case in g["cases"]:
+        (w, h), (cw, ch), margin, rows, cols = case["size"], case["cell_size"], case["margin"], case["rows"], case["cols"]
+        if cw != int(cw) or ch != int(ch):
+            continue                                             # (Grid_Cache truncates the cell size: integer cells only here)
+        pts, want = [], []
+        e = 1e-7
+        for col, row, x0, x1, y0, y1 in case["bounds"]:
+            cell = col * rows + row
+            for x, y, inside in ((x0, y0, True), (x1 - e, y1 - e, True), (x0, y1 - e, True), (x1 - e, y0, True),
+                                 (x1, y0, False), (x0, y1, False), (x0 - e, y0, False), (x0, y0 - e, False)):
+                if x1 > x0 and y1 > y0:
+                    pts.append((x, y)); want.append((cell, inside))
+        pos = np.array(pts, dtype=np.float64)
+        src_row, t_pos, cell_off = _ffi.grid_pack_cells(pos, w, h, int(cw), int(ch), rows, cols, margin)
+        cells_of = {}
+        for cell in range(rows * cols):
+            for p in src_row[cell_off[cell]:cell_off[cell + 1]]:
+                cells_of.setdefault(int(p), set()).add(cell)
+        for i, (cell, inside) in enumerate(want):
+            assert (cell in cells_of.get(i, set())) == inside, (case["size"], case["cell_size"], margin, pts[i], cell, inside)
+            checked += 1
+    assert checked > 500
