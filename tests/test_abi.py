@@ -61,3 +61,39 @@ def test_abi_revision_of_header_library_and_binding_agree():
     fields = re.search(r"typedef struct fm_stats_ex \{(.*?)\} fm_stats_ex;", hdr, flags=re.S).group(1)
     names = re.findall(r"\b([a-z_]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
     assert names == [f[0] for f in _ffi.fm_stats_ex._fields_]
+
+
+def test_struct_layouts_of_the_binding_match_the_header_as_a_c_compiler_sees_it(tmp_path):
+    """The ctypes mirrors of fm_stats, fm_stats_ex and fm_expand_desc against sizeof / offsetof from gcc on the header:
+    same size, every field at the same offset, in the same order."""
+    import ctypes
+    import subprocess
+    structs = {"fm_stats": _ffi.fm_stats, "fm_stats_ex": _ffi.fm_stats_ex, "fm_expand_desc": _ffi.fm_expand_desc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fastmatch_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (name, name))
+        for f in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f[0], name, f[0]))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        if not line:
+            continue
+        name, field, value = line.split()
+        cls = structs[name]
+        if field == "size":
+            assert ctypes.sizeof(cls) == int(value), name
+        else:
+            assert getattr(cls, field).offset == int(value), (name, field)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
+    # ... and the header declares no field the binding lacks
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fastmatch_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct fm_expand_desc \{(.*?)\} fm_expand_desc;", hdr, flags=re.S).group(1)
+    names = re.findall(r"\b([a-z_0-9]+)\s*[,;]", body)
+    assert names == [f[0] for f in _ffi.fm_expand_desc._fields_]
