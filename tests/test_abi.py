@@ -97,3 +97,41 @@ def test_struct_layouts_of_the_binding_match_the_header_as_a_c_compiler_sees_it(
     body = re.search(r"typedef struct fm_expand_desc \{(.*?)\} fm_expand_desc;", hdr, flags=re.S).group(1)
     names = re.findall(r"\b([a-z_0-9]+)\s*[,;]", body)
     assert names == [f[0] for f in _ffi.fm_expand_desc._fields_]
+
+
+def test_every_prototype_of_the_header_matches_the_binding_argument_by_argument():
+    """ADVICE r03 found a signature that had changed under the binding.  Every prototype of the header against the ctypes
+    argtypes: same number of parameters, and per parameter the same class (pointer, 64-bit integer, 32-bit integer, double,
+    float) -- an inserted or reordered argument cannot go unnoticed."""
+    import ctypes
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fastmatch_hip.h")).read(), flags=re.S)
+    protos = re.findall(r"\b(?:const\s+char\s*\*|int|void)\s+(fm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) == len(_ffi.SYMBOLS)
+
+    def klass_of_text(p):
+        p = " ".join(p.split())
+        if "*" in p or "[" in p:
+            return "ptr"
+        if re.search(r"\bdouble\b", p):
+            return "f64"
+        if re.search(r"\bfloat\b", p):
+            return "f32"
+        if re.search(r"\b(int64_t|uint64_t|size_t|long long)\b", p):
+            return "i64"
+        if re.search(r"\b(int32_t|uint32_t|int|unsigned)\b", p):
+            return "i32"
+        raise AssertionError("unclassified parameter: " + p)
+
+    def klass_of_ctype(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) is not None and issubclass(t, ctypes._Pointer):
+            return "ptr"
+        return {ctypes.c_double: "f64", ctypes.c_float: "f32", ctypes.c_int64: "i64", ctypes.c_uint64: "i64",
+                ctypes.c_int: "i32", ctypes.c_int32: "i32", ctypes.c_uint32: "i32"}[t]
+
+    for name, params in protos:
+        params = params.strip()
+        texts = [] if params in ("", "void") else [p for p in params.split(",")]
+        argtypes = _ffi.SYMBOLS[name][1]
+        assert len(texts) == len(argtypes), "%s: header has %d parameters, the binding %d" % (name, len(texts), len(argtypes))
+        for i, (p, t) in enumerate(zip(texts, argtypes)):
+            assert klass_of_text(p) == klass_of_ctype(t), "%s: parameter %d (%s) is bound as %s" % (name, i, " ".join(p.split()), t)
