@@ -268,3 +268,24 @@ def test_cell_planner_against_the_reference_crop_bounds():
             assert (cell in cells_of.get(i, set())) == inside, (case["size"], case["cell_size"], margin, pts[i], cell, inside)
             checked += 1
     assert checked > 500
+
+
+def test_cell_planner_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The library's host-only code (api_grid.hip) built for the HOST with -fsanitize=address,undefined and driven by
+    tests/tools/planner_sanitize.hip: 4000 random geometries, keypoints incl. NaN / infinite / 1e300 coordinates, output
+    buffers one row short -- no report, and every packed row inside its cell's crop by an independent formula."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "planner_sanitize")
+    csrc = os.path.join(root, "fast-match_amd", "csrc")
+    subprocess.check_call([hipcc, "-std=c++17", "-O1", "-g", "--cuda-host-only", "--offload-arch=gfx950",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", csrc, "-I", os.path.join(root, "include"),
+                           os.path.join(csrc, "api_grid.hip"), os.path.join(root, "tests", "tools", "planner_sanitize.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
