@@ -143,3 +143,18 @@ def test_vectorised_baseline_equals_the_faithful_scan():
             T[3] = Q[5]; T[11] = Q[5]; Q[17] = Q[5]
         same(Q, T)
     same(*far_banks(300, 200, rng))
+
+
+def test_oracle_c_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """oracle/bfmatch_oracle.c compiled with -fsanitize=address,undefined into tests/tools/oracle_sanitize.c: 600 random
+    shapes (0 / 1 rows, k = 2 against one row, dim 1 .. 128, exact-size heap blocks), the four float32 accumulation
+    orders, the vectorised cross-check against the scalar one -- no report."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-O1", "-g", "-march=x86-64-v3", "-fopenmp", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", os.path.join(root, "oracle", "bfmatch_oracle.c"),
+                           os.path.join(root, "tests", "tools", "oracle_sanitize.c"), "-lm", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
