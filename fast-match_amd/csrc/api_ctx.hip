@@ -249,6 +249,7 @@ static const OptionDef kOptions[] = {
     {"batch_group", &Tuning::batch_group, 1, kRRBatchMax, "FM_BATCH_GROUP"}, {"batch_tail", &Tuning::batch_tail, 0, kRRBatchMax, "FM_BATCH_TAIL"},
     {"async_time_every", &Tuning::async_time_every, 0, 1 << 20, "FM_ASYNC_TIME_EVERY"},
     {"k1_order", &Tuning::k1_order, 0, 2, "FM_K1_ORDER"}, {"bound_every", &Tuning::bound_every, 1, 1024, "FM_BOUND_EVERY"}, {"refill_grid", &Tuning::refill_grid, 1, 1 << 20, "FM_REFILL_GRID"},
+    {"self_tri", &Tuning::self_tri, 0, 2, "FM_SELF_TRI"}, {"tri_stages", &Tuning::tri_stages, 0, 4096, "FM_TRI_STAGES"},
     {"expand_big", &Tuning::expand_big, 0, 1, nullptr}, {"expand_huge", &Tuning::expand_huge, 0, 1, nullptr}, {"expand_delegate", &Tuning::expand_delegate, 0, 1 << 30, "FM_EXPAND_DELEGATE"}, {"expand_grow", &Tuning::expand_grow, 0, 4, nullptr}, {"expand_prof", &Tuning::expand_prof, 0, 1, "FM_EXPAND_PROF"},
     {"delegated_rounds", &Tuning::delegated_rounds, 0, 0, nullptr},       // a counter: set to 0, read
 };
@@ -361,6 +362,7 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     for (auto& m : ctx->marks) for (hipEvent_t ev : m.ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->aslot) free_slot(sl);
     for (auto& sl : ctx->bslot) free_slot(sl);
+    for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
     if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);

@@ -360,6 +360,44 @@ __global__ void selfdist_merge_kernel(SelfMerge m, int nsplit, int ncols_alloc, 
     m.out[b][i] = (k == ~0ull) ? (double)INFINITY : (double)key_dist(k, f32);
 }
 
+// The triangular self sweep (rowreduce.hip, TRI) leaves, per row, the best hi it has reached as an output row in
+// bound[]: d2 = |row|^2 + 1 - bound; a word at or below kTriNoBoundHost met no real row (a bank of one row).
+struct TriFinish {
+    const int* bound[kRRBatchMax];
+    const int32_t* norm[kRRBatchMax];
+    double* out[kRRBatchMax];
+    int64_t n[kRRBatchMax];
+};
+
+__global__ void selfdist_tri_finish_kernel(TriFinish m)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= m.n[b]) return;
+    const int h = m.bound[b][i];
+    m.out[b][i] = (h > kTriNoBoundHost) ? (double)sqrtf((float)(unsigned)(m.norm[b][i] + 1 - h)) : (double)INFINITY;
+}
+
+// Plan + device table of the triangular sweep for banks of n_pad rows, kept per context.
+static int tri_plan_for(fm_ctx* ctx, int64_t n_pad, TriPlan* out)
+{
+    const std::pair<int64_t, int> key(n_pad, ctx->tune.tri_stages * 2048 + ctx->tune.bound_every);
+    auto it = ctx->tri_plans.find(key);
+    if (it != ctx->tri_plans.end()) { *out = it->second; return FM_OK; }
+    std::vector<int> table;
+    TriPlan pl = plan_tri(n_pad, ctx->tune.tri_stages, &table);
+    int* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, table.size() * sizeof(int)));
+    hipError_t e = hipMemcpy(d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(ctx, e); }
+    pl.d_table = d;
+    pl.bound_every = 1;
+    for (int b = 2; b <= 1024; b <<= 1) if (ctx->tune.bound_every == b) pl.bound_every = b;
+    ctx->tri_plans[key] = pl;
+    *out = pl;
+    return FM_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // float32 route: K5 alone, or the fp16 filter (K8) with K5 as its conditional fallback
 // ---------------------------------------------------------------------------------------
@@ -718,6 +756,37 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
                                m, pl.nsplit, pl.ncols_alloc, b->n, 1);
             HIP_TRY(ctx, hipGetLastError());
             ++i;
+            continue;
+        }
+        if (ctx->tune.glds != 0 && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && b->n_pad >= 32768))) {
+            // every distance once: the triangular sweep, up to "batch_group" banks of one padded size per launch
+            TriPlan tp;
+            if ((rc = tri_plan_for(ctx, b->n_pad, &tp)) != FM_OK) return rc;
+            int g = 1;
+            while (i + g < n && g < group_max && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0 && banks[i + g]->n_pad == b->n_pad) ++g;
+            const size_t bbytes = ((size_t)tp.ncols_alloc * 4 + 255) & ~(size_t)255;
+            if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, (size_t)g * bbytes)) != FM_OK) return rc;
+            const Bank* bk[kRRBatchMax];
+            int* bnd[kRRBatchMax];
+            TriFinish fin{};
+            int64_t nmax = 0;
+            for (int j = 0; j < g; ++j) {
+                bk[j] = banks[i + j];
+                bnd[j] = (int*)((char*)ctx->ws_partial + (size_t)j * bbytes);
+                fin.bound[j] = bnd[j]; fin.norm[j] = bk[j]->norm; fin.out[j] = d_out[i + j]; fin.n[j] = bk[j]->n;
+                nmax = bk[j]->n > nmax ? bk[j]->n : nmax;
+                // (each distance is computed once; the pairs a caller asked for are still n x n)
+                ctx->pending_pairs += bk[j]->n * bk[j]->n;
+                ctx->pending_bytes += bank_bytes(bk[j]);
+            }
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[0], (int)0x80000000, (size_t)g * (bbytes / 4), ctx->stream));
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce_tri(g, bk, tp, bnd, ctx->tune.prio != 0, ctx->stream));
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+            ctx->kernel_timed = timed;
+            hipLaunchKernelGGL(selfdist_tri_finish_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)g), dim3(256), 0, ctx->stream, fin);
+            HIP_TRY(ctx, hipGetLastError());
+            i += g;
             continue;
         }
         const RowReducePlan pl = plan_rowreduce_self(b->n_pad, ctx->tune);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/fastmatch_hip.h"
 
 namespace fm {
@@ -84,6 +85,9 @@ struct Tuning {
                                       // two; r04 A/B on two boxes, ms per pair in the 12-pair launch: 1 -> 0.8356 / 0.8501, 8 -> 0.8290 /
                                       // 0.8399, 32 -> 0.8277, 1024 -> 0.8340: profiles/r04c_k1_bound_every_*)
     int refill_grid = 128;            // fm_bank_refill_u8_async: workgroups of the preparation kernel (each walks its share of the tiles)
+    int self_tri = 1;                 // fm_self_dist on integer banks: 1 = the triangular sweep (every distance once) from 32768 rows
+                                      // on, 0 = the masked full sweep always, 2 = the triangular sweep always (tests)
+    int tri_stages = 0;               // ... stages (128 rows) per slice of the triangular sweep (0 = plan_tri's search)
     int k1_order = 0;                 // K1: workgroup -> (chunk, split) mapping (rowreduce.hip, map_block): 0 split major,
                                       // 1 an XCD owns output chunks, 2 an XCD owns a contiguous share of the split-major order
 };
@@ -115,6 +119,18 @@ int rowreduce_grid(const RowReducePlan& plan);      // workgroups per bank pair 
 RowReducePlan plan_rowreduce_self(int64_t n_pad, const Tuning& tn);
 hipError_t launch_rowreduce_self(const Bank& bank, const RowReducePlan& plan, unsigned long long* partial, int* bound,
                                  bool use_glds, hipStream_t stream);
+
+// fm_self_dist on large integer banks: the triangular sweep (rowreduce.hip, "TRI") -- every distance of a bank
+// against itself once, bound[] carries the result (d2(i) = norm[i] + 1 - bound[i]; <= kTriNoBoundHost: none).
+struct TriPlan {
+    int nchunks = 0, ncols_alloc = 0, npieces = 0, stages = 0;
+    int ndiag = 0;                     // the first ndiag workgroups of the table are launch A (the diagonal blocks)
+    int bound_every = 16;              // Tuning::bound_every (a power of two)
+    const int* d_table = nullptr;      // device: int4 per workgroup (chunk, first stage, end stage, 0)
+};
+TriPlan plan_tri(int64_t n_pad, int target_stages, std::vector<int>* table);
+hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& plan, int* const* bound, bool prio, hipStream_t stream);
+constexpr int kTriNoBoundHost = -(1 << 25);     // (a real pair's word is >= -3 * 2^21, a padding row's or the masked diagonal's ~ -2^26)
 
 // ---- K5: float32 route (dist_f32.hip); partial keys carry float32 distance bits ----------
 // run_flag: device word; the kernel returns at once when *run_flag == 0 (null = always run) and

@@ -27,6 +27,9 @@
 #include "tile_ops.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include <functional>
 
 #ifdef FM_COUNT_VISITS
 __device__ unsigned long long g_visits[256];     // [split]: exact-path visits (wave, block), [64 + split]: lanes that want them, [128 + split]: units x blocks
@@ -68,11 +71,35 @@ struct RRParams {
     int            order;         // workgroup -> (chunk, split) mapping, see map_block
     int            bound_mask;    // shared bounds are re-read at every stage of a sweep's first 8 and then at the stages
                                   // whose number & bound_mask == 0 (0: every stage; option "bound_every" 1 | 2 | 4 | 8)
+    int            tri_nocol;     // TRI, measurements only (FM_TRI_NOCOL=1, WRONG results): the column direction never fires
+    const int4*    tri;           // TRI kernels: workgroup -> (output chunk, first stage, end stage, -), plan_tri's table
 };
 
 // Accumulator value of a masked (output row == reduced row) pair in the SELF kernels: below the padding
 // rows' -2^25, so the diagonal never beats anything, and (value << 5) still fits int32.
 constexpr int kSelfMasked = kPadCinit - 1;
+
+// ---- triangular self sweep (TRI) ------------------------------------------------------------------------
+// d(i, j) = d(j, i): the masked sweep above computes every distance of a bank against itself twice.  The TRI
+// kernels sweep, for an output chunk, only the stages from the chunk's own rows on (the square block on the
+// diagonal in full, masked as above) and use every tile in BOTH directions: along the lane as before (the
+// output row's best over the streamed rows) and across it -- the streamed row's best over the output rows --
+// as a filter against the streamed rows' own words of bound[], which hold the same thing (the best hi a row
+// has reached as an OUTPUT row).  Only the VALUE of the minimum is kept (cache.pyx:252, 273 keep r[1].distance),
+// so bound[] itself carries the result: every improvement of either direction is published with an atomic
+// maximum, and d2(i) = |i|^2 + 1 - bound[i] after the sweep (selfdist_tri_finish_kernel).
+//   frame of bound[m], m as output row, partner c:   B = 2 c.m + 1 - |c|^2
+//   what a lane holds of the pair (m streamed, c = its output row):  acc = c.m + cinit[m],  cinit = -(|m|^2 >> 1)
+//   B > bound[m]   <=>   2 acc - |c|^2 >= bound[m] + 2 cinit[m] =: X[m]                       (exact, integers)
+// X[m] is staged per stage in LDS beside the rows (the bounds are read two stages ahead: a stale bound is
+// merely weaker), together with X8 = the minimum of X over the 8 rows a lane holds of a 32-row unit: the fast
+// path tests max(acc) of the unit against X8 (one v_lshl_add + one compare per unit and block), the exact
+// path tests row by row and publishes.
+constexpr int kTriNever   = 1 << 28;          // X of a row that takes nothing (padding, the diagonal block)
+constexpr int kTriAlways  = -(1 << 28);       // X of a row without a bound yet
+constexpr int kTriXRow    = kStageBytes;                 // int32[128] X per staged row, accumulator order
+constexpr int kTriX8      = kStageBytes + 512;           // int32 X8 at 64 * unit + 16 * lane group
+constexpr int kStageBytesTri = kStageBytes + 512 + 256;  // 18176
 
 // Workgroups of a bank pair that the grid holds under `order` (RowReducePlan::order, option "k1_order"):
 //   0  split major: bid -> (chunk = bid % nchunks, split = bid / nchunks).  Consecutive workgroups -- dealt
@@ -134,6 +161,13 @@ __device__ __forceinline__ void load_bound_untracked(int& dst, const int* ptr)
 {
     asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory");
 }
+// The same through a scalar base and a 32-bit byte offset (+ immediate): no 64-bit address lives in VGPRs.
+template <int IMM, bool SC1 = true>
+__device__ __forceinline__ void load_word_untracked_s(int& dst, const int* base, unsigned voff)
+{
+    if constexpr (SC1) asm volatile("global_load_dword %0, %1, %2 offset:%3 sc1" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+    else               asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
 
 template <bool GLDS, int NW>
 __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* buf, int wave, int lane)
@@ -163,6 +197,51 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
     }
 }
 
+// The same for 8 waves with a wave-UNIFORM wave number (TRI kernels): scalar base + one 32-bit lane offset per
+// LDS-DMA instruction and the LDS destination in M0 straight from scalars -- the compiler's selection for the
+// builtin keeps a 64-bit address pair per piece and the LDS addresses in VGPRs (8 registers the TRI kernel lacks).
+// lo = 128 (lane >> 3) + 16 ((lane & 7) ^ (lane >> 4)): a wave's pieces g = 2 wave, 2 wave + 1 differ in the
+// swizzle term (row >> 1) & 7 by 4 (g & 1) only, i.e. in bit 6 of the byte offset.
+__device__ __forceinline__ void lds_dma_16(unsigned lds_addr, const void* sbase, unsigned voff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+// Agent-scope atomic maximum (no return) through a scalar base and a 32-bit byte offset + immediate.
+template <int IMM>
+__device__ __forceinline__ void atomic_max_s(const int* base, unsigned voff, int val)
+{
+    asm volatile("global_atomic_smax %0, %1, %2 offset:%3" :: "v"(voff), "v"(val), "s"(base), "n"(IMM) : "memory");
+}
+// Maximum over the 16 lanes of a DPP row (the lanes of one lane group: the 16 output rows that face one streamed row).
+__device__ __forceinline__ int rowmax16(int x)
+{
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x128, 0xf, 0xf, false));     // row_ror:8
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x124, 0xf, 0xf, false));     // row_ror:4
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x122, 0xf, 0xf, false));     // row_ror:2
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x121, 0xf, 0xf, false));     // row_ror:1
+    return x;
+}
+// Lane number recomputed where it is used (two VALU): keeps lane-derived addresses of the once-per-stage paths out
+// of the registers that live across the unit loop (volatile: not hoisted out of the stage loop again).
+__device__ __forceinline__ int lane_now()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+__device__ __forceinline__ void issue_stage_u8(const RRParams& p, int stage, char* buf, int wave, int lane, unsigned lo)
+{
+    const int8_t* base = p.red_rows + (size_t)stage * kStageRowBytes + wave * 2048;
+    const unsigned dst = (unsigned)(size_t)LDS_PTR(buf) + (unsigned)wave * 2048u;
+    lds_dma_16(dst, base, lo);
+    unsigned lo1;       // (lo ^ 64 formed here: as a loop invariant it would be one more register across the unit loop)
+    asm volatile("v_xor_b32 %0, 64, %1" : "=v"(lo1) : "v"(lo));
+    lds_dma_16(dst + 1024u, base + 1024, lo1);
+    if (wave == 7)
+        lds_dma_16((unsigned)(size_t)LDS_PTR(buf) + kStageRowBytes, p.red_aux + (size_t)stage * (kStageAuxBytes / 4), (unsigned)lane_now() * 16u);
+}
+
 // NW waves per workgroup share every staged tile; each wave owns NC blocks of 16 output rows.
 // NBUF = LDS stage buffers: 2 = the stage consumed next is the one prefetched last (its LDS-DMA is
 // waited for with vmcnt(0) at every stage hand-over); 3 = prefetch two stages ahead, so the
@@ -173,22 +252,32 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 // the top-1 is min over m != n of d(n, m): what Metric_Cache keeps of bf_match(d, d, k = 2), r[1].distance
 // (cache.pyx:250-252, 271-273; d(n, n) = 0 is always rank 0, and a duplicate's 0 is that minimum).  The
 // 32-row unit that holds a wave's own rows is a wave-uniform test, twice per sweep at most.
-template <int NC, int KTOP, bool GLDS, int NW, int NBUF, int PRIO, bool SELF = false>
+template <int NC, int KTOP, bool GLDS, int NW, int NBUF, int PRIO, bool SELF = false, bool TRI = false>
 __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid, char* smem)
 {
     static_assert(NBUF == 2 || (NBUF == 3 && GLDS), "three stage buffers need the LDS-DMA path");
     static_assert(!SELF || KTOP == 1, "the masked-diagonal sweep is a top-1");
+    static_assert(!TRI || (SELF && NBUF == 3 && NW == 8 && NC == 4), "the triangular sweep is built for one shape");
+    constexpr int kStride = TRI ? kStageBytesTri : kStageBytes;     // bytes of one LDS stage buffer
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = TRI ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int g    = lane >> 4;          // lane group: rows 4g .. 4g+3 of every 16-row tile
+    const unsigned dma_lo = 128u * (lane >> 3) + 16u * ((lane & 7) ^ (lane >> 4));      // (TRI: issue_stage_u8)
     const int c16  = lane & 15;
     // Split-major in time under every order (map_block): the first wave of resident workgroups covers
     // (nearly) every output chunk for the first few slices, so the bounds it publishes serve all later
     // workgroups (which reduce other slices for the same output rows) from their first tile on.
-    int chunk, split;
-    if (!map_block(p, bid, chunk, split)) return;
+    int chunk, split, st0, st1;
+    if constexpr (TRI) {
+        const int4 e = p.tri[bid];          // (uniform: scalar loads)
+        chunk = e.x; st0 = e.y; st1 = e.z; split = 0;
+    } else {
+        if (!map_block(p, bid, chunk, split)) return;
+        st0 = split * p.stages_per_split;
+        st1 = min(st0 + p.stages_per_split, p.nstages);
+    }
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
 
     // Stationary operand: this wave's NC x 16 output rows, two 64-byte K-halves each.
@@ -219,9 +308,6 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     // consumed at the next stage hand-over, behind the wait the hand-over needs anyway.
     int* const bound_thr = (KTOP == 2 && p.bound) ? p.bound + p.ncols_alloc : p.bound;
 
-    const int st0 = split * p.stages_per_split;
-    const int st1 = min(st0 + p.stages_per_split, p.nstages);
-
     // Per-lane LDS offsets of the A fragments (swizzled) and of the aux words.
     const int sw = (c16 >> 1) & 7;
     int aoff[2];
@@ -232,6 +318,33 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     constexpr int kDmaPerWave = 16 / NW;          // LDS-DMA instructions a wave issues per stage (+1 aux on the last wave)
     // SELF: the 32-row unit of the reduced bank in which this wave's own rows start
     const int own_unit = SELF ? __builtin_amdgcn_readfirstlane(cb >> 5) : 0;
+
+    // TRI: -|c|^2 of this lane's output rows (an output row beyond the bank takes part in nothing), the end of
+    // the chunk's own stages (the diagonal block: both directions come out of the row direction there), and the
+    // bound / norm words of the streamed rows two stages ahead (waves 0 and 1: one row per lane).
+    int negcn[NC];
+    int tri_b = 0, tri_n = 0;
+    const int diag_end = TRI ? (chunk + 1) * (16 * NC * NW / kStageRows) : 0;
+    if constexpr (TRI) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int n = cb + 16 * j + c16;
+            negcn[j] = (n < p.nred) ? -p.col_norm[n] : -(1 << 30);
+        }
+    }
+    // X of stage `stg`'s row (64 wave + lane) from its bound and norm words, into that stage's buffer
+    auto tri_store = [&](int stg, char* sbuf, int b, int nm) {
+        const int lane = lane_now();
+        const int rho = 64 * wave + lane;
+        int X = (b < kTriAlways) ? kTriAlways : b - nm + (nm & 1);
+        if (stg * kStageRows + rho >= p.nred || stg < diag_end || p.tri_nocol) X = kTriNever;
+        *(int*)(sbuf + kTriXRow + 4 * rho) = X;
+        // (lane exchanges addressed from `lane` above, not __shfl_xor: its lane number is hoisted out of the stage loop and spilled)
+        int m8 = min(X, __builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, X));
+        m8 = min(m8, __builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, m8));
+        m8 = min(m8, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, m8));
+        if ((lane & 19) == 0) *(int*)(sbuf + kTriX8 + 64 * (rho >> 5) + 4 * (lane & 12)) = m8;
+    };
 
     // Bounds published by the blocks that reduce other slices for the same output rows:
     // bound[n] is the K-th best hi some block has reached, so the final K-th best is
@@ -247,18 +360,35 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         gnext[j] = (p.bound && n < p.ncols_alloc)
             ? __hip_atomic_load(bound_thr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
     }
+    if constexpr (TRI) {
+        if (wave < 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (st0 + k < st1) {
+                    const int m = (st0 + k) * kStageRows + 64 * wave + lane;      // (< nred_pad: the arrays cover it)
+                    const int b = __hip_atomic_load(p.bound + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tri_store(st0 + k, smem + k * kStride, b, p.col_norm[m]);
+                }
+            }
+        }
+    }
     // prologue prefetch (issued AFTER the bound loads: vmcnt retires in order, so "at most the newest
     // stage's DMA outstanding" implies that the bound loads and every older DMA have landed)
-    if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
-    if constexpr (NBUF == 3) {
-        if (st0 + 1 < st1) issue_stage<GLDS, NW>(p, st0 + 1, smem + kStageBytes, wave, lane);
+    if constexpr (TRI) {
+        if (st0 < st1) issue_stage_u8(p, st0, smem, wave, lane, dma_lo);
+        if (st0 + 1 < st1) issue_stage_u8(p, st0 + 1, smem + kStride, wave, lane, dma_lo);
+    } else {
+        if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
+        if constexpr (NBUF == 3) {
+            if (st0 + 1 < st1) issue_stage<GLDS, NW>(p, st0 + 1, smem + kStride, wave, lane);
+        }
     }
 
     // One pipeline step on LDS buffer BUF (compile-time, so every ds_read address is
     // base register + immediate); the stage loop below is unrolled by two.
     auto stage = [&](auto buf_tag, int st) {
         constexpr int BUF = decltype(buf_tag)::value;
-        char* buf = smem + BUF * kStageBytes;
+        char* buf = smem + BUF * kStride;
         if constexpr (NBUF == 3) {
             // stage st's DMA was issued two hand-overs ago; only the DMA of stage st + 1 (the newest
             // VMEM operations of this wave, unless an exact path published a bound since) may still
@@ -273,6 +403,7 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             // behind the wait, so no use of them can be scheduled in front of it)
 #pragma unroll
             for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(gnext[j]));
+            if constexpr (TRI) { asm volatile("" : "+v"(tri_b)); asm volatile("" : "+v"(tri_n)); }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -295,7 +426,20 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             }
         }
         if constexpr (NBUF == 2) {
-            if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStageBytes, wave, lane);
+            if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStride, wave, lane);
+        }
+        if constexpr (TRI) {
+            // the words read at the previous hand-over (older than the DMA that wait left in flight) become stage
+            // st + 1's X in its buffer, which every wave left two barriers ago and the DMA fills beside it; then
+            // the words of stage st + 2 are requested, in front of its DMA
+            if (wave < 2) {
+                if (st > st0 && st + 1 < st1) tri_store(st + 1, smem + ((BUF + 1) % 3) * kStride, tri_b, tri_n);
+                if (st + 2 < st1) {
+                    const unsigned moff = (unsigned)((st + 2) * kStageRows + 64 * wave + lane_now()) * 4u;
+                    load_word_untracked_s<0>(tri_b, p.bound, moff);
+                    load_word_untracked_s<0, false>(tri_n, p.col_norm, moff);
+                }
+            }
         }
         // (a bound that is a few stages old is merely weaker; late in a sweep the bounds hardly move, and each of these loads
         // is an agent-scope read that goes past the XCD's L2: 5e6 of them per 100k x 100k pair were 3/4 of the kernel's
@@ -304,7 +448,14 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int n = cb + 16 * j + c16;
-                if constexpr (NBUF == 3) {
+                if constexpr (TRI) {
+                    static_assert(NC == 4, "immediate offsets below");
+                    const unsigned boff = (unsigned)(cb + c16) * 4u;
+                    if (j == 0) load_word_untracked_s<0>(gnext[0], p.bound, boff);
+                    if (j == 1) load_word_untracked_s<64>(gnext[1], p.bound, boff);
+                    if (j == 2) load_word_untracked_s<128>(gnext[2], p.bound, boff);
+                    if (j == 3) load_word_untracked_s<192>(gnext[3], p.bound, boff);
+                } else if constexpr (NBUF == 3) {
                     // (ncols_alloc is a multiple of the chunk, so n is always inside the array)
                     load_bound_untracked(gnext[j], bound_thr + n);
                 } else {
@@ -315,7 +466,8 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         }
         if constexpr (NBUF == 3) {
             // (after the bound loads, see the prologue) into the buffer every wave left at the barrier above
-            if (st + 2 < st1) issue_stage<GLDS, NW>(p, st + 2, smem + ((BUF + 2) % 3) * kStageBytes, wave, lane);
+            if constexpr (TRI) { if (st + 2 < st1) issue_stage_u8(p, st + 2, smem + ((BUF + 2) % 3) * kStride, wave, lane, dma_lo); }
+            else if (st + 2 < st1) issue_stage<GLDS, NW>(p, st + 2, smem + ((BUF + 2) % 3) * kStride, wave, lane);
         }
 
 #pragma unroll
@@ -361,6 +513,91 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
                 tmax[j] = max(max(max(acc[1][j][2], acc[1][j][3]), m0), m1);
                 any |= tmax[j] >= thr[j];
             }
+            if constexpr (TRI) {
+                // column direction, fast path: can any of this lane's 8 rows gain from its output row?  2 acc - |c|^2 >= X8
+                const int x8v = *(const int*)(buf + xoff + (kTriX8 - kStageRowBytes) + 64 * u);
+                bool anyc = false;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) anyc |= ((tmax[j] << 1) + negcn[j]) >= x8v;
+                if (__builtin_amdgcn_ballot_w64(any || anyc) != 0ull) {
+                    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                        const v4i low0 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 64);
+                        const v4i low1 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 128 + 64);
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) {
+                            if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
+#ifdef FM_COUNT_VISITS
+                                if (lane == 0) atomicAdd(&g_visits[0], 1ull);
+#endif
+                                // (only the value is kept: top[j].unit is dead code here)
+                                const bool improved = top[j].update(acc[0][j], acc[1][j], low0, low1, 0);
+                                const int h = top[j].key[0] >> 4;
+                                thr[j] = max(thr[j], (h + 1) >> 1);
+                                if (improved) {        // (cb + 16 j + c16 < ncols_alloc: whole chunks)
+                                    const unsigned boff = (unsigned)(cb + c16) * 4u;
+                                    if (j == 0) atomic_max_s<0>(p.bound, boff, h);
+                                    if (j == 1) atomic_max_s<64>(p.bound, boff, h);
+                                    if (j == 2) atomic_max_s<128>(p.bound, boff, h);
+                                    if (j == 3) atomic_max_s<192>(p.bound, boff, h);
+                                }
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(anyc) != 0ull) {
+                        // exact, row by row: B = 2 (acc - cinit) + 1 - |c|^2 beats bound[m] iff 2 acc - |c|^2 >= X[m]
+                        char* const xrow = buf + xoff + (kTriXRow - kStageRowBytes) + 128 * u;
+                        const v4i xr0 = *(const v4i*)xrow, xr1 = *(const v4i*)(xrow + 64);
+                        const v4i ci0 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4));
+                        const v4i ci1 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 128);
+                        const unsigned browoff = (unsigned)(st * kStageRows + 32 * u + 4 * g) * 4u;
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) {
+                            if (__builtin_amdgcn_ballot_w64(((tmax[j] << 1) + negcn[j]) >= x8v) != 0ull) {
+#ifdef FM_COUNT_VISITS
+                                if (lane == 0) atomicAdd(&g_visits[1], 1ull);
+#endif
+                                // (most visits end here: the lane's best row cleared the loosest of its 8 bounds, none its own)
+                                bool hit = false;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    hit |= ((acc[0][j][r] << 1) + negcn[j]) >= xr0[r];
+                                    hit |= ((acc[1][j][r] << 1) + negcn[j]) >= xr1[r];
+                                }
+                                if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
+                                const bool lane0 = (lane_now() & 15) == 0;
+#pragma unroll
+                                for (int sr = 0; sr < 8; ++sr) {
+                                    const int s = sr >> 2, r = sr & 3;
+                                    const int v = (acc[s][j][r] << 1) + negcn[j];
+                                    const int xr = s ? xr1[r] : xr0[r];
+                                    if (__builtin_amdgcn_ballot_w64(v >= xr) != 0ull) {
+                                        // one atomic per streamed row: the best of the 16 output rows that face it
+                                        const int best = rowmax16(v >= xr ? v : INT32_MIN);
+                                        if (lane0 && best >= xr) {
+                                            const int ci = s ? ci1[r] : ci0[r];
+                                            const int B = best - 2 * ci + 1;
+                                            switch (sr) {     // (unrolled: the offset is an immediate)
+                                            case 0: atomic_max_s<0>(p.bound, browoff, B); break;
+                                            case 1: atomic_max_s<4>(p.bound, browoff, B); break;
+                                            case 2: atomic_max_s<8>(p.bound, browoff, B); break;
+                                            case 3: atomic_max_s<12>(p.bound, browoff, B); break;
+                                            case 4: atomic_max_s<64>(p.bound, browoff, B); break;
+                                            case 5: atomic_max_s<68>(p.bound, browoff, B); break;
+                                            case 6: atomic_max_s<72>(p.bound, browoff, B); break;
+                                            default: atomic_max_s<76>(p.bound, browoff, B); break;
+                                            }
+                                            __hip_atomic_fetch_max((int*)xrow + 16 * s + r, best + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef FM_COUNT_VISITS
+                                            atomicAdd(&g_visits[2], 1ull);
+#endif
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            } else
             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
                 const v4i low0 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 64);
                 const v4i low1 = *(const v4i*)(buf + xoff + u * (kAuxPerTile * 4) + 128 + 64);
@@ -420,6 +657,8 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     if (lane == 0) atomicAdd(&g_visits[128 + (split & 127)], (unsigned long long)(st1 - st0) * 4 * NC);
 #endif
     // Merge the four lane groups (same output row, interleaved reduced rows), then emit.
+    // (TRI: every improvement went to bound[], which IS the result)
+    if constexpr (!TRI)
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         int bh[KTOP], bi[KTOP];
@@ -497,6 +736,124 @@ void rowreduce_batch_kernel(RRBatch b)
     const int pair = (int)blockIdx.x / b.blocks_per_pair;
     const RRParams p = b.p[pair];
     rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO, SELF>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+}
+
+// The triangular self sweep (see kTriNever above): one bank, or up to kRRBatchMax banks of one padded size.
+template <int PRIO>
+__global__ __launch_bounds__(64 * 8, 4)
+void rowreduce_tri_kernel(RRParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[3 * kStageBytesTri];
+    rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x, smem);
+}
+
+template <int PRIO>
+__global__ __launch_bounds__(64 * 8, 4)
+void rowreduce_tri_batch_kernel(RRBatch b)
+{
+    __shared__ __attribute__((aligned(16))) char smem[3 * kStageBytesTri];
+    const int pair = (int)blockIdx.x / b.blocks_per_pair;
+    const RRParams p = b.p[pair];
+    rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+}
+
+// Workgroups of the triangular sweep of a bank of n_pad rows, in two launches.
+//   A  every output chunk k (512 rows = 4 stages) against its own rows: the square block on the diagonal, masked.
+//      After it every row's word of bound[] holds the best of 511 candidates.
+//   B  chunk k against the stages from 4 k + 4 on, cut into pieces of S stages counted from there, piece-number
+//      major: piece i of every chunk, then piece i + 1.  The column direction of a tile only pays when the
+//      streamed rows' bounds are already good -- a row that is visited by many workgroups at once (a slice-major
+//      order: 190 visits of 512 candidates each against the same stale word) fires ~1000 atomics per row instead
+//      of a handful -- so a row's visits must be spread over the whole sweep: in this order the pieces that run
+//      together stream rows at the same DISTANCE from their chunks, i.e. different rows, and a row meets its
+//      partners in order of that distance from both directions at once.
+// S = target, or (target 0) the S in 20 .. 72 whose workgroups a list schedule on the 512 resident slots finishes first.
+static int tri_pieces(int nstages, int S, std::vector<int>* table, int* n_diag)
+{
+    const int nchunks = (nstages + 3) / 4;
+    int n = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        if (table) { table->push_back(k); table->push_back(4 * k); table->push_back(std::min(nstages, 4 * k + 4)); table->push_back(0); }
+        ++n;
+    }
+    *n_diag = n;
+    for (int i = 0; 4 + i * S < nstages; ++i)
+        for (int k = 0; k < nchunks; ++k) {
+            const int lo = 4 * k + 4 + i * S, hi = std::min(nstages, lo + S);
+            if (lo >= hi) break;                       // (later chunks are shorter still)
+            if (table) { table->push_back(k); table->push_back(lo); table->push_back(hi); table->push_back(0); }
+            ++n;
+        }
+    return n;
+}
+
+TriPlan plan_tri(int64_t n_pad, int target, std::vector<int>* table)
+{
+    TriPlan pl;
+    const int nstages = (int)(n_pad / kStageRows);
+    pl.nchunks = (nstages + 3) / 4;
+    pl.ncols_alloc = pl.nchunks * 512;
+    int S = target, nd = 0;
+    if (S <= 0) {
+        double best = 1e300;
+        std::vector<int> tb;
+        for (int c = 20; c <= 72; ++c) {
+            tb.clear();
+            const int np = tri_pieces(nstages, c, &tb, &nd);
+            // list schedule of launch B in dispatch order on 512 slots; a workgroup costs its stages + ~2 (prologue, hand-over)
+            std::vector<double> slot(512, 0.0);
+            std::make_heap(slot.begin(), slot.end(), std::greater<double>());
+            double end = 0.0;
+            for (int i = nd; i < np; ++i) {
+                std::pop_heap(slot.begin(), slot.end(), std::greater<double>());
+                const double f = slot.back() + (tb[4 * i + 2] - tb[4 * i + 1]) + 2.0;
+                slot.back() = f;
+                std::push_heap(slot.begin(), slot.end(), std::greater<double>());
+                end = f > end ? f : end;
+            }
+            if (end < best) { best = end; S = c; }
+        }
+    }
+    if (S < 4) S = 4;
+    pl.stages = S;
+    if (table) table->clear();
+    pl.npieces = tri_pieces(nstages, S, table, &pl.ndiag);
+    return pl;
+}
+
+hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& plan, int* const* bound, bool prio, hipStream_t stream)
+{
+    if (n < 1 || n > kRRBatchMax || !plan.d_table || plan.npieces < 1) return hipErrorInvalidValue;
+    RRBatch b;
+    for (int i = 0; i < n; ++i) {
+        RRParams& p = b.p[i];
+        p = RRParams{};
+        p.col_rows = banks[i]->rows8;  p.col_norm = banks[i]->norm;  p.ncols_pad = (int)banks[i]->n_pad;
+        p.red_rows = banks[i]->rows8;  p.red_aux = banks[i]->aux;    p.nred = (int)banks[i]->n;
+        p.nstages = (int)(banks[i]->n_pad / kStageRows);
+        p.nsplit = 1;  p.nchunks = plan.nchunks;  p.stages_per_split = p.nstages;  p.ncols_alloc = plan.ncols_alloc;
+        p.partial = nullptr;  p.bound = bound[i];  p.order = 0;  p.bound_mask = plan.bound_every > 1 ? plan.bound_every - 1 : 0;
+        p.tri = (const int4*)plan.d_table;
+        p.tri_nocol = getenv("FM_TRI_NOCOL") ? 1 : 0;
+    }
+    // (one instantiation, with the s_setprio around the MFMA burst: the one without it does not fit 128 VGPRs)
+    (void)prio;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
+        if (count <= 0) continue;
+        for (int i = 0; i < n; ++i) b.p[i].tri = (const int4*)plan.d_table + first;
+        if (n == 1) {
+            hipLaunchKernelGGL((rowreduce_tri_kernel<1>), dim3(count), dim3(512), 0, stream, b.p[0]);
+        } else {
+            for (int i = n; i < kRRBatchMax; ++i) b.p[i] = b.p[0];
+            b.n = n;
+            b.blocks_per_pair = count;
+            hipLaunchKernelGGL((rowreduce_tri_batch_kernel<1>), dim3(count * n), dim3(512), 0, stream, b);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
