@@ -100,6 +100,7 @@ SYMBOLS = {
     "fm_xcheck1_keys_dev": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_knn2_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
     "fm_self_dist": (_INT, [_P, _P, _P]),
+    "fm_self_dist_plan": (_INT, [_I64, _I32, _P, _I64, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "fm_xcheck1": (_INT, [_P, _P, _P, _P, _P]),
     "fm_ratio_filter": (_INT, [_P, _P, _P, _P, _I64, ctypes.c_double, _P, _P, ctypes.POINTER(_I64)]),
     "fm_match_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
@@ -178,6 +179,23 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+def self_dist_plan(n_pad, stages=0):
+    """fm_self_dist_plan (host code of the library): the workgroups of the triangular self-distance sweep of a bank
+    padded to ``n_pad`` rows -> (table int32[n, 4] = (chunk, first stage, end stage, 0), n_diag, stages_used)."""
+    lib = load_library()
+    nwg, nd, su = _I32(), _I32(), _I32()
+    rc = lib.fm_self_dist_plan(int(n_pad), int(stages), None, 0, ctypes.byref(nwg), ctypes.byref(nd), ctypes.byref(su))
+    if rc == 0:
+        table = np.empty((nwg.value, 4), dtype=np.int32)
+        rc = lib.fm_self_dist_plan(int(n_pad), int(stages), _ptr(table), nwg.value, ctypes.byref(nwg), ctypes.byref(nd), ctypes.byref(su))
+    if rc != 0:
+        msg = lib.fm_last_error(None)
+        e = FastMatchHipError("fm_self_dist_plan: %s" % (msg.decode() if msg else rc))
+        e.code = rc
+        raise e
+    return table, nd.value, su.value
 
 
 def grid_pack_cells(positions, width, height, cell_w, cell_h, rows, cols, margin):
@@ -398,7 +416,7 @@ class Context(object):
     def set_option(self, name, value):
         """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
         "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
-        "async_time_every", "k1_order", "bound_every", "refill_grid", "expand_big", "expand_huge", "expand_delegate", "expand_grow", "expand_prof".  Results never depend on them."""
+        "async_time_every", "k1_order", "bound_every", "self_tri", "tri_stages", "refill_grid", "expand_big", "expand_huge", "expand_delegate", "expand_grow", "expand_prof".  Results never depend on them."""
         self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def get_option(self, name):

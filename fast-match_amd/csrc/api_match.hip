@@ -378,6 +378,21 @@ __global__ void selfdist_tri_finish_kernel(TriFinish m)
     m.out[b][i] = (h > kTriNoBoundHost) ? (double)sqrtf((float)(unsigned)(m.norm[b][i] + 1 - h)) : (double)INFINITY;
 }
 
+extern "C" int fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table, int64_t cap, int32_t* n_workgroups,
+                                 int32_t* n_diag, int32_t* stages_used)
+{
+    if (n_pad < kStageRows || n_pad % kStageRows != 0 || n_pad > (int64_t)1 << 30 || stages < 0 || cap < 0 || (cap > 0 && !table))
+        return fail(nullptr, FM_EINVAL, "fm_self_dist_plan: n_pad must be a positive multiple of 128, stages >= 0");
+    std::vector<int> tb;
+    const TriPlan pl = plan_tri(n_pad, stages, &tb);
+    if (n_workgroups) *n_workgroups = pl.npieces;
+    if (n_diag) *n_diag = pl.ndiag;
+    if (stages_used) *stages_used = pl.stages;
+    const int64_t m = cap < pl.npieces ? cap : pl.npieces;
+    for (int64_t i = 0; i < 4 * m; ++i) table[i] = tb[(size_t)i];
+    return FM_OK;
+}
+
 // Plan + device table of the triangular sweep for banks of n_pad rows, kept per context.
 static int tri_plan_for(fm_ctx* ctx, int64_t n_pad, TriPlan* out)
 {

@@ -29,7 +29,8 @@ struct F32Params {
     int          ncols_pad;
     const float* red_rows;    // [nred_pad][128]
     int          nred;        // real rows
-    int          nsteps;      // nred_pad / 64
+    int          nsteps;      // ceil(nred_pad / 64)
+    int          nred_pad;    // rows the reduced bank's arrays hold
     int          nsplit;
     int          steps_per_split;
     int          ncols_alloc;
@@ -38,15 +39,17 @@ struct F32Params {
     int          self;        // the banks are one bank: row n is not a candidate for output row n (fm_self_dist)
 };
 
-__device__ __forceinline__ void load_tile_kmajor(const float* __restrict__ rows, int row0, float* __restrict__ img, int tid)
+__device__ __forceinline__ void load_tile_kmajor(const float* __restrict__ rows, int row0, int row_end, float* __restrict__ img, int tid)
 {
     // 64 rows x 128 floats: thread t reads float4 #(t + 256*i) of the tile (coalesced along k)
-    // and scatters it into the k-major image img[k][row].
+    // and scatters it into the k-major image img[k][row].  Rows from row_end on are not read (zeros): a VIEW into a
+    // bank -- one cell's rows from an arbitrary first row, round_xcheck_dense -- is clipped to the bank's allocation,
+    // so its padded size need not be a multiple of this tile (up to 63 rows past a hipMalloc'ed array).
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int f4 = tid + 256 * i;              // 0 .. 2047
         const int r = f4 >> 5, k4 = (f4 & 31) * 4;
-        const float4 v = *(const float4*)(rows + (size_t)(row0 + r) * kDim + k4);
+        const float4 v = (row0 + r < row_end) ? *(const float4*)(rows + (size_t)(row0 + r) * kDim + k4) : float4{0.f, 0.f, 0.f, 0.f};
         img[(k4 + 0) * kF32Ld + r] = v.x;
         img[(k4 + 1) * kF32Ld + r] = v.y;
         img[(k4 + 2) * kF32Ld + r] = v.z;
@@ -71,7 +74,7 @@ void rowreduce_f32_kernel(F32Params p)
     const int chunk = blockIdx.x / p.nsplit;
     const int c0 = chunk * kF32Tile;
 
-    if (c0 < p.ncols_pad) load_tile_kmajor(p.col_rows, c0, colimg, tid);
+    if (c0 < p.ncols_pad) load_tile_kmajor(p.col_rows, c0, p.ncols_pad, colimg, tid);
 
     float bd[4][KTOP];      // best distances per owned column (ascending)
     int   bi[4][KTOP];
@@ -87,7 +90,7 @@ void rowreduce_f32_kernel(F32Params p)
     const int s1 = min(s0 + p.steps_per_split, p.nsteps);
     for (int st = s0; st < s1; ++st) {
         __syncthreads();                                   // previous redimg fully consumed
-        load_tile_kmajor(p.red_rows, st * kF32Tile, redimg, tid);
+        load_tile_kmajor(p.red_rows, st * kF32Tile, p.nred_pad, redimg, tid);
         __syncthreads();
         float s[4][4];
 #pragma unroll
@@ -184,7 +187,7 @@ RowReducePlan plan_rowreduce_f32(int64_t ncols_pad, int64_t nred_pad, int force_
     pl.nchunks = (int)((ncols_pad + kF32Tile - 1) / kF32Tile);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * kF32Tile;
-    const int64_t nsteps = nred_pad / kF32Tile;
+    const int64_t nsteps = (nred_pad + kF32Tile - 1) / kF32Tile;
     int64_t nsplit = (4096 + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nsteps / 8) nsplit = nsteps / 8;
     if (nsplit < 1) nsplit = 1;
@@ -209,7 +212,8 @@ hipError_t launch_rowreduce_f32(const Bank& cols, const Bank& red, int ktop, con
     p.ncols_pad = (int)cols.n_pad;
     p.red_rows = red.rowsf;
     p.nred = (int)red.n;
-    p.nsteps = (int)(red.n_pad / kF32Tile);
+    p.nsteps = (int)((red.n_pad + kF32Tile - 1) / kF32Tile);
+    p.nred_pad = (int)red.n_pad;
     p.nsplit = plan.nsplit;
     p.steps_per_split = plan.stages_per_split;
     p.ncols_alloc = plan.ncols_alloc;

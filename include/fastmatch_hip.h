@@ -87,6 +87,9 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *                         contiguous share of the split-major order (the guide's XCD remap); see rowreduce.hip
  *   "bound_every"  1..1024  K1 / K2: workgroups re-read the shared K-th-best bounds at every stage of a sweep's first
  *                         eight and then at every n-th (a power of two; 16).  A stale bound is merely weaker
+ *   "self_tri"     0..2   fm_self_dist / fm_self_dist_batch on integer banks: 1 = the triangular sweep from 32768 padded rows
+ *                         on (1), 0 = always the masked full sweep, 2 = always the triangular one
+ *   "tri_stages"   0..    ... 128-row stages per workgroup of its launch B (0 = chosen per bank size: fm_self_dist_plan)
  *   "refill_grid"  1..    fm_bank_refill_u8_async: workgroups of its preparation kernel (128: few, long-lived ones beside
  *                         the distance kernels)
  *   "expand_big"   0|1    K7: re-run pairs whose round exceeds 2048 query rows in the 4096-row variant (1)
@@ -178,8 +181,17 @@ int  fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, 
  * That entry's distance is min over j != i of d(i, j): row i itself is at 0, always the first entry unless a
  * duplicate with a lower index is, and then i (or another duplicate) is the second at 0 = that minimum; only the
  * VALUE is kept, so its order among ties does not matter.  Computed as such: a top-1 sweep of the bank over
- * itself with the diagonal masked (K1's top-1 kernel, not the top-2 one).                                   */
+ * itself with the diagonal masked (K1's top-1 kernel, not the top-2 one).  r05: integer banks of >= 32768 rows
+ * take the TRIANGULAR sweep (option "self_tri"): d(i, j) = d(j, i), so every 16 x 16 tile above the diagonal is
+ * computed once and used for both of its rows' minima (rowreduce.hip, "TRI"); same values, bit for bit.        */
 int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
+/* HOST code, no context: the workgroups of that triangular sweep for a bank padded to n_pad rows (a multiple of 128)
+ * -- table[4 i .. 4 i + 3] = (output chunk of 512 rows, first 128-row stage, end stage, 0) of workgroup i, the first
+ * *n_diag of them the diagonal blocks (launch A), the rest launch B; stages == 0 lets the library choose the piece
+ * length (returned in *stages_used).  Writes min(cap, *n_workgroups) entries.  Every (chunk k, stage >= 4 k) is
+ * covered exactly once: tests/test_tri_plan.py.                                                                  */
+int  fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table /*[cap][4]*/, int64_t cap, int32_t* n_workgroups,
+                       int32_t* n_diag, int32_t* stages_used);
 /* The Metric_Cache builds of n images in one call: self distances of every bank, ATTACHED to it on the device
  * (as fm_bank_set_selfdist would, without the trip through the host); consecutive integer-route banks of one
  * padded size share a distance-kernel launch (option "batch_group").  out == NULL (or every out[i] NULL):

@@ -647,3 +647,41 @@ def test_match_many_with_integer_and_float32_pairs_in_one_call(ctx, monkeypatch)
         _same_matches(r, og(0.8))
         _same_matches(r, fastmatch.match(mc, fi, {"context": ctx})(0.8))
         assert len(r) > 20
+
+
+@pytest.mark.parametrize("f32_filter", [0, 1])
+def test_float32_delegated_round_on_the_last_cell_of_the_bank(ctx, monkeypatch, f32_filter):
+    """a delegated round's cross-check runs the float32 route on a VIEW of the target bank (one cell's
+    rows from an arbitrary first row, clipped to the bank's allocation), so the view's padded size is not a multiple
+    of the all-pairs kernel's 64-row tile: on the LAST non-empty cell K5 read up to 63 rows past the array.  A
+    RootSIFT-style pair whose keypoints crowd into the image's last cell (620 x 430: the last column and row of cells
+    are 20 and 30 px wide), all-pairs kernel alone (f32_filter 0) and behind the fp16 filter: device loop with
+    delegated rounds == host loop, nothing faults."""
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    q, t = synth.image_pair((620, 430), 9000, 9105, p=0.25)
+    rng = np.random.default_rng(9105)
+    crowd = rng.choice(9000, 6000, replace=False)
+    for side, sh in ((t, (0.0, 0.0)), (q, (-3.0, 2.0))):
+        side["positions"][crowd] = np.stack([rng.uniform(585, 619, 6000), rng.uniform(385, 429, 6000)], axis=1) + np.array(sh)
+
+    def root(d):
+        d = d.astype(np.float32)
+        return np.sqrt(d / np.maximum(d.sum(1, keepdims=True), 1)).astype(np.float32)
+
+    mc = cache.Metric_Cache.from_arrays(root(q["descriptors"]), q["positions"], q["size"], root(q["thumb_descriptors"]),
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], root(t["descriptors"]), t["thumb_positions"],
+                             root(t["thumb_descriptors"]), t["thumb_size"])
+    old = ctx.get_option("f32_filter")
+    ctx.set_option("f32_filter", f32_filter)
+    ctx.set_option("delegated_rounds", 0)
+    try:
+        ds, hs = {}, {}
+        got = fastmatch.match(mc, fi, {"context": ctx, "stats": ds})(0.8)
+        assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds
+        assert ctx.get_option("delegated_rounds") > 0
+        host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "device_loop": False})(0.8)
+    finally:
+        ctx.set_option("f32_filter", old)
+    _same_matches(got, host)
+    assert ds["rounds"] == hs["rounds"] and len(got) > 100

@@ -11,13 +11,23 @@ from kat import far_banks
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 2], ids=["masked-full-sweep", "triangular-sweep"])
+def sweep(ctx, request):
+    """Both forms of the integer route's self sweep on every case: option "self_tri" 0 = the masked full sweep,
+    2 = the triangular one whatever the size (the default, 1, takes it from 32768 padded rows on)."""
+    old = ctx.get_option("self_tri")
+    ctx.set_option("self_tri", request.param)
+    yield request.param
+    ctx.set_option("self_tri", old)
+
+
 def _eq(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 64, 65, 127, 128, 129, 511, 512, 513, 1000, 4097, 33000])
-def test_self_dist_sizes_u8(ctx, n):
+def test_self_dist_sizes_u8(ctx, sweep, n):
     """Every position of the diagonal inside a wave's two 32-row units, banks with and without padding rows,
     the 4-wave and the 8-wave kernel (33 000 rows), one row -> +inf."""
     D = synth.synth_sift(n, np.random.default_rng(n))
@@ -27,7 +37,7 @@ def test_self_dist_sizes_u8(ctx, n):
         assert np.isinf(sd[0])
 
 
-def test_self_dist_duplicates_and_zero_rows(ctx):
+def test_self_dist_duplicates_and_zero_rows(ctx, sweep):
     """A duplicate's 0 is the value, whichever index it has; all-equal banks; all-zero rows (the padding rows'
     twin: a zero row must still beat them)."""
     rng = np.random.default_rng(5)
@@ -49,7 +59,7 @@ def test_self_dist_duplicates_and_zero_rows(ctx):
     assert ctx.self_dist(ctx.bank(two)).tolist() == [3.0, 3.0]
 
 
-def test_self_dist_short_dim_and_extremes(ctx):
+def test_self_dist_short_dim_and_extremes(ctx, sweep):
     rng = np.random.default_rng(6)
     for dim in (1, 7, 64, 127):
         D = rng.integers(0, 256, (300, dim), dtype=np.uint8)
@@ -58,7 +68,7 @@ def test_self_dist_short_dim_and_extremes(ctx):
     assert _eq(ctx.self_dist(ctx.bank(D)), oracle.self_dist(D))
 
 
-def test_self_dist_in_the_sqrt_tie_range(ctx):
+def test_self_dist_in_the_sqrt_tie_range(ctx, sweep):
     """Only the VALUE is kept: sqrtf is monotone, so the smallest float32 root is the root of the smallest d2
     and no tie repair is needed -- banks whose every distance lies where two d2 share a root."""
     rng = np.random.default_rng(11)
@@ -106,7 +116,7 @@ def test_self_dist_float32_filter_forced_and_rescans(ctx):
     c.close()
 
 
-def test_self_dist_batch_attaches_and_matches(ctx):
+def test_self_dist_batch_attaches_and_matches(ctx, sweep):
     """Several Metric_Cache builds in one call: banks of one size share a launch, others (another size, float32,
     empty, one row) run beside them; the values are attached on the device (match_ratio uses them) and equal the
     oracle's."""
@@ -247,7 +257,7 @@ def test_stats_carry_algorithmic_bytes(ctx):
     assert ctx.stats()["bytes_moved"] == (3000 + 2600) * 128 + 3000 * 128
 
 
-def test_self_dist_300k_rows_against_oracle_rows(ctx):
+def test_self_dist_300k_rows_against_oracle_rows(ctx, sweep):
     """configs[2]'s bank size: 300k rows through the masked top-1 sweep; a row sample against the oracle's 2-NN of
     those rows over the whole bank, and size-independent properties for all rows."""
     rng = np.random.default_rng(300)
@@ -258,3 +268,47 @@ def test_self_dist_300k_rows_against_oracle_rows(ctx):
     rows = np.concatenate([rng.choice(300000, 300, replace=False), [0, 7, 63, 64, 123456, 299999]])
     _, od = oracle.bf_knn(D[rows], D, 2)
     assert _eq(sd[rows], od[:, 1].astype(np.float64))
+
+
+@pytest.mark.parametrize("stages", [0, 4, 9, 40])
+def test_triangular_sweep_piece_lengths_and_fuzz(ctx, stages):
+    """The triangular sweep under several piece lengths ("tri_stages") on random sizes around the chunk (512) and stage
+    (128) boundaries, duplicates and zero rows included: bit for bit the oracle's values."""
+    old = ctx.get_option("self_tri"), ctx.get_option("tri_stages")
+    ctx.set_option("self_tri", 2)
+    ctx.set_option("tri_stages", stages)
+    try:
+        rng = np.random.default_rng(500 + stages)
+        for _ in range(14):
+            n = int(rng.choice([rng.integers(1, 300), rng.integers(500, 530), rng.integers(1000, 1040), rng.integers(2040, 2600),
+                                rng.integers(5000, 9000)]))
+            D = synth.synth_sift(n, rng)
+            if n > 40:
+                D[rng.integers(0, n)] = D[rng.integers(0, n)]
+                D[rng.integers(0, n)] = 0
+            assert _eq(ctx.self_dist(ctx.bank(D)), oracle.self_dist(D)), (n, stages)
+    finally:
+        ctx.set_option("self_tri", old[0])
+        ctx.set_option("tri_stages", old[1])
+
+
+def test_default_takes_the_triangular_sweep_from_32768_rows(ctx):
+    """The default ("self_tri" 1): 70 001 rows through the triangular sweep == the masked full sweep == the oracle on a
+    row sample; each distance is computed once, the statistics still count the n x n pairs the caller asked for."""
+    assert ctx.get_option("self_tri") == 1
+    rng = np.random.default_rng(70001)
+    D = synth.synth_sift(70001, rng)
+    D[69999] = D[12]
+    b = ctx.bank(D)
+    ctx.reset_stats()
+    tri = ctx.self_dist(b)
+    assert ctx.stats()["pairs"] == 70001 * 70001
+    ctx.set_option("self_tri", 0)
+    try:
+        full = ctx.self_dist(b)
+    finally:
+        ctx.set_option("self_tri", 1)
+    assert _eq(tri, full) and tri[69999] == 0 and tri[12] == 0
+    rows = np.concatenate([rng.choice(70001, 200, replace=False), [0, 511, 512, 69999, 70000]])
+    _, od = oracle.bf_knn(D[rows], D, 2)
+    assert _eq(tri[rows], od[:, 1].astype(np.float64))

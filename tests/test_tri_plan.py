@@ -1,0 +1,47 @@
+"""CPU: the workgroup table of the triangular self-distance sweep (fm_self_dist_plan, host code of the library;
+rowreduce.hip "TRI").  Metric_Cache's self distances (cache.pyx:250-252, 271-273) need every pair (i, j), i != j,
+once: output chunk k (512 rows = 4 stages of 128) must meet every stage >= 4 k exactly once -- its own four stages
+in launch A (the masked block on the diagonal), the rest in launch B."""
+import numpy as np
+import pytest
+
+import fastmatch_amd
+from fastmatch_amd import _ffi
+
+
+@pytest.mark.parametrize("n_pad", [128, 256, 512, 640, 1024, 4224, 33024, 100096, 300032])
+@pytest.mark.parametrize("stages", [0, 4, 7, 32, 61, 5000])
+def test_every_chunk_meets_every_later_stage_once(n_pad, stages):
+    table, n_diag, used = _ffi.self_dist_plan(n_pad, stages)
+    nstages = n_pad // 128
+    nchunks = (nstages + 3) // 4
+    assert n_diag == nchunks
+    assert used >= 4 and (stages == 0 or used == max(stages, 4))
+    cover = np.zeros((nchunks, nstages), dtype=np.int32)
+    for i, (k, s0, s1, _) in enumerate(table):
+        assert 0 <= k < nchunks and 4 * k <= s0 < s1 <= nstages
+        if i < n_diag:
+            assert (k, s0, s1) == (i, 4 * i, min(nstages, 4 * i + 4))
+        else:
+            assert s0 >= 4 * k + 4 and s1 - s0 <= used
+        cover[k, s0:s1] += 1
+    want = np.arange(nstages)[None, :] >= 4 * np.arange(nchunks)[:, None]
+    assert np.array_equal(cover, want.astype(np.int32))
+
+
+def test_plan_rejects_bad_sizes():
+    for n_pad in (0, 100, -128):
+        with pytest.raises(fastmatch_amd.FastMatchHipError):
+            _ffi.self_dist_plan(n_pad)
+
+
+def test_chosen_piece_length_fills_the_chip():
+    """stages = 0: launch B's workgroups, list-scheduled on the 512 resident slots, leave no long tail."""
+    table, n_diag, used = _ffi.self_dist_plan(100096, 0)
+    lens = (table[n_diag:, 2] - table[n_diag:, 1]).astype(np.float64) + 2.0
+    slots = np.zeros(512)
+    for L in lens:
+        i = int(np.argmin(slots))
+        slots[i] += L
+    assert 20 <= used <= 72
+    assert slots.max() <= 1.12 * lens.sum() / 512
