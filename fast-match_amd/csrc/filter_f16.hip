@@ -262,16 +262,14 @@ void filter_kernel(FParams p)
                         // (r04: the eight wave-wide tests first, back to back, as scalar masks -- the loop below then branches
                         // on SGPRs.  Written as "compare, ballot, branch" per row the compiler emitted v_cmp -> vcc ->
                         // s_cbranch_vccz eight times in a row, every branch waiting for the vector compare in front of it.)
+                        // (r05, tried and dropped: when the eight masks are disjoint -- scalar popcounts -- ONE straight-line
+                        // insertion of the lane's unit maximum instead of this loop: 2.82 -> 2.86-2.89 ms on one box,
+                        // profiles/r05b_k8_single_insertion_ab.log.  The branches are not what a visit costs.)
                         unsigned long long wm[8];
-#ifndef FM_K8_OLD_VISIT
 #pragma unroll
                         for (int r = 0; r < 8; ++r) wm[r] = __builtin_amdgcn_ballot_w64(acc[r >> 2][j][r & 3] >= thr[j]);
-#endif
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {                   // ascending row order
-#ifdef FM_K8_OLD_VISIT
-                            wm[r] = __builtin_amdgcn_ballot_w64(acc[r >> 2][j][r & 3] >= thr[j]);      // (A/B builds only: r01 - r03's form)
-#endif
                             if (wm[r] == 0ull) continue;
                             const float av = acc[r >> 2][j][r & 3];
                             const bool want = av >= thr[j];
