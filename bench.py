@@ -91,9 +91,47 @@ def cpu_baseline_simd(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_SIMD_BUD
     t0 = time.perf_counter()
     oracle.bf_xcheck1_simd(Q[:s], T, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": s * len(T) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "oracle bf_xcheck1_simd (C, AVX2 vpmaddwd, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s"
-                      % (s, len(Q), len(T), dt)}
+    value = s * len(T) / dt
+    # what the host could do at best with this instruction: 2 vpmaddwd (16 int16 products each) per cycle and PHYSICAL core
+    # = 32 multiply-adds of the 128 a descriptor pair takes, i.e. 0.25 pairs per cycle and core
+    phys, ghz = host_cores_and_ghz(threads)
+    peak = phys * ghz * 1e9 * 32.0 / 128.0
+    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "physical_cores": phys, "ghz": ghz, "host_vpmaddwd_peak_pairs_per_s": peak, "frac_of_host_peak": value / peak,
+            "sample": "oracle bf_xcheck1_simd (C, AVX2 vpmaddwd, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s; "
+                      "= %.1f %% of this host's vpmaddwd peak (%d physical cores x %.2f GHz x 32 multiply-adds per cycle / 128 per pair): "
+                      "one target row streams past eight query rows per pass, a horizontal sum and a scalar compare per pair -- a "
+                      "cache-blocked kernel with vector compares would run several times faster, so the GPU / CPU ratio from this "
+                      "figure still flatters the GPU; the fraction of the MFMA roof is the number that counts"
+                      % (s, len(Q), len(T), dt, 100.0 * value / peak, phys, ghz)}
+
+
+def host_cores_and_ghz(threads):
+    """(physical cores, nominal GHz) of this host from /proc/cpuinfo; (threads, 2.0) where that cannot be read."""
+    try:
+        txt = open("/proc/cpuinfo").read()
+        cores = set()
+        phys_id = core_id = None
+        mhz = []
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "physical id":
+                phys_id = v
+            elif k == "core id":
+                core_id = v
+            elif k == "cpu MHz":
+                mhz.append(float(v))
+            elif k == "" and phys_id is not None and core_id is not None:
+                cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        if phys_id is not None and core_id is not None:
+            cores.add((phys_id, core_id))
+        m = __import__("re").search(r"@\s*([0-9.]+)\s*GHz", txt)
+        ghz = float(m.group(1)) if m else (max(mhz) / 1000.0 if mhz else 2.0)
+        return (min(len(cores), threads) if cores else threads), ghz
+    except Exception:
+        return threads, 2.0
 
 
 def verify_against_oracle(ctx, Q, T, selfdist, keep, timed_rows, pair0):
@@ -121,9 +159,15 @@ def verify_against_oracle(ctx, Q, T, selfdist, keep, timed_rows, pair0):
 
 def derived_pair(Q, T, j, rng):
     """Pair j of the batch: rows of pair 0 permuted and the 128 dimensions rolled by 8 j --
-    different banks in memory, the same distribution of distances and accepted matches."""
+    different banks in memory, the same distribution of distances and accepted matches.  The LAST pair of a batch is
+    drawn independently from ANOTHER distribution (a batch of twelve twins cannot show a cost tuned to
+    one distribution): 55 % planted rows instead of 30 %, noise sigma 10 instead of 6."""
     if j == 0:
         return Q, T
+    if j == PAIRS_PER_STEP - 1:
+        from fastmatch_amd import synth
+        Qi, Ti, _ = synth.planted_pair(len(Q), len(T), seed=SEED + 7777 + j, p=0.55, sigma=10.0)
+        return Qi, Ti
     pq, pt = rng.permutation(len(Q)), rng.permutation(len(T))
     return np.ascontiguousarray(np.roll(Q[pq], 8 * j, axis=1)), np.ascontiguousarray(np.roll(T[pt], 8 * j, axis=1))
 
@@ -504,19 +548,17 @@ def main():
     dev = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
     legs = not args.no_legs
 
-    # Steps are pipelined two deep by default (FM_BENCH_PIPELINE=0: one fm_sync per step): step i + 1 is
-    # enqueued before the host waits for step i (fm_mark / fm_wait, two output sets), so a step's twelve pairs
-    # can share ONE distance-kernel launch -- its small kernels run beside the next step's launch.  Without
-    # the pipeline the library ends a run of pairs with a short launch instead (8 + 2).
-    pipelined = os.environ.get("FM_BENCH_PIPELINE", "1") != "0" and os.environ.get("FM_BENCH_SYNC") != "1"
+    # Steps are pipelined two deep: step i + 1 is enqueued before the host waits for step i (fm_mark / fm_wait, two
+    # output sets), so a step's twelve pairs share ONE distance-kernel launch -- its small kernels run beside the next
+    # step's launch.  (r05: the per-pair, blocking and unpipelined step variants of r02 - r04 are gone; their A/Bs are
+    # in DESIGN.md section 6.)
     import fastmatch_amd
     from fastmatch_amd import synth, sharding
     ctx = fastmatch_amd.Context(local_rank)
-    if pipelined:                                           # the whole step in one launch (fm_ctx_set_option)
-        if "FM_BATCH_GROUP" not in os.environ:
-            ctx.set_option("batch_group", 16)
-        if "FM_BATCH_TAIL" not in os.environ:
-            ctx.set_option("batch_tail", 0)
+    if "FM_BATCH_GROUP" not in os.environ:                  # the whole step in one launch (fm_ctx_set_option)
+        ctx.set_option("batch_group", 16)
+    if "FM_BATCH_TAIL" not in os.environ:
+        ctx.set_option("batch_tail", 0)
 
     # the batch of independent pairs of this rank, resident in HBM before the timed region
     Q, T, planted = synth.planted_pair(NQ, NT, seed=SEED + rank)
@@ -539,61 +581,41 @@ def main():
         banks.append((qb, tb))
         del Qj, Tj
 
-    # N = 1: caller-owned output buffers in page-locked memory, one set per pair of the batch: the
-    # compaction kernel writes them directly and the pairs of a step are enqueued back to back
-    # (fm_match_accepted_async), one synchronisation per step
-    outbufs = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
-                ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64)) for _ in range(PAIRS_PER_STEP)]
-    counts = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
+    # N = 1: caller-owned output buffers in page-locked memory, one set per pair of the batch and pipeline slot: the
+    # compaction kernel writes them directly (fm_match_accepted_batch), the host reads step i while step i + 1 runs
+    use_async = world == 1
+    outbufs_sets, counts_sets, batch_sets = [], [], []
+    if world == 1:
+        for _ in range(2):
+            ob = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
+                   ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64)) for _ in range(PAIRS_PER_STEP)]
+            cn = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
+            outbufs_sets.append(ob)
+            counts_sets.append(cn)
+            batch_sets.append(ctx.prepare_batch(banks, ob, cn))
+    outbufs = outbufs_sets[0] if world == 1 else [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
+                                                  ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64))]
     outbuf = outbufs[0]
-    use_async = world == 1 and os.environ.get("FM_BENCH_SYNC") != "1"
-    dev_async = world > 1 and os.environ.get("FM_BENCH_SYNC") != "1"
-    use_batch = use_async and os.environ.get("FM_BENCH_BATCH", "1") != "0"
-    batch_args = ctx.prepare_batch(banks, outbufs, counts) if use_batch else None
-    counts_sets, batch_sets = [counts], [batch_args]
-    if use_batch and pipelined:                             # second output set for the two-deep pipeline
-        outbufs2 = [(ctx.pinned_empty(NQ, np.int32), ctx.pinned_empty(NQ, np.int32),
-                     ctx.pinned_empty(NQ, np.float32), ctx.pinned_empty(NQ, np.float64)) for _ in range(PAIRS_PER_STEP)]
-        counts2 = [ctx.pinned_empty(1, np.int64) for _ in range(PAIRS_PER_STEP)]
-        counts_sets.append(counts2)
-        batch_sets.append(ctx.prepare_batch(banks, outbufs2, counts2))
 
-    # N > 1: the all-gather of pair i's accepted matches (RCCL, its own stream) overlaps the
-    # matching kernels of pair i+1 (the library's stream); the last one is waited for inside
-    # the timed region.  On GPUs the rows never leave HBM (fm_match_accepted_dev).
-    # Default (FM_BENCH_BATCH unset): the pairs of a step share distance-kernel launches
-    # (fm_match_accepted_dev_batch) and ONE all-gather ships the step's rows, overlapping the next step.
-    step_gather = (world > 1 and os.environ.get("FM_BENCH_SYNC") != "1" and os.environ.get("FM_BENCH_BATCH", "1") != "0"
-                   and os.environ.get("FM_BENCH_HOST_GATHER") != "1" and os.environ.get("FM_BENCH_GATHER") != "rccl")
-    # FM_BENCH_GATHER=counted: counts first, then only the rows that are there (a third of the bytes, one host wait
-    # per step; sharding.MatchGatherer two_phase) -- for the day the padded all-gather shows in the 8-GPU curve
-    gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank),
-                                      pairs_per_step=PAIRS_PER_STEP if step_gather else 1,
-                                      two_phase=os.environ.get("FM_BENCH_GATHER") == "counted") if world > 1 else None
-    device_gather = gatherer is not None and os.environ.get("FM_BENCH_HOST_GATHER") != "1"
-    pair_args = ctx.prepare_pairs(banks) if step_gather else None
-    h_counts = ctx.pinned_empty(PAIRS_PER_STEP, np.int64)
-    h_counts_sets = [h_counts, ctx.pinned_empty(PAIRS_PER_STEP, np.int64)]
-    # FM_BENCH_GATHER=rccl: the library's own all-gather (fm_comm_init / fm_gather_matches, RCCL on the
-    # matching stream) instead of torch.distributed's; the id travels by a torch broadcast
-    abi_gather = None
-    if world > 1 and backend == "nccl" and os.environ.get("FM_BENCH_GATHER") == "rccl":
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
-        cdev = torch.device("cuda", local_rank)
-        abi_gather = {"rows": torch.zeros((NQ, 3), dtype=torch.int32, device=cdev),
-                      "count": torch.zeros(1, dtype=torch.int64, device=cdev),
-                      "all_rows": torch.zeros((world, NQ, 3), dtype=torch.int32, device=cdev),
-                      "all_counts": torch.zeros(world, dtype=torch.int64, device=cdev)}
-        gatherer = None
+    # N > 1 (BASELINE.json: "RCCL over xGMI only for result gather"): the rows never leave HBM -- the step's pairs share
+    # distance-kernel launches (fm_match_accepted_dev_batch writes every pair's accepted rows into the gatherer's send
+    # buffer) and ONE all-gather per step ships them on a stream of its own, beside the next step's kernels.
+    #   default               padded: every rank ships PAIRS_PER_STEP x NQ row slots, no host wait
+    #   FM_BENCH_GATHER=counted   counts first, then only the rows that are there (a third of the bytes, one host wait per
+    #                         step; sharding.MatchGatherer two_phase) -- the tested alternative, for the day the padded
+    #                         all-gather shows in the 8-GPU curve
+    gather_mode = "counted" if os.environ.get("FM_BENCH_GATHER") == "counted" else "padded"
+    gatherer = sharding.MatchGatherer(dev, capacity=NQ, fill_device=torch.device("cuda", local_rank), pairs_per_step=PAIRS_PER_STEP,
+                                      two_phase=gather_mode == "counted") if world > 1 else None
+    pair_args = ctx.prepare_pairs(banks) if world > 1 else None
+    h_counts_sets = [ctx.pinned_empty(PAIRS_PER_STEP, np.int64), ctx.pinned_empty(PAIRS_PER_STEP, np.int64)]
 
     pipe = {"i": 0, "prev": None, "last": 0}
 
     def consume(prev):                                      # the host reads step i's results while step i + 1 runs
         s, ticket = prev
         ctx.wait(ticket)
-        if use_async:
+        if world == 1:
             return int(sum(int(c[0]) for c in counts_sets[s]))
         return int(h_counts_sets[s].sum())
 
@@ -603,70 +625,24 @@ def main():
             pipe["prev"] = None
         return pipe["last"]
 
-    def step():
-        n_acc = 0
-        if pipelined and (use_batch or step_gather):
-            s = pipe["i"] % 2
-            pipe["i"] += 1
-            if use_batch:
-                ctx.match_accepted_batch(batch_sets[s], TAU)
-            else:
-                rows, cnts = gatherer.send_buffers()
-                ctx.match_accepted_dev_batch(pair_args, TAU, rows.data_ptr(), cnts.data_ptr(), NQ, h_counts=h_counts_sets[s],
-                                             consumer_stream=gatherer.consumer_stream())
-                gatherer.submit_device()
-            ticket = ctx.mark()
-            if pipe["prev"] is not None:
-                pipe["last"] = consume(pipe["prev"])
-            pipe["prev"] = (s, ticket)
-            return pipe["last"]
-        if use_async:
-            if use_batch:                                   # pairs of one shape share distance-kernel launches
-                ctx.match_accepted_batch(batch_args, TAU)
-            else:
-                for j, (qb, tb) in enumerate(banks):
-                    ctx.match_accepted_async(qb, tb, TAU, outbufs[j], counts[j])
-            ctx.sync()                                      # results of the whole batch are on the host now
-            return int(sum(int(c[0]) for c in counts))
-        if step_gather:
+    def step(gather=True):
+        """One pass of the hot path over this rank's batch; gather=False (N > 1, measurement only): the same kernels
+        without the all-gather, for `collective.gather_exposed_ms`."""
+        s = pipe["i"] % 2
+        pipe["i"] += 1
+        if world == 1:
+            ctx.match_accepted_batch(batch_sets[s], TAU)
+        else:
             rows, cnts = gatherer.send_buffers()
-            ctx.match_accepted_dev_batch(pair_args, TAU, rows.data_ptr(), cnts.data_ptr(), NQ, h_counts=h_counts,
+            ctx.match_accepted_dev_batch(pair_args, TAU, rows.data_ptr(), cnts.data_ptr(), NQ, h_counts=h_counts_sets[s],
                                          consumer_stream=gatherer.consumer_stream())
-            gatherer.submit_device()
-            ctx.sync()
-            return int(h_counts.sum())
-        if dev_async and (abi_gather is not None or device_gather):
-            # no host synchronisation between pairs: K1 launches back to back on the library's stream,
-            # each pair's small kernels + its all-gather beside the next pair's K1
-            for j, (qb, tb) in enumerate(banks):
-                if abi_gather is not None:
-                    g = abi_gather
-                    ctx.match_accepted_dev_async(qb, tb, TAU, g["rows"].data_ptr(), g["count"].data_ptr(), NQ, h_count=counts[j])
-                    ctx.gather_matches(g["rows"].data_ptr(), g["count"].data_ptr(), NQ, g["all_rows"].data_ptr(),
-                                       g["all_counts"].data_ptr(), wait=False)
-                else:
-                    rows, count = gatherer.send_buffers()
-                    ctx.match_accepted_dev_async(qb, tb, TAU, rows.data_ptr(), count.data_ptr(), NQ, h_count=counts[j],
-                                                 consumer_stream=gatherer.consumer_stream())
-                    gatherer.submit_device()
-            ctx.sync()
-            return int(sum(int(c[0]) for c in counts))
-        for qb, tb in banks:
-            if abi_gather is not None:
-                g = abi_gather
-                n_acc += ctx.match_accepted_dev(qb, tb, TAU, g["rows"].data_ptr(), g["count"].data_ptr(), NQ)
-                ctx.gather_matches(g["rows"].data_ptr(), g["count"].data_ptr(), NQ, g["all_rows"].data_ptr(),
-                                   g["all_counts"].data_ptr(), wait=False)
-            elif device_gather:
-                rows, count = gatherer.send_buffers()
-                n_acc += ctx.match_accepted_dev(qb, tb, TAU, rows.data_ptr(), count.data_ptr(), NQ)
+            if gather:
                 gatherer.submit_device()
-            else:
-                q_acc, t_acc, d_acc, r_acc = ctx.match_accepted(qb, tb, TAU, out=outbuf)
-                n_acc += len(q_acc)
-                if gatherer is not None:
-                    gatherer.submit(sharding.pack_matches(q_acc, t_acc, d_acc))
-        return n_acc
+        ticket = ctx.mark()
+        if pipe["prev"] is not None:
+            pipe["last"] = consume(pipe["prev"])
+        pipe["prev"] = (s, ticket)
+        return pipe["last"]
 
     def barrier():
         if world > 1:
@@ -685,12 +661,9 @@ def main():
     npass = 0
     for _ in range(args.steps):
         npass = step()
-    if pipelined and (use_batch or step_gather):
-        npass = finish_steps()                              # the last step's results, still inside the timed region
+    npass = finish_steps()                                  # the last step's results, still inside the timed region
     if gatherer is not None:
         gatherer.finish()
-    if abi_gather is not None:
-        ctx.sync()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -704,6 +677,41 @@ def main():
     else:
         npass_all = npass
     st = ctx.stats()
+    # N > 1: what the collective is and what it costs, so that a 1 -> 8 curve explains itself.  Measured once, OUTSIDE
+    # the timed region: the same steps with and without the all-gather (same kernels, same pipeline).
+    collective = None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ksteps = max(2, min(args.steps, 6))
+
+        def timed_steps(gather):
+            barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(ksteps):
+                step(gather)
+            finish_steps()
+            if gather:
+                gatherer.finish()
+            torch.cuda.synchronize()
+            barrier()
+            return (time.perf_counter() - t) / ksteps
+
+        with_g, without_g = timed_steps(True), timed_steps(False)
+        tt = torch.tensor([with_g, without_g], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        collective = {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend), "world_size": world,
+                      "ranks_seen": int(ones.item()), "gather": gather_mode, "collectives_per_step": 1 if gather_mode == "padded" else 2,
+                      "rows_per_rank_per_step": int(gatherer.rows_shipped),
+                      "bytes_per_rank_per_step": int(gatherer.rows_shipped) * 12 + PAIRS_PER_STEP * 8,
+                      "bytes_received_per_rank_per_step": (world - 1) * (int(gatherer.rows_shipped) * 12 + PAIRS_PER_STEP * 8),
+                      "step_ms_with_gather": 1e3 * float(tt[0].item()), "step_ms_without_gather": 1e3 * float(tt[1].item()),
+                      "gather_exposed_ms": 1e3 * float(tt[0].item() - tt[1].item()),
+                      "note": "one all-gather of every rank's accepted rows (int32 query, train, distance bits) + counts per step, on "
+                              "a stream of its own beside the next step's kernels; exposed = step wall with - without it, max over "
+                              "ranks, %d steps each, measured after the timed region" % ksteps}
+    per_pair_counts = ([int(c[0]) for c in counts_sets[0]] if world == 1 else [int(c) for c in h_counts_sets[0]])
     qb, tb = banks[0]
     # pair 0's accepted rows as the timed batch left them (output set 0), kept for the self-check below
     timed_rows0 = None
@@ -873,16 +881,18 @@ def main():
                                    "SIFT descriptors, brute-force cross-checked 1-NN + ratio 0.7 (BASELINE.json configs[1])"
                                    % (PAIRS_PER_STEP, NQ // 1000, NT // 1000),
                        "nq": NQ, "nt": NT, "dim": 128, "tau": TAU, "pairs_per_gpu": PAIRS_PER_STEP,
-                       "parallelism": "independent image pairs sharded over GPUs; RCCL all-gather of accepted matches"
-                                      + (" (fm_gather_matches, C-ABI)" if abi_gather is not None else
-                                         " from device buffers" if device_gather else "")},
+                       "parallelism": "independent image pairs sharded over GPUs; RCCL all-gather of accepted matches from device buffers"},
             "matches_per_s": npass_all * args.steps / elapsed,
             "accepted_matches_per_step": npass_all,
+            "accepted_matches_pair0": per_pair_counts[0],
+            "accepted_matches_independent_pair": per_pair_counts[-1] if PAIRS_PER_STEP > 1 else None,
+            "batch_note": "pairs 1 .. n-2 of a rank's batch are row permutations + dimension rolls of pair 0 (same distance "
+                          "distribution, other addresses); the last pair is drawn independently with 55 % planted rows and noise "
+                          "sigma 10 (pair 0: 30 %, sigma 6): its accepted count stands beside pair 0's",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS,
                          "unit": "TOP/s", "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_tag": traffic_tag, "traffic_note": traffic_note,
-                         "kernel": ("fm::rowreduce_batch_kernel<4,1,8,3,1>" if (use_batch or step_gather) else "fm::rowreduce_kernel<4,1,true,8,3,1>")
-                                   + " (v_mfma_i32_16x16x64_i8)",
+                         "kernel": "fm::rowreduce_batch_kernel<4,1,8,3,1> (v_mfma_i32_16x16x64_i8)",
                          "kernel_ms": k_ms, "kernel_ms_per_launch": k_ms * pairs_per_launch,
                          "image_pairs_per_launch": pairs_per_launch,
                          "kernel_launches_timed": st["kernel_launches"],
@@ -898,6 +908,7 @@ def main():
                                  "library's own stream) per image pair, kernel_ms_per_launch = per launch; traffic / hbm_gbps = PMC HBM bytes "
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
                                  "cycles of the launch (profiles/)"},
+            "collective": collective,
             "self_2nn": self2,
             "classic_ratio_match": crm,
             "single_pair": single,

@@ -56,7 +56,8 @@ class fm_expand_desc(ctypes.Structure):
 
 EXPAND_STATUS = {0: "ok", 1: "pending stack full", 2: "a radius subset the device could not take (see FM_EXPAND_SUBSET_FULL)",
                  3: "target position outside the image", 4: "result list full", 5: "hash table full",
-                 6: "float32 round: candidate list full", 7: "lazy target: a cell is wanted"}
+                 6: "float32 round: candidate list full", 7: "lazy target: a cell is wanted", 9: "per-round log full"}
+FM_EXPAND_NEED_CELL = 7     # include/fastmatch_hip.h
 
 # name -> (restype, argtypes); every symbol include/fastmatch_hip.h declares
 _P = ctypes.c_void_p
@@ -120,6 +121,9 @@ SYMBOLS = {
     "fm_expand_fetch": (_INT, [_P, _P, _I64, _P, _P, _P]),
     "fm_expand_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int32)]),
     "fm_expand_trim": (_INT, [_P, _P, ctypes.c_int32]),
+    "fm_expand_set_log": (_INT, [_P, _P, ctypes.c_int32]),
+    "fm_expand_log_counts": (_INT, [_P, _P, ctypes.c_int32, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "fm_expand_fetch_log": (_INT, [_P, _P, ctypes.c_int32, _I64, _I64, _P, _P, _P, _P]),
     "fm_mem_info": (_INT, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "fm_comm_unique_id": (_INT, [_P]),
     "fm_comm_init": (_INT, [_P, _INT, _INT, _P]),
@@ -330,12 +334,50 @@ class Expander(object):
         ctx._check(ctx.lib.fm_expand_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
         self.handle = h
         self._banks = (q_bank, t_bank)            # the banks must outlive the expander
+        # host copies of the positions the log's records are rebuilt from (fetch_log)
+        self.q_pos = q_pos
+        self.t_pos = t_pos
+        self._lazy_pos = {}                       # lazy targets: first row -> positions of the cell added there
+        self.logging = False
+
+    def set_log(self, enable=True, first_capacity=0):
+        """Runs of this pair record the reference's per-round log on the device (fm_expand_set_log);
+        ``first_capacity`` > 1: the log arrays start that small (they grow fourfold when a run fills them)."""
+        if bool(enable) != self.logging or first_capacity > 1:
+            self.ctx._check(self.ctx.lib.fm_expand_set_log(self.ctx.handle, self.handle,
+                                                           int(first_capacity) if enable and first_capacity > 1 else (1 if enable else 0)))
+            self.logging = bool(enable)
+
+    def fetch_log(self, slot=0):
+        """The log of the last run in ``slot``: (query_pos f64[n, 2], target_pos f64[n, 2], cell i64[n], n_accepted i64[n]
+        (-1: the cell had no features), query_row i32[m], target_row i32[m], ratio f64[m]) -- rounds in order, the accepted
+        matches of all rounds back to back."""
+        nr, ne = _I64(0), _I64(0)
+        self.ctx._check(self.ctx.lib.fm_expand_log_counts(self.ctx.handle, self.handle, int(slot), ctypes.byref(nr), ctypes.byref(ne)))
+        rounds = np.empty((nr.value, 6), dtype=np.int64)
+        q, t, ratio = np.empty(ne.value, dtype=np.int32), np.empty(ne.value, dtype=np.int32), np.empty(ne.value, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.fm_expand_fetch_log(self.ctx.handle, self.handle, int(slot), nr.value, ne.value,
+                                                         _ptr(rounds), _ptr(q), _ptr(t), _ptr(ratio)))
+        pos = np.ascontiguousarray(rounds[:, :4]).view(np.float64)
+        return pos[:, 0:2], pos[:, 2:4], rounds[:, 4].copy(), rounds[:, 5].copy(), q, t, ratio
+
+    def target_positions(self):
+        """Full-image positions of the target bank's rows (lazy targets: of the cells added so far)."""
+        if not self.lazy:
+            return self.t_pos
+        n = max([r + len(p) for r, p in self._lazy_pos.items()] + [0])
+        out = np.zeros((n, 2), dtype=np.float64)
+        for r, p in self._lazy_pos.items():
+            out[r:r + len(p)] = p
+        return out
 
     def set_cell(self, cell, first_row, positions):
         """Register a computed cell of a lazy target: rows [first_row, first_row + len(positions)) of the target bank."""
         pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 2)
         self.ctx._check(self.ctx.lib.fm_expand_set_cell(self.ctx.handle, self.handle, int(cell), int(first_row), pos.shape[0],
                                                         _ptr(pos) if pos.shape[0] else None))
+        if pos.shape[0]:
+            self._lazy_pos[int(first_row)] = pos
 
     def run_lazy(self, seeds, tau, resume):
         """One launch of a lazy pair: (n_matches, n_rounds, n_pairs, status, need_cell); status 7 = compute ``need_cell``

@@ -30,6 +30,9 @@ struct ExpandRun {
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0, found_cap = 0;
     // huge tier: the tables of a round whose radius subset does not fit LDS (created when a run first needs them)
     void* huge = nullptr;          // h_cand i32[nq] | h_qbest u64[nq] | h_tbest u64[largest cell] | h_ucand i32[nq] | h_pkey u64[nq]
+    // per-round log (fm_expand_set_log): round records | query rows | target rows | ratios; grown fourfold on FM_EXPAND_LOG_FULL
+    void* logb = nullptr;
+    int64_t lg_round_cap = 0, lg_entry_cap = 0;
 };
 
 struct fm_expand {
@@ -47,6 +50,12 @@ struct fm_expand {
     int64_t ncells = 0, t_cap = 0;
     double* d_tpos = nullptr;      // (inside blob) [t_cap][2]
     int64_t match_cap = 0, stack_cap = 0, seen_cap = 0;       // defaults of a new run state
+    bool want_log = false;         // fm_expand_set_log: the runs of this pair write the per-round log
+    int64_t log_cap0 = 0;          // ... first capacity of both log arrays (0 = the defaults below)
+    // fm_expand_run_lazy: slot 0 is parked at a missing cell (the last launch ended with FM_EXPAND_NEED_CELL) and may be resumed;
+    // the seeds of the run that parked (a resume re-uses them: they are on the device)
+    bool parked = false;
+    int64_t parked_seeds = 0;
     std::vector<ExpandRun> runs;   // run slot k = the k-th run of this pair inside one launch
 };
 
@@ -58,6 +67,7 @@ static void expand_run_free(ExpandRun& r)
     if (r.blob) (void)hipFree(r.blob);
     if (r.d_seeds) (void)hipFree(r.d_seeds);
     if (r.huge) (void)hipFree(r.huge);
+    if (r.logb) (void)hipFree(r.logb);
     r = ExpandRun{};
 }
 
@@ -71,7 +81,7 @@ static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
     // (seen and found are neighbours: one fill resets both)
     const size_t o_stack = carve((size_t)r.stack_cap * 32), o_seen = carve((size_t)r.seen_cap * 8), o_found = carve((size_t)r.found_cap * 16);
     const size_t o_mi = carve((size_t)r.match_cap * 4), o_mp = carve((size_t)r.match_cap * 32), o_mr = carve((size_t)r.match_cap * 8);
-    const size_t o_res = carve(256), o_resume = carve(256);
+    const size_t o_res = carve((size_t)kExpResultWords * 8), o_resume = carve(256);
     hipError_t e = hipMalloc(&r.blob, off);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -83,6 +93,20 @@ static int expand_run_alloc(fm_ctx* ctx, ExpandRun& r)
     r.m_index = (int32_t*)(b + o_mi); r.m_pos = (double*)(b + o_mp); r.m_ratio = (double*)(b + o_mr);
     r.result = (long long*)(b + o_res);
     r.resume_state = (long long*)(b + o_resume);
+    // (a resume flag without a parked run is refused on the host; the words are defined all the same)
+    if (hipMemsetAsync(b + o_res, 0, (size_t)kExpResultWords * 8 + 256, ctx->stream) != hipSuccess) (void)hipGetLastError();
+    return FM_OK;
+}
+
+// The log arrays of a run state (created with the state's current capacities; 0 = the pair's defaults).
+static int expand_run_log(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
+{
+    if (!ex->want_log || r.logb) return FM_OK;
+    if (r.lg_round_cap <= 0) r.lg_round_cap = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(4096, 4 * ex->ncells);
+    if (r.lg_entry_cap <= 0) r.lg_entry_cap = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(65536, 4 * ex->nq);
+    const size_t bytes = al256((size_t)r.lg_round_cap * 48) + al256((size_t)r.lg_entry_cap * 4) * 2 + al256((size_t)r.lg_entry_cap * 8);
+    hipError_t e = hipMalloc(&r.logb, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); r.logb = nullptr; return fail(ctx, FM_ENOMEM, std::string("fm_expand: log arrays: ") + hipGetErrorString(e)); }
     return FM_OK;
 }
 
@@ -129,6 +153,25 @@ static void expand_bind_run(ExpandPair& P, const ExpandRun& r, const fm_expand* 
     P.m_index = r.m_index; P.m_pos = r.m_pos; P.m_ratio = r.m_ratio; P.match_cap = r.match_cap;
     P.result = r.result;
     P.resume_state = r.resume_state;
+    P.lg_round = nullptr; P.lg_q = nullptr; P.lg_t = nullptr; P.lg_ratio = nullptr; P.lg_round_cap = 0; P.lg_entry_cap = 0;
+    if (r.logb) {
+        char* lb = (char*)r.logb;
+        P.lg_round = (long long*)lb;
+        P.lg_q = (int32_t*)(lb + al256((size_t)r.lg_round_cap * 48));
+        P.lg_t = (int32_t*)(lb + al256((size_t)r.lg_round_cap * 48) + al256((size_t)r.lg_entry_cap * 4));
+        P.lg_ratio = (double*)(lb + al256((size_t)r.lg_round_cap * 48) + 2 * al256((size_t)r.lg_entry_cap * 4));
+        P.lg_round_cap = r.lg_round_cap; P.lg_entry_cap = r.lg_entry_cap;
+    }
+}
+
+// A run that ended with FM_EXPAND_LOG_FULL gets log arrays four times as large (both: which one filled is not told).
+static int expand_log_grow(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
+{
+    const int64_t limit = (int64_t)1 << 28;
+    if (r.lg_entry_cap >= limit || r.lg_round_cap >= limit) return FM_ENOMEM;
+    if (r.logb) { (void)hipFree(r.logb); r.logb = nullptr; }
+    r.lg_round_cap *= 4; r.lg_entry_cap *= 4;
+    return expand_run_log(ctx, ex, r);
 }
 
 extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
@@ -269,11 +312,16 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
 {
     if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: NULL argument");
     if (!ex->lazy) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: the pair was not created with lazy targets");
-    if (n_seeds < 0 || (n_seeds > 0 && !seeds)) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: bad seeds");
+    if (n_seeds < 0 || (n_seeds > 0 && !seeds && !resume)) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: bad seeds");
+    //  a resume restores the loop state the LAST launch saved: only a run that parked at a missing cell has one
+    if (resume && !ex->parked) return fail(ctx, FM_EINVAL, "fm_expand_run_lazy: resume without a parked run (the last launch did not end with FM_EXPAND_NEED_CELL)");
+    if (resume) n_seeds = ex->parked_seeds;          // (they are on the device since the run began)
+    ex->parked = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = expand_ensure_run(ctx, ex, 0);
     if (rc != FM_OK) return rc;
     ExpandRun* r = &ex->runs[0];
+    if ((rc = expand_run_log(ctx, ex, *r)) != FM_OK) return rc;
     if ((rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, sizeof(ExpandPair) + 64)) != FM_OK) return rc;
     CallScope cs(ctx);
     if (!resume) {
@@ -295,13 +343,21 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
     // big rounds' cross-checks go to the dense kernels, as in fm_expand_run: the run parks with status 8 and is resumed here
     host.delegate_min = host.tie_guard ? 0 : ctx->tune.expand_delegate;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    long long res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (;;) {
+    long long res[16] = {0};
+    for (int grown = 0;;) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, false, 3, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (res[3] == 9 && grown < 12 && expand_log_grow(ctx, ex, *r) == FM_OK) {
+            // the log filled: larger arrays and the run from its start (the cells computed so far stay)
+            ++grown;
+            HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
+            expand_bind_run(host, *r, ex);
+            host.resume = 0;
+            continue;
+        }
         if (res[3] != 8) break;
         if ((rc = round_xcheck_dense(ctx, *ex->query, host.h_cand, res[5], *ex->lazy_target, res[6], res[7], host.h_qbest)) != FM_OK) return rc;
         if (ctx->tune.delegated_rounds < INT32_MAX) ++ctx->tune.delegated_rounds;
@@ -314,6 +370,63 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
     if (n_pairs) *n_pairs = res[2];
     if (status) *status = (int32_t)res[3];
     if (need_cell) *need_cell = (int32_t)res[4];
+    ex->parked = res[3] == 7;
+    ex->parked_seeds = n_seeds;
+    return FM_OK;
+}
+
+// ---- per-round log (options["log"], fastmatch.pyx:79-80, 172-180) on the device ---------------------------------------
+extern "C" int fm_expand_set_log(fm_ctx* ctx, fm_expand* ex, int32_t enable)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, "fm_expand_set_log: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ex->want_log = enable != 0;
+    ex->log_cap0 = enable > 1 ? enable : 0;
+    if (!ex->want_log || ex->log_cap0 > 0)
+        for (auto& r : ex->runs) if (r.logb) { (void)hipFree(r.logb); r.logb = nullptr; r.lg_round_cap = 0; r.lg_entry_cap = 0; }
+    return FM_OK;
+}
+
+static int expand_log_slot(fm_ctx* ctx, const fm_expand* ex, int32_t slot, const ExpandRun** r, const char* who)
+{
+    if (!ctx || !ex) return fail(ctx, FM_EINVAL, std::string(who) + ": NULL argument");
+    if (slot < 0 || (size_t)slot >= ex->runs.size()) return fail(ctx, FM_EINVAL, std::string(who) + ": the pair has no such run slot");
+    if (!ex->runs[(size_t)slot].logb) return fail(ctx, FM_EINVAL, std::string(who) + ": the run wrote no log (fm_expand_set_log)");
+    *r = &ex->runs[(size_t)slot];
+    return FM_OK;
+}
+
+extern "C" int fm_expand_log_counts(fm_ctx* ctx, const fm_expand* ex, int32_t slot, int64_t* n_rounds, int64_t* n_entries)
+{
+    const ExpandRun* r = nullptr;
+    int rc = expand_log_slot(ctx, ex, slot, &r, "fm_expand_log_counts");
+    if (rc != FM_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    long long res[16];
+    HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_rounds) *n_rounds = res[1];
+    if (n_entries) *n_entries = res[8];
+    return FM_OK;
+}
+
+extern "C" int fm_expand_fetch_log(fm_ctx* ctx, const fm_expand* ex, int32_t slot, int64_t n_rounds, int64_t n_entries,
+                                   int64_t* rounds, int32_t* query_row, int32_t* target_row, double* ratio)
+{
+    const ExpandRun* r = nullptr;
+    int rc = expand_log_slot(ctx, ex, slot, &r, "fm_expand_fetch_log");
+    if (rc != FM_OK) return rc;
+    if (n_rounds < 0 || n_rounds > r->lg_round_cap || n_entries < 0 || n_entries > r->lg_entry_cap)
+        return fail(ctx, FM_EINVAL, "fm_expand_fetch_log: counts out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ExpandPair P{};
+    expand_bind_run(P, *r);
+    if (n_rounds && rounds) HIP_TRY(ctx, hipMemcpyAsync(rounds, P.lg_round, (size_t)n_rounds * 48, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_entries && query_row) HIP_TRY(ctx, hipMemcpyAsync(query_row, P.lg_q, (size_t)n_entries * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_entries && target_row) HIP_TRY(ctx, hipMemcpyAsync(target_row, P.lg_t, (size_t)n_entries * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_entries && ratio) HIP_TRY(ctx, hipMemcpyAsync(ratio, P.lg_ratio, (size_t)n_entries * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FM_OK;
 }
 
@@ -393,6 +506,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
             if (n_seeds[i] < 0 || (n_seeds[i] > 0 && !seeds[i])) return fail(ctx, FM_EINVAL, "fm_expand_run: bad seeds");
             const int slot = seen_pairs[ex]++;
             if ((rc = expand_ensure_run(ctx, ex, (size_t)slot)) != FM_OK) return rc;
+            if ((rc = expand_run_log(ctx, ex, ex->runs[(size_t)slot])) != FM_OK) return rc;
         }
         seen_pairs.clear();
         for (int i = 0; i < n; ++i) {                      // (pointers into runs[] are taken once the vectors stopped growing)
@@ -444,8 +558,11 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     for (int i = 0; i < n; ++i) set_delegate(i);
     // kernel of a run: int8 tiers 0 / 1 / 2, float32 tiers 0 / 2
     auto group_of = [&](int i) { return host[i].f32 ? (big[(size_t)i] == 2 ? 4 : 3) : (int)big[(size_t)i]; };
+    // (function scope: the asynchronous copy below reads it until the next stream synchronisation -- ADVICE r04)
+    std::vector<ExpandPair> grouped;
     auto launch_groups = [&](const std::vector<int>& idx) -> int {
-        std::vector<ExpandPair> grouped;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the previous launch's copy out of `grouped` / into ws_in is done
+        grouped.clear();
         grouped.reserve(idx.size());
         int cnt[5] = {0, 0, 0, 0, 0};
         for (int g = 0; g < 5; ++g)
@@ -465,7 +582,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     if ((rc = launch_groups(all_runs)) != FM_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->kernel_timed = true;
-    // per run: n_matches, n_rounds, n_pairs, status | (a parked run) cell, subset size, first train row, train rows
+    // per run: n_matches, n_rounds, n_pairs, status | (a parked run) cell, subset size, first train row, train rows (expand_pair.h)
     std::vector<long long> res((size_t)n * 8);
     for (int i = 0; i < n; ++i)
         HIP_TRY(ctx, hipMemcpyAsync(&res[(size_t)i * 8], run[(size_t)i]->result, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -514,7 +631,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // hash table (status 1, 4, 5: thresholds above 1 accept nearly every cross-checked pair and the
     // expansion heads for every (cell, query cell) combination) in a run state four times as large, at most
     // `expand_grow` times over (default 2; the status stands after that).  The other runs keep their results.
-    for (int pass = 0; pass <= ctx->tune.expand_grow + 2; ++pass) {
+    for (int pass = 0; pass <= ctx->tune.expand_grow + 10; ++pass) {     // (+ 2: the capacity tiers; the rest: log arrays that started small)
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) {
             const long long st = res[(size_t)i * 8 + 3];
@@ -528,6 +645,12 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                     redo.push_back(i);
                 }
                 continue;                                 // (no memory for the tables: the status stands)
+            }
+            if (st == 9 && pass < ctx->tune.expand_grow + 10) {         // the log filled: larger arrays, the run again
+                if (expand_log_grow(ctx, pairs[i], *r) != FM_OK) continue;
+                expand_bind_run(host[i], *r, big[(size_t)i] == 2 ? pairs[i] : nullptr);
+                redo.push_back(i);
+                continue;
             }
             if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (int)big[(size_t)i]) {
                 const int64_t limit = (int64_t)1 << 28;
@@ -560,23 +683,23 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     }
     ctx->tune.delegated_rounds = (int)std::min<int64_t>((int64_t)INT32_MAX, (int64_t)ctx->tune.delegated_rounds + delegated);
     if (dbg && getenv("FM_PARK_PROF")) {               // (a library built with -DFM_PARK_PROF: expand.hip)
-        long long pr[16];
+        long long pr[kExpResultWords];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
         static const char* hn[7] = {"pop + radius walk", "list + histogram + bounds", "partition", "chunk sorts (+ x-check)", "step 4", "step 5", "rounds that fit"};
-        fprintf(stderr, "[fm_expand_run, run 0] %lld rounds beyond the LDS tables; thread 0's clock, ms: ", pr[15]);
-        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.2f  ", hn[k], pr[8 + k] * 1e-5);
+        fprintf(stderr, "[fm_expand_run, run 0] %lld rounds beyond the LDS tables; thread 0's clock, ms: ", pr[39]);
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "%s %.2f  ", hn[k], pr[32 + k] * 1e-5);
         fprintf(stderr, "\n");
     }
     if (delegated > 0 && dbg)
         fprintf(stderr, "[fm_expand_run] %lld cross-checks delegated to the dense kernels; host seconds: enqueue dense %.4f, enqueue resume %.4f, "
                         "wait %.4f\n", (long long)delegated, t_dense, t_launch, t_wait);
     if (ctx->tune.expand_prof) {
-        long long pr[16];
+        long long pr[kExpResultWords];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
         static const char* names[12] = {"pop:barrier", "radius", "sort", "x1_tail", "compact", "neigh+push+emit", "end", "pop:thread0",
                                         "x1:bfrag+barrier", "x1:gather", "x1:mfma", "x1:merge"};
         fprintf(stderr, "[fm_expand prof, run 0, %lld rounds] ", pr[1]);
-        for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[4 + k] * 0.01 / (double)pr[1] : 0.0);
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "%s %.2f us  ", names[k], pr[1] ? pr[16 + k] * 0.01 / (double)pr[1] : 0.0);
         fprintf(stderr, "\n");
     }
     rc = cs.finish();

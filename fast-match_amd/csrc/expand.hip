@@ -53,7 +53,7 @@ struct ExpCfg {
 };
 
 enum { kExpOk = 0, kExpStackFull = 1, kExpCandFull = 2, kExpOutOfBounds = 3, kExpMatchFull = 4, kExpTableFull = 5,
-       kExpListFull = 6, kExpNeedCell = 7, kExpNeedXcheck = 8 };
+       kExpListFull = 6, kExpNeedCell = 7, kExpNeedXcheck = 8, kExpLogFull = 9 };
 static_assert(kRF_StageBytes <= ExpCfg<kExpCand>::kStageBytes, "the float32 round's gather image must fit the stage buffer");
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -417,6 +417,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         gptr<int32_t> h_cand, h_ucand; gptr<unsigned long long> h_qbest, h_tbest, h_pkey;
         gptr<const int64_t> cell_start; gptr<const int32_t> cell_cnt, cell_ready; gptr<long long> resume_state; int resume;
         long long delegate_min;
+        gptr<long long> lg_round; gptr<int32_t> lg_q, lg_t; gptr<double> lg_ratio; long long lg_round_cap, lg_entry_cap;
     } P;
     P.q_rows8 = (gptr<const int8_t>)M.q_rows8; P.q_norm = (gptr<const int32_t>)M.q_norm;
     P.q_selfdist = (gptr<const double>)M.q_selfdist; P.q_pos = (gptr<const double>)M.q_pos; P.q_pos_ord = (gptr<const double>)M.q_pos_ord;
@@ -435,6 +436,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.h_cand = (gptr<int32_t>)M.h_cand; P.h_ucand = (gptr<int32_t>)M.h_ucand; P.h_qbest = (gptr<unsigned long long>)M.h_qbest; P.h_tbest = (gptr<unsigned long long>)M.h_tbest; P.h_pkey = (gptr<unsigned long long>)M.h_pkey;
     P.cell_start = (gptr<const int64_t>)M.cell_start; P.cell_cnt = (gptr<const int32_t>)M.cell_cnt; P.cell_ready = (gptr<const int32_t>)M.cell_ready;
     P.resume_state = (gptr<long long>)M.resume_state; P.resume = M.resume; P.delegate_min = M.delegate_min;
+    P.lg_round = (gptr<long long>)M.lg_round; P.lg_q = (gptr<int32_t>)M.lg_q; P.lg_t = (gptr<int32_t>)M.lg_t; P.lg_ratio = (gptr<double>)M.lg_ratio;
+    P.lg_round_cap = M.lg_round_cap; P.lg_entry_cap = M.lg_entry_cap;
     const RoundF32G RF(M.rf);
     const int tid = threadIdx.x;
 
@@ -461,6 +464,15 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 #define HUGE_STAMP(k) do { } while (0)
 #endif
 
+    // per-round log: entries written so far (thread 0 updates it at the end of a round, everyone reads it behind barriers)
+    __shared__ long long sh_nlog;
+    if (tid == 0) sh_nlog = 0;
+    // the record of the round in progress (thread 0): its entry, the cell it fetched, its accepted matches
+    auto log_header = [&](int cell_id, int n_acc) {
+        gptr<long long> rec = P.lg_round + (n_rounds - 1) * 6;
+        for (int k = 0; k < 4; ++k) rec[k] = __double_as_longlong(cur[k]);
+        rec[4] = cell_id; rec[5] = n_acc;
+    };
     bool skip_pop = false;        // (uniform) the first round of a resumed run takes the saved entry
     bool skip_x = false;          // (uniform) ... and, resumed behind a DELEGATED cross-check (P.resume == 2), goes straight to steps 4 / 5
     int need_cell = -1;
@@ -468,7 +480,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (P.resume) {
             top = P.resume_state[0]; seed_i = P.resume_state[1]; n_matches = P.resume_state[2];
             n_rounds = P.resume_state[3]; n_pairs = P.resume_state[4]; seen_n = P.resume_state[5];
-            if (tid == 0) for (int k = 0; k < 4; ++k) cur[k] = __longlong_as_double(P.resume_state[6 + k]);
+            if (tid == 0) { for (int k = 0; k < 4; ++k) cur[k] = __longlong_as_double(P.resume_state[6 + k]); sh_nlog = P.resume_state[13]; }
             skip_pop = true;
             skip_x = P.resume == 2;
         }
@@ -588,6 +600,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
                     P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
                     for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
+                    P.resume_state[13] = sh_nlog;
                 }
                 need_cell = cell;
                 status = kExpNeedCell;
@@ -611,6 +624,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             fkeys = true;
         } else {
         ++n_rounds;
+        if (P.lg_round && n_rounds > P.lg_round_cap) { status = kExpLogFull; break; }
 
         // ---- 2. radius query (Position_Index.radius) ------------------------------------------
         block_sort_clear(hist);          // (for the sort behind the radius query: the barrier in between is the query's own)
@@ -692,7 +706,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 
         EXP_STAMP(2);
         // ---- 3. cross-checked 1-NN against the cell ---------------------------------------------
-        if (nt == 0 || nq == 0) continue;                   // match_position returns empty arrays
+        if (nt == 0 || nq == 0) {                           // match_position returns empty arrays (the round is still logged;
+            // -1: a cell without features, fastmatch.pyx:155-156, returns arrays of another shape than an empty subset does)
+            if (P.lg_round && tid == 0) log_header(cell, nt == 0 ? -1 : 0);
+            continue;
+        }
         n_pairs += (long long)nq * nt;
         if constexpr (HUGE) {
             // a round whose subset fits LDS but whose CELL is large (thousands of train rows: a blob of keypoints) is
@@ -703,7 +721,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
                     P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
                     for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
-                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt;
+                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt; P.resume_state[13] = sh_nlog;
                 }
                 need_cell = cell;
                 status = kExpNeedXcheck;
@@ -725,7 +743,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         }
         } else if constexpr (HUGE) {
             // ---- 2b / 3b. a radius subset beyond the LDS tables: chunks of the sort-key range -----------------
-            if (nt == 0) continue;
+            if (nt == 0) { if (P.lg_round && tid == 0) log_header(cell, -1); continue; }
             n_pairs += (long long)nq * nt;
             __shared__ int chb[kHugeChunks + 1];            // chunk c = sort buckets [chb[c], chb[c + 1])
             __shared__ int chrow[kHugeChunks + 1];          // ... = slots [chrow[c], chrow[c + 1]) of the sorted subset
@@ -873,7 +891,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     P.resume_state[0] = top; P.resume_state[1] = seed_i; P.resume_state[2] = n_matches;
                     P.resume_state[3] = n_rounds; P.resume_state[4] = n_pairs; P.resume_state[5] = seen_n;
                     for (int k = 0; k < 4; ++k) P.resume_state[6 + k] = __double_as_longlong(cur[k]);
-                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt;
+                    P.resume_state[10] = nq; P.resume_state[11] = t0; P.resume_state[12] = nt; P.resume_state[13] = sh_nlog;
                 }
                 need_cell = cell;
                 status = kExpNeedXcheck;
@@ -907,26 +925,38 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         }
         unsigned long long* rk = (unsigned long long*)smem;        // result keys (the stage buffer is free now)
         int n_emit = 0, na = 0;
+        int log_na = 0;                                            // (uniform) accepted matches of this round that went to the log
         if (nq <= kExpThreads && !huge_round) {
             // The usual size -- one thread per slot, nothing is compacted: slot order IS the order of the accepted list.
             const int i = tid;
             bool acc = false, known = false;
             double ratio = 0.0, mqx = 0, mqy = 0, px = 0, py = 0, nx = 0, ny = 0;
             unsigned long long nk = ~0ull, k1 = 0, rbits = 0;
-            int qrow_idx = 0;
+            int qrow_idx = 0, t_local = 0;
             long long nslot = 0;
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
                     const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
                     qrow_idx = cand[i];
-                    const int t_local = (int)(unsigned)qb;
+                    t_local = (int)(unsigned)qb;
                     const double sd = P.q_selfdist[qrow_idx];
                     mqx = P.q_pos[2 * qrow_idx]; mqy = P.q_pos[2 * qrow_idx + 1];
                     px = P.t_pos[2 * (t0 + t_local)]; py = P.t_pos[2 * (t0 + t_local) + 1];
                     ratio = (double)d / sd;
                     acc = ratio < P.tau;
                 }
+            }
+            if (P.lg_round) {                  // (uniform) the round's record: every accepted match in slot order, before the dedup
+                int ao, unused;
+                const int atot = block_rank_flags(acc, false, &ao, &unused, wave_cnt, rank_toggle) & 0xffff;
+                if (sh_nlog + atot > P.lg_entry_cap) { status = kExpLogFull; break; }
+                if (acc) {
+                    const long long e = sh_nlog + ao;
+                    P.lg_q[e] = qrow_idx; P.lg_t[e] = (int)(t0 + t_local); P.lg_ratio[e] = ratio;
+                }
+                if (tid == 0) log_header(cell, atot);
+                log_na = atot;
             }
             if (acc) {
                 rbits = (unsigned long long)__double_as_longlong(ratio);
@@ -1014,6 +1044,13 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
                 // those reads from these writes): entries na+o <= i never clobber unread ones
                 if constexpr (HUGE) { if (huge_round && na + cnt > CAND) { status = kExpCandFull; break; } }   // (uniform)
+                if (P.lg_round) {              // (uniform) the accepted list IS the round's record
+                    if (sh_nlog + na + cnt > P.lg_entry_cap) { status = kExpLogFull; break; }
+                    if (acc) {
+                        const long long e = sh_nlog + na + o;
+                        P.lg_q[e] = qrow; P.lg_t[e] = (int)(t0 + t_local); P.lg_ratio[e] = ratio;
+                    }
+                }
                 if (acc) {
                     // (a huge round's slot numbers do not fit beside t_local: the accepted list keeps the query row itself,
                     // in cand[], which the round no longer needs -- its reads above came from global memory)
@@ -1028,6 +1065,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 na += cnt;
             }
             if (status != kExpOk) break;
+            if (P.lg_round) { if (tid == 0) log_header(cell, na); log_na = na; }
             lds_barrier();
             EXP_STAMP(4);
 #ifdef FM_PARK_PROF
@@ -1169,6 +1207,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         if (huge_round) HUGE_STAMP(5);
 #endif
         n_matches += n_emit;
+        if (P.lg_round && tid == 0) sh_nlog += log_na;             // (read again only behind the barrier below)
         __threadfence_block();
         __syncthreads();           // table / stack writes visible before the next round reads them
         if (sh_i[7]) { status = kExpTableFull; break; }
@@ -1182,10 +1221,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         P.result[1] = n_rounds;
         P.result[2] = n_pairs;
         P.result[3] = status;
-        if (P.prof) for (int k = 0; k < 12; ++k) P.result[4 + k] = pt[k];
+        P.result[8] = sh_nlog;
+        if (P.prof) for (int k = 0; k < 12; ++k) P.result[16 + k] = pt[k];
 #ifdef FM_PARK_PROF
         HUGE_STAMP(6);
-        for (int k = 0; k < 8; ++k) P.result[8 + k] = (P.resume ? P.result[8 + k] : 0) + hp[k];
+        for (int k = 0; k < 8; ++k) P.result[32 + k] = (P.resume ? P.result[32 + k] : 0) + hp[k];
 #endif
         if constexpr (LAZY || HUGE) {
             P.result[4] = need_cell;

@@ -53,15 +53,29 @@ struct ExpandPair {
     const int64_t* cell_start;     // [cols*rows]
     const int32_t* cell_cnt;       // [cols*rows]
     const int32_t* cell_ready;     // [cols*rows] 0 = not computed yet
-    long long* resume_state;       // [13] loop state of a parked run (top, seed cursor, counters, the popped entry; a delegated
-                                   // cross-check: + subset size, first train row, train rows)
+    long long* resume_state;       // [14] loop state of a parked run (top, seed cursor, counters, the popped entry; a delegated
+                                   // cross-check: + subset size, first train row, train rows; [13] log entries so far)
     int        resume;             // 1: restore resume_state and take its entry first; 2: ... and go straight to steps 4 / 5
                                    // (the round's cross-checked keys are in h_qbest)
     long long  delegate_min;       // > 0: rounds of at least this many descriptor pairs whose subset does not fit LDS are parked
                                    // for a dense cross-check on the whole GPU (expand.hip, DELEGATED)
-    long long* result;             // [12]: n_matches, n_rounds, n_pairs, status, 8 phase timers (lazy: [4] = the cell wanted)
+    // Result words of a run (kExpResultWords of them): [0] n_matches, [1] n_rounds, [2] n_pairs, [3] status,
+    // [4] the cell a parked run waits for, [5 .. 7] a delegated cross-check's subset size / first train row / train rows,
+    // [8] log entries written, [16 .. 27] the 12 phase timers (prof), [32 .. 39] FM_PARK_PROF builds' phase sums.
+    long long* result;
     int        prof;               // non-zero: thread 0 accumulates per-phase 100 MHz ticks
+    // Per-round log (options["log"], fastmatch.pyx:79-80, 172-180), or null: one record per processed round --
+    // the popped entry (query_pos, target_pos as float64 bits), the cell the round fetched (col * rows + row: the
+    // host derives Grid_Cache.last from the order in which cells first appear, cache.pyx:102-106) and the number of
+    // accepted matches -- and, per accepted match in the round's order BEFORE the result dedup (log_round keeps
+    // result_pos[ratios < tau], fastmatch.pyx:177, 179), its query row, its row of the packed target bank and its ratio.
+    long long* lg_round;           // [lg_round_cap][6]
+    int32_t*   lg_q;               // [lg_entry_cap]
+    int32_t*   lg_t;               // [lg_entry_cap]
+    double*    lg_ratio;           // [lg_entry_cap]
+    long long  lg_round_cap, lg_entry_cap;
 };
+constexpr int kExpResultWords = 64;
 
 
 }  // namespace fm

@@ -100,6 +100,9 @@ constexpr int kTriAlways  = -(1 << 28);       // X of a row without a bound yet
 constexpr int kTriXRow    = kStageBytes;                 // int32[128] X per staged row, accumulator order
 constexpr int kTriX8      = kStageBytes + 512;           // int32 X8 at 64 * unit + 16 * lane group
 constexpr int kStageBytesTri = kStageBytes + 512 + 256;  // 18176
+constexpr int kTriRaw     = 3 * kStageBytesTri;          // behind the three stage buffers: bound[] words of 128 rows, their norms
+constexpr int kTriGn      = kTriRaw + 1024;              // per wave 4 x 64 words: the refreshed bounds of its own output rows
+constexpr int kTriLdsBytes = kTriGn + 8 * 1024;
 
 // Workgroups of a bank pair that the grid holds under `order` (RowReducePlan::order, option "k1_order"):
 //   0  split major: bid -> (chunk = bid % nchunks, split = bid / nchunks).  Consecutive workgroups -- dealt
@@ -165,8 +168,10 @@ __device__ __forceinline__ void load_bound_untracked(int& dst, const int* ptr)
 template <int IMM, bool SC1 = true>
 __device__ __forceinline__ void load_word_untracked_s(int& dst, const int* base, unsigned voff)
 {
-    if constexpr (SC1) asm volatile("global_load_dword %0, %1, %2 offset:%3 sc1" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-    else               asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+    // ("+v": the loop-carried variable keeps ONE register through the unrolled stage loop -- with "=v" the copies of the loop
+    // body got registers of their own and the compiler moved values between them in front of the wait, tests/test_isa_hazards.py)
+    if constexpr (SC1) asm volatile("global_load_dword %0, %1, %2 offset:%3 sc1" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+    else               asm volatile("global_load_dword %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 
 template <bool GLDS, int NW>
@@ -229,6 +234,13 @@ __device__ __forceinline__ int lane_now()
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
+}
+// One dword per lane into LDS (64 consecutive words from lds_addr on); sc1: the bounds are other workgroups' atomics.
+template <bool SC1>
+__device__ __forceinline__ void lds_dma_4(unsigned lds_addr, const void* sbase, unsigned voff)
+{
+    if constexpr (SC1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1" :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+    else               asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void issue_stage_u8(const RRParams& p, int stage, char* buf, int wave, int lane, unsigned lo)
 {
@@ -321,9 +333,10 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
 
     // TRI: -|c|^2 of this lane's output rows (an output row beyond the bank takes part in nothing), the end of
     // the chunk's own stages (the diagonal block: both directions come out of the row direction there), and the
-    // bound / norm words of the streamed rows two stages ahead (waves 0 and 1: one row per lane).
+    // bound / norm words of the streamed rows two stages ahead (waves 0 and 1: one row per lane; they travel by LDS-DMA
+    // into kTriRaw, not through registers: a loop-carried VGPR with a load in flight was copied by the compiler in front
+    // of the hand-over's wait -- tests/test_isa_hazards.py).
     int negcn[NC];
-    int tri_b = 0, tri_n = 0;
     const int diag_end = TRI ? (chunk + 1) * (16 * NC * NW / kStageRows) : 0;
     if constexpr (TRI) {
 #pragma unroll
@@ -360,7 +373,13 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         gnext[j] = (p.bound && n < p.ncols_alloc)
             ? __hip_atomic_load(bound_thr + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MIN;
     }
+    // TRI: the refreshed bounds travel by LDS-DMA into kTriGn (no loop-carried register has a load in flight: the compiler
+    // moved such registers between the copies of the unrolled stage loop in front of the wait, tests/test_isa_hazards.py);
+    // the words read here apply at once
+    bool gn_fresh = false;            // (uniform) the previous hand-over requested a refresh
     if constexpr (TRI) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) thr[j] = max(thr[j], gnext[j] >> 1);
         if (wave < 2) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -401,16 +420,25 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             }
             // (volatile asm statements keep their order: the bound registers count as written here,
             // behind the wait, so no use of them can be scheduled in front of it)
+            if constexpr (!TRI) {
 #pragma unroll
-            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(gnext[j]));
-            if constexpr (TRI) { asm volatile("" : "+v"(tri_b)); asm volatile("" : "+v"(tri_n)); }
+                for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(gnext[j]));
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();   // stage st landed; every wave is done with the other buffer
         }
+        if constexpr (TRI) {
+            if (gn_fresh) {            // (the words are this wave's own request: landed behind the wait above)
+                const int* gw = (const int*)(smem + kTriGn + 1024 * wave) + lane_now();
 #pragma unroll
-        for (int j = 0; j < NC; ++j) thr[j] = max(thr[j], gnext[j] >> 1);      // hi >= g possible iff acc >= floor(g / 2)
+                for (int j = 0; j < NC; ++j) thr[j] = max(thr[j], gw[64 * j] >> 1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) thr[j] = max(thr[j], gnext[j] >> 1);      // hi >= g possible iff acc >= floor(g / 2)
+        }
         if constexpr (KTOP == 2) {
             if (p.bound) {
 #pragma unroll
@@ -429,33 +457,43 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStride, wave, lane);
         }
         if constexpr (TRI) {
-            // the words read at the previous hand-over (older than the DMA that wait left in flight) become stage
-            // st + 1's X in its buffer, which every wave left two barriers ago and the DMA fills beside it; then
-            // the words of stage st + 2 are requested, in front of its DMA
+            // the words requested at the previous hand-over (LDS-DMA older than the one that wait left in flight, so they
+            // have landed; the barrier covers wave 0 <-> 1 only in that each reads what it requested itself) become stage
+            // st + 1's X in its buffer, which every wave left two barriers ago and the row DMA fills beside it; then the
+            // words of stage st + 2 are requested, in front of its row DMA
             if (wave < 2) {
-                if (st > st0 && st + 1 < st1) tri_store(st + 1, smem + ((BUF + 1) % 3) * kStride, tri_b, tri_n);
+                if (st > st0 && st + 1 < st1) {
+                    const int l = lane_now();
+                    const int b = *(const int*)(smem + kTriRaw + 4 * (64 * wave + l));
+                    const int nm = *(const int*)(smem + kTriRaw + 512 + 4 * (64 * wave + l));
+                    tri_store(st + 1, smem + ((BUF + 1) % 3) * kStride, b, nm);
+                }
                 if (st + 2 < st1) {
-                    const unsigned moff = (unsigned)((st + 2) * kStageRows + 64 * wave + lane_now()) * 4u;
-                    load_word_untracked_s<0>(tri_b, p.bound, moff);
-                    load_word_untracked_s<0, false>(tri_n, p.col_norm, moff);
+                    const unsigned raw = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)kTriRaw + 256u * (unsigned)wave;
+                    const unsigned voff = (unsigned)lane_now() * 4u;
+                    const size_t m0 = (size_t)(st + 2) * kStageRows + 64 * wave;
+                    lds_dma_4<true>(raw, p.bound + m0, voff);
+                    lds_dma_4<false>(raw + 512u, p.col_norm + m0, voff);
                 }
             }
         }
         // (a bound that is a few stages old is merely weaker; late in a sweep the bounds hardly move, and each of these loads
         // is an agent-scope read that goes past the XCD's L2: 5e6 of them per 100k x 100k pair were 3/4 of the kernel's
         // fabric traffic -- r04: re-read at every stage only while the sweep is young)
+        if constexpr (TRI) {
+            gn_fresh = st + 1 < st1 && (st - st0 < 8 || ((st - st0) & p.bound_mask) == 0);
+            if (gn_fresh) {
+                const unsigned dst = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)kTriGn + 1024u * (unsigned)wave;
+                const unsigned voff = (unsigned)(lane_now() & 15) * 4u;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) lds_dma_4<true>(dst + 256u * j, p.bound + cb + 16 * j, voff);
+            }
+        } else
         if (p.bound && (st - st0 < 8 || ((st - st0) & p.bound_mask) == 0)) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int n = cb + 16 * j + c16;
-                if constexpr (TRI) {
-                    static_assert(NC == 4, "immediate offsets below");
-                    const unsigned boff = (unsigned)(cb + c16) * 4u;
-                    if (j == 0) load_word_untracked_s<0>(gnext[0], p.bound, boff);
-                    if (j == 1) load_word_untracked_s<64>(gnext[1], p.bound, boff);
-                    if (j == 2) load_word_untracked_s<128>(gnext[2], p.bound, boff);
-                    if (j == 3) load_word_untracked_s<192>(gnext[3], p.bound, boff);
-                } else if constexpr (NBUF == 3) {
+                if constexpr (NBUF == 3) {
                     // (ncols_alloc is a multiple of the chunk, so n is always inside the array)
                     load_bound_untracked(gnext[j], bound_thr + n);
                 } else {
@@ -743,7 +781,7 @@ template <int PRIO>
 __global__ __launch_bounds__(64 * 8, 4)
 void rowreduce_tri_kernel(RRParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[3 * kStageBytesTri];
+    __shared__ __attribute__((aligned(16))) char smem[kTriLdsBytes];
     rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x, smem);
 }
 
@@ -751,7 +789,7 @@ template <int PRIO>
 __global__ __launch_bounds__(64 * 8, 4)
 void rowreduce_tri_batch_kernel(RRBatch b)
 {
-    __shared__ __attribute__((aligned(16))) char smem[3 * kStageBytesTri];
+    __shared__ __attribute__((aligned(16))) char smem[kTriLdsBytes];
     const int pair = (int)blockIdx.x / b.blocks_per_pair;
     const RRParams p = b.p[pair];
     rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);

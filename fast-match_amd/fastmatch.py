@@ -16,9 +16,9 @@ workgroup per run replays the reference's exact depth-first order -- the match s
 SURVEY.md fact 9): for a ``cache.Feature_Image`` target (every feature known up front) in one
 launch per call, any number of (pair, threshold) runs side by side; for the reference's PIXEL
 target, whose cells are computed when the loop first reaches them (cache.pyx:102-106, 124-138), the
-kernel parks at a missing cell and the host computes it and resumes (``lazy_device_loop``).  Only
-when a per-round ``log`` is wanted, the descriptors are float32 with a pixel target, or a capacity
-of the device loop is exceeded does the host replay the loop (``do_iter``): each round's arithmetic --
+kernel parks at a missing cell and the host computes it and resumes (``lazy_device_loop``).  A per-round
+``log`` (the README's flow) is written by the kernel too (r05).  Only when the descriptors are float32 with
+a pixel target or a capacity of the device loop is exceeded does the host replay the loop (``do_iter``): each round's arithmetic --
 OpenCV's ``BFMatcher(NORM_L2, crossCheck=True).knnMatch`` plus the float64 ratio -- is then one launch
 of the HIP round kernel on banks that stay resident (the query bank with its self distances, one bank
 per computed grid cell); the radius subset's row indices go up, (train index, distance, ratio) come back.
@@ -26,7 +26,7 @@ per computed grid cell); the radius subset's row indices go up, (train index, di
 ``target_img`` is either the reference's ``uint8[H, W, 3]`` array (SIFT through OpenCV on
 the host, needs ``cv2``) or a ``cache.Feature_Image`` carrying pre-extracted features.
 Extra option keys (additions): ``"context"``/``"device"`` select the GPU,
-``"stats"`` (a dict) receives round/pair counters, ``"feature_function"`` replaces
+``"stats"`` (a dict) receives round/pair counters; ``"log"`` (the reference's own key) is filled from the device loop's records, ``"feature_function"`` replaces
 ``matchutil.get_features`` (cv2 SIFT) for the thumbnail and the lazily computed grid cells
 (e.g. ``standin.standin_features`` where cv2 is absent).
 """
@@ -60,12 +60,13 @@ def match(query_cache, target_img, options={}):
     # The whole expansion loop runs on the device when every target feature is known up
     # front (a Feature_Image) and no per-round log is wanted; otherwise (lazy SIFT per cell,
     # logging) the host replays the loop and only each round's arithmetic runs on the device.
-    use_device_loop = (isinstance(target_img, Feature_Image) and log is None
-                       and options.get("device_loop", True))
+    # r05: a per-round ``log`` no longer sends the run to the host loop -- the kernel records the rounds
+    # (fm_expand_set_log) and ``_append_device_log`` rebuilds the reference's dicts from them.
+    use_device_loop = isinstance(target_img, Feature_Image) and options.get("device_loop", True)
     # r04: a pixel target (cells computed on demand, the reference's own mode: cache.pyx:102-106, 124-138) runs the loop on
     # the device too -- the kernel parks when it reaches a cell that has not been computed, the host computes it (SIFT on the
     # crop), adds it to the growing target bank and resumes (lazy_device_loop below)
-    use_lazy_loop = (not isinstance(target_img, Feature_Image) and log is None and options.get("device_loop", True))
+    use_lazy_loop = not isinstance(target_img, Feature_Image) and options.get("device_loop", True)
     state = {"expander": None, "lazy": None}
 
     def seeds_for(tau):
@@ -77,6 +78,8 @@ def match(query_cache, target_img, options={}):
             return None
         if state["expander"] is None:
             state["expander"] = make_expander(query_cache, target_cache, radius, context)
+            if state["expander"] and log is not None:
+                state["expander"].set_log(True, first_capacity=options.get("log_first_capacity", 0))
         return state["expander"] or None
 
     def host_loop(tau):
@@ -92,12 +95,15 @@ def match(query_cache, target_img, options={}):
             state["lazy"] = make_lazy_expander(query_cache, target_cache, radius, context, options.get("lazy_capacity"))
             if state["lazy"] is False:
                 return None
+            if log is not None:
+                state["lazy"][0].set_log(True, first_capacity=options.get("log_first_capacity", 0))
         ex, t_bank = state["lazy"]
         seeds, resume, added = seeds_for(tau), False, 0
         from . import _ffi
+        grid_before = _grid_state(target_cache) if log is not None else None
         while True:
             n_matches, n_rounds, n_pairs, status, need = ex.run_lazy(seeds, tau, resume)
-            if status == 7:                                    # FM_EXPAND_NEED_CELL
+            if status == _ffi.FM_EXPAND_NEED_CELL:
                 col, row = divmod(need, target_cache.rows)
                 value = target_cache.get_cell(col, row)        # the caching function runs here (SIFT on the crop)
                 kp, ds = value if isinstance(value, tuple) else (None, None)
@@ -130,6 +136,8 @@ def match(query_cache, target_img, options={}):
                 stats["device_loops"] = stats.get("device_loops", 0) + 1
                 stats["rounds"] = stats.get("rounds", 0) + n_rounds
                 stats["pairs"] = stats.get("pairs", 0) + n_pairs
+            if log is not None:
+                _append_device_log(log, ex, 0, target_cache, radius, grid_before, mark_computed=False)
             index, pos, ratio = ex.fetch(n_matches)
             if options.get("return_arrays", False):
                 return index, pos, ratio
@@ -145,7 +153,8 @@ def match(query_cache, target_img, options={}):
             ex = expander()
             if ex is not None and taus:
                 res = run_device_loops(context, [ex] * len(taus), [seeds_for(t) for t in taus], taus, stats=stats,
-                                       as_arrays=options.get("return_arrays", False))
+                                       as_arrays=options.get("return_arrays", False),
+                                       logs=None if log is None else [(log, target_cache, radius)] * len(taus))
             elif use_lazy_loop:
                 res = [lazy_device_loop(t) for t in taus]      # (one after the other: they share the cells computed so far)
             return [r if r is not None else host_loop(t) for r, t in zip(res, taus)]
@@ -156,7 +165,8 @@ def match(query_cache, target_img, options={}):
         ex = expander()
         if ex is not None:
             res = run_device_loops(context, [ex], [seeds_for(tau)], [tau], stats=stats,
-                                   as_arrays=options.get("return_arrays", False))[0]
+                                   as_arrays=options.get("return_arrays", False),
+                                   logs=None if log is None else [(log, target_cache, radius)])[0]
             if res is not None:
                 return res
         return host_loop(tau)
@@ -281,7 +291,42 @@ def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None)
     return ex, t_bank
 
 
-def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False):
+def _grid_state(grid):
+    """What Grid_Cache.last depends on (cache.pyx:102-106): the cells computed so far and the current value."""
+    return {"known": set((col, row) for col, rows in grid.grid.items() for row in rows), "last": grid.last}
+
+
+def _append_device_log(log, ex, slot, grid, radius, before, mark_computed):
+    """The reference's per-round records (log_round, fastmatch.pyx:172-180) from what the device loop wrote
+    (fm_expand_set_log): positions of the accepted matches from the banks' host-side positions, and
+    ``target_grid`` = Grid_Cache.last as the host loop would have seen it -- the crop of the most recently COMPUTED
+    cell, i.e. it changes at a round whose cell appears for the first time (``before``: the grid's state when the run
+    began; the runs of one launch are replayed in order).  ``mark_computed``: a pre-extracted target's cells are
+    computed here, in that order, so that the Grid_Cache ends in the state the host loop leaves it in."""
+    q_pos, t_pos, cell, n_acc, q_row, t_row, ratio = ex.fetch_log(slot)
+    tp = ex.target_positions()
+    known, last = before["known"], before["last"]
+    at = 0
+    for i in range(len(cell)):
+        col, row = divmod(int(cell[i]), grid.rows)
+        if (col, row) not in known:
+            known.add((col, row))
+            last = grid.cell_bounds(col, row)
+            if mark_computed:
+                grid.get_cell(col, row)
+        k = int(n_acc[i])
+        if k < 0:                    # a cell without features: match_position's empty arrays (fastmatch.pyx:155-156)
+            matches, ratios = np.array([]), np.array([])
+        else:
+            matches = np.stack([ex.q_pos[q_row[at:at + k]], tp[t_row[at:at + k]]], axis=1) if k else np.zeros((0, 2, 2))
+            ratios = ratio[at:at + k].copy()
+            at += k
+        log.append({"query_pos": q_pos[i].copy(), "target_pos": t_pos[i].copy(), "target_grid": last, "matches": matches,
+                    "radius": radius, "ratios": ratios, "margin": grid.margin})
+    before["last"] = last
+
+
+def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=False, logs=None):
     """The device-resident loop for several independent runs: (expander, seeds, tau) triples, an expander may appear
     several times (several thresholds of one pair).  All runs go into ONE launch when the run states fit the device's
     memory, else into as few launches as do (``_launch_plan``).  Returns, per run, the match list in do_iter's format
@@ -290,13 +335,19 @@ def run_device_loops(context, expanders, seeds, taus, stats=None, as_arrays=Fals
     plan = _launch_plan(context, expanders)
     if stats is not None and len(plan) > 1:
         stats["device_launches"] = stats.get("device_launches", 0) + len(plan)
+    grid_states = {}                 # per Grid_Cache: its state as the runs of this call are replayed in order
     for idx in plan:
         results, fetched = _expand_launch(context, [expanders[i] for i in idx], [seeds[i] for i in idx], [taus[i] for i in idx])
+        slots = context.expand_slots([expanders[i] for i in idx])
         for j, (i, (n_matches, n_rounds, n_pairs, status)) in enumerate(zip(idx, results)):
             if status != 0:
                 if stats is not None:
                     stats["device_fallbacks"] = stats.get("device_fallbacks", 0) + 1
                 continue
+            if logs is not None and logs[i] is not None:
+                lg, grid, radius = logs[i]
+                st = grid_states.setdefault(id(grid), _grid_state(grid))
+                _append_device_log(lg, expanders[i], slots[j], grid, radius, st, mark_computed=True)
             if stats is not None:
                 stats["device_loops"] = stats.get("device_loops", 0) + 1
                 stats["rounds"] = stats.get("rounds", 0) + n_rounds

@@ -386,7 +386,13 @@ typedef struct fm_expand_desc {
 #define FM_EXPAND_TABLE_FULL    5
 #define FM_EXPAND_LIST_FULL     6  /* float32 round: more candidates inside the fp16 margin than fit  */
 #define FM_EXPAND_NEED_CELL     7  /* lazy target: the loop reached a cell that has not been added yet (fm_expand_run_lazy) */
+#define FM_EXPAND_LOG_FULL      9  /* the per-round log's arrays filled and could not grow any further (fm_expand_set_log);
+                                      * (8 is internal: a round parked for the dense kernels, settled inside the call) */
 
+/* LIFETIME: the pair BORROWS desc->query and desc->target -- device arrays and, for delegated rounds and lazy
+ * targets, the banks' host-side descriptors -- so both banks must outlive the fm_expand, and a bank that an fm_expand names
+ * must not be refilled (fm_bank_refill_u8_async) while it exists: row counts, cell offsets and the float32-root guard were
+ * fixed when the pair was created.  (The Python binding keeps references; a C client keeps the order destroy(pair), then banks.) */
 int  fm_expand_create(fm_ctx* ctx, const fm_expand_desc* desc, fm_expand** out);
 int  fm_expand_destroy(fm_ctx* ctx, fm_expand* ex);
 /* Run n expansions in one launch, one workgroup each.  Run i = (pairs[i], seeds[i], tau[i]): seeds[i] =
@@ -412,7 +418,8 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
  *                           output rows like any other.
  *   fm_expand_set_cell    : cell (= col * rows + row) := rows [first_row, first_row + n_rows) with their full-image positions;
  *                           n_rows = 0 for a cell without features.
- *   fm_expand_run_lazy    : one run in slot 0, from the start (resume = 0) or from where the last launch parked (resume != 0).
+ *   fm_expand_run_lazy    : one run in slot 0, from the start (resume = 0) or from where the last launch parked (resume != 0:
+ *                           FM_EINVAL unless that launch ended with FM_EXPAND_NEED_CELL; its seeds are re-used, `seeds` is ignored).
  *                           status 0: done (fm_expand_fetch); FM_EXPAND_NEED_CELL: *need_cell; else the device gave up.
  *                           (Rounds of >= "expand_delegate" descriptor pairs are cross-checked by the dense kernels inside the call.) */
 int  fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank);
@@ -460,6 +467,24 @@ int  fm_expand_fetch(fm_ctx* ctx, const fm_expand* ex, int64_t n, int32_t* index
  * assigns them (the k-th entry naming a pair reads its slot k).                                    */
 int  fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex, const int32_t* slot, const int64_t* n,
                           int32_t* const* index, double* const* positions, double* const* ratio);
+
+/* ---- the per-round log on the device (r05) ------------------------------------------------------------------------------
+ * options["log"] of fastmatch.match (fastmatch.pyx:46, 79-80): do_iter appends log_round(...) (fastmatch.pyx:172-180) once per
+ * processed round -- query_pos, target_pos, Grid_Cache.last, result_pos[ratios < tau], radius, ratios[ratios < tau], margin.
+ * With fm_expand_set_log(enable != 0) the runs of the pair (fm_expand_run and fm_expand_run_lazy) record, per processed round
+ * in order, rounds[i][0..3] = the popped (query_pos, target_pos) as float64 bit patterns, rounds[i][4] = the cell the round
+ * fetched (col * rows + row: Grid_Cache.last is the crop of the most recently COMPUTED cell, cache.pyx:102-106, which the
+ * caller derives from the order in which cells first appear), rounds[i][5] = its accepted matches; and, for every accepted
+ * match in the round's order BEFORE the result dedup (fastmatch.pyx:82-86 dedups the matches, not the log), its query row, its
+ * row of the (packed / growing) target bank and its float64 ratio.  fm_expand_log_counts gives the sizes of the last run in
+ * `slot`, fm_expand_fetch_log copies them (any pointer may be NULL).  The arrays grow fourfold with the run states
+ * ("expand_grow"); a run that still overflows ends with FM_EXPAND_LOG_FULL.  enable > 1: on, with `enable` records and
+ * `enable` accepted matches as the arrays' FIRST capacity (the defaults: 4 x the grid's cells, 4 x the query's keypoints).  */
+int  fm_expand_set_log(fm_ctx* ctx, fm_expand* ex, int32_t enable);
+int  fm_expand_log_counts(fm_ctx* ctx, const fm_expand* ex, int32_t slot, int64_t* n_rounds, int64_t* n_entries);
+int  fm_expand_fetch_log(fm_ctx* ctx, const fm_expand* ex, int32_t slot, int64_t n_rounds, int64_t n_entries,
+                         int64_t* rounds /*[n_rounds][6]*/, int32_t* query_row /*[n_entries]*/, int32_t* target_row /*[n_entries]*/,
+                         double* ratio /*[n_entries]*/);
 
 /* ---- result gather across the GPUs of a node (RCCL over xGMI) --------------------------------
  * Independent image pairs are sharded over ranks (one process per GPU, pair i -> rank i mod N);

@@ -268,7 +268,12 @@ static void knn1_rows_u8_simd(const uint8_t* A, int64_t na, const uint8_t* B, in
                     a16[r * dpad + k] = (r < rows && k < dim) ? (int16_t)A[(i0 + r) * dim + k] : 0;
             }
             for (int64_t j = 0; j < nb; j++) {
-                for (int k = 0; k < dpad; k++) b16[k] = k < dim ? (int16_t)B[j * dim + k] : 0;
+                {   /* the row widened to int16: 16 bytes per vpmovzxbw, the tail (dim not a multiple of 16) by hand */
+                    int k = 0;
+                    for (; k + 16 <= dim; k += 16)
+                        _mm256_store_si256((__m256i*)(b16 + k), _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i*)(B + j * dim + k))));
+                    for (; k < dpad; k++) b16[k] = k < dim ? (int16_t)B[j * dim + k] : 0;
+                }
                 for (int r = 0; r < rows; r++) {
                     __m256i acc = _mm256_setzero_si256();
                     for (int k = 0; k < dpad; k += 16) {

@@ -36,6 +36,20 @@ def test_two_rank_bench_equals_the_sum_of_its_ranks(gather):
     solo = [_bench({"FM_BENCH_SEED_OFFSET": str(r)}, "--gpus", "1") for r in range(2)]
     assert all(s["n_gpus"] == 1 for s in solo)
     assert two["accepted_matches_per_step"] == sum(s["accepted_matches_per_step"] for s in solo) > 1000
+    # the line describes its collective: what was gathered, by whom, how many bytes, what it cost
+    c = two["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["ranks_seen"] == 2 and c["gather"] == gather
+    assert c["collectives_per_step"] == (1 if gather == "padded" else 2)
+    if gather == "padded":
+        assert c["rows_per_rank_per_step"] == 3 * 33000 and c["bytes_per_rank_per_step"] == 3 * 33000 * 12 + 3 * 8
+    else:
+        assert 0 < c["rows_per_rank_per_step"] < 3 * 33000
+    assert c["bytes_received_per_rank_per_step"] == c["bytes_per_rank_per_step"]
+    assert c["step_ms_with_gather"] > 0 and c["step_ms_without_gather"] > 0
+    assert abs(c["gather_exposed_ms"] - (c["step_ms_with_gather"] - c["step_ms_without_gather"])) < 1e-9
+    assert all(s["collective"] is None for s in solo)
+    # the batch's last pair comes from another distribution: its accepted count differs from pair 0's
+    assert solo[0]["accepted_matches_independent_pair"] not in (None, solo[0]["accepted_matches_pair0"])
     # configs[3] leg: the same four pairs, sharded over the ranks or not -- same rounds, pairs and matches
     c2, c1 = two["expand_c4"], solo[0]["expand_c4"]
     assert c2["n_gpus"] == 2 and (c2["rounds"], c2["descriptor_pairs"], c2["matches"]) == (c1["rounds"], c1["descriptor_pairs"], c1["matches"])

@@ -293,3 +293,88 @@ def test_readme_flow_on_the_graf_pixels(ctx, tmp_path, monkeypatch, capsys):
             good = score(idx, p, None)
             print("\n[graf img1-img4, stand-in features (NOT SIFT), tau %.1f] %d keypoints/query image, %d matches, %d within 5 px of H1to4p"
                   % (tau, len(dq), len(matches), int(good.sum())))
+
+
+@pytest.mark.gpu
+def test_pixel_target_with_a_log_stays_on_the_device(ctx):
+    """README.md:47-49 passes options = {'log': log}: until r05 that alone sent the run to the host-driven loop.  The lazy
+    device loop now writes the records itself: log of the device run == log of the host loop (device_loop False), entry by
+    entry, over two thresholds on one closure (the second finds every cell cached, so target_grid goes stale exactly as
+    Grid_Cache.last does, cache.pyx:102-106), and the arrays' growth path (first capacity 8)."""
+    from fastmatch_amd import cache, fastmatch
+    img1 = texture(800, 640, seed=1)
+    mild = np.array([[1.0, 0.01, 18.0], [-0.008, 1.0, -11.0], [1e-5, -5e-6, 1.0]])
+    img4 = warp(img1, mild)
+    feat = standin.standin_features
+    kq, dq = feat(img4)
+    thumb_q = imaging.get_thumbnail(img4, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    mc = cache.Metric_Cache.from_arrays(dq, pos(kq), (800, 640), dtq, pos(ktq), (thumb_q.shape[1], thumb_q.shape[0]),
+                                        options={"context": ctx})
+    for first_capacity in (0, 8):
+        dlog, hlog, ds, hs = [], [], {}, {}
+        dev = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": ds, "log": dlog,
+                                         "log_first_capacity": first_capacity})
+        host = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": hs, "log": hlog, "device_loop": False})
+        for tau in (0.7, 0.9):
+            got, ref = dev(tau), host(tau)
+            assert len(got) == len(ref) > 20
+            for (ia, da), (ib, db) in zip(got, ref):
+                assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+        assert ds.get("device_loops") == 2 and "device_fallbacks" not in ds and ds["rounds"] == hs["rounds"] == len(dlog)
+        assert len(dlog) == len(hlog)
+        for a, b in zip(dlog, hlog):
+            assert np.array_equal(a["query_pos"], b["query_pos"]) and np.array_equal(a["target_pos"], b["target_pos"])
+            assert a["target_grid"] == b["target_grid"] and a["radius"] == b["radius"] and a["margin"] == b["margin"]
+            assert np.array_equal(a["matches"], b["matches"]) and np.array_equal(a["ratios"], b["ratios"])
+            assert np.asarray(a["matches"]).shape == np.asarray(b["matches"]).shape
+
+
+@pytest.mark.gpu
+def test_readme_flow_on_the_graf_pixels_with_real_sift(ctx, tmp_path, monkeypatch, capsys):
+    """BASELINE.json configs[0] as the reference runs it: README.md:41-50 on images/graf/img1 <-> img4 with REAL SIFT
+    (matchutil.get_features -> cv2, matchutil.py:22-33).  Skips where cv2 is absent (this image, the GPU image); the day
+    it exists this runs by itself: device loop == host loop == oracle on cv2's features, and the precision against the
+    dataset's homography H1to4p is PRINTED -- the quality number the reference never computed for graf."""
+    pytest.importorskip("cv2")
+    from PIL import Image
+    from fastmatch_amd import cache, fastmatch, matchutil
+    from oracle import fastmatch_oracle as fo
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graf")
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("images/graf")
+    for n in ("img1", "img4"):
+        Image.open(os.path.join(here, n + ".png")).save("images/graf/%s.ppm" % n)
+    H = evaluate.load_homography(os.path.join(here, "H1to4p"))
+    target_path, query_path = "images/graf/img1.ppm", "images/graf/img4.ppm"
+    feat = matchutil.get_features                                            # cv2 SIFT
+    query_cache = cache.Metric_Cache(query_path, {"context": ctx})
+    target_img = imaging.open_img(target_path)
+    log, stats, hstats = [], {}, {}
+    matches = list(fastmatch.match(query_cache, target_img, {"context": ctx, "log": log, "stats": stats})(0.7))
+    host = list(fastmatch.match(query_cache, target_img, {"context": ctx, "stats": hstats, "device_loop": False})(0.7))
+    assert len(matches) == len(host) and stats["rounds"] == hstats["rounds"] == len(log)
+    for (ia, da), (ib, db) in zip(matches, host):
+        assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    kq, dq = feat(imaging.open_img(query_path))
+    thumb_q = imaging.get_thumbnail(query_path, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    oq = fo.OQuery(dq, pos(kq), (800, 640),
+                   thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    thumb_t = imaging.get_thumbnail(target_img, (400, 400))
+    ktt, dtt = feat(thumb_t)
+    ot = {"size": (800, 640), "image": target_img, "feature_function": feat,
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    exp = fo.o_match(oq, ot, {})(0.7)
+    assert len(matches) == len(exp)
+    for (ia, da), (ib, db) in zip(matches, exp):
+        assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    score = evaluate.homography_scorer(H, 5.0, query_is_source=False)
+    idx = np.array([m[0] for m in matches])
+    p = np.array([m[1]["positions"] for m in matches]).reshape(-1, 2, 2)
+    good = score(idx, p, None)
+    with capsys.disabled():
+        print("\n[graf img1-img4, cv2 SIFT, tau 0.7] %d keypoints/query image, %d matches, %d within 5 px of H1to4p = precision %.3f"
+              % (len(dq), len(matches), int(good.sum()), float(good.mean()) if len(good) else 0.0))

@@ -685,3 +685,72 @@ def test_float32_delegated_round_on_the_last_cell_of_the_bank(ctx, monkeypatch, 
         ctx.set_option("f32_filter", old)
     _same_matches(got, host)
     assert ds["rounds"] == hs["rounds"] and len(got) > 100
+
+
+def _same_log(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x["query_pos"], y["query_pos"]) and np.array_equal(x["target_pos"], y["target_pos"])
+        assert x["target_grid"] == y["target_grid"] and x["radius"] == y["radius"] and x["margin"] == y["margin"]
+        assert np.array_equal(x["matches"], y["matches"]) and np.array_equal(x["ratios"], y["ratios"])
+        assert np.asarray(x["matches"]).shape == np.asarray(y["matches"]).shape
+
+
+@pytest.mark.parametrize("size,n,opts", [
+    ((800, 640), 3000, {}),
+    ((611, 389), 2500, {"grid_size": (64, 48), "grid_margin": 0, "radius": 75}),
+    ((1000, 1000), 12500, {"radius": 140}),                   # rounds beyond 512 slots: the compacted accepted list
+])
+def test_log_is_written_by_the_device_loop(ctx, size, n, opts):
+    """options["log"] (the README's flow, README.md:47-49; fastmatch.pyx:79-80, 172-180) no longer sends a run to the
+    host loop: the kernel records every processed round and the records rebuilt from it equal the host loop's and the
+    oracle's entry by entry -- including Grid_Cache.last going stale once every visited cell is cached (second threshold
+    on the same closure) and rounds on cells without features."""
+    mc, fi, oq, ot = _build(size, n, seed=size[1] + n, ctx=ctx)
+    dlog, hlog, olog, ds, hs = [], [], [], {}, {}
+    get = fastmatch.match(mc, fi, dict(opts, log=dlog, context=ctx, stats=ds))
+    hget = fastmatch.match(mc, fi, dict(opts, log=hlog, context=ctx, stats=hs, device_loop=False))
+    oget = fo.o_match(oq, ot, dict(opts, log=olog))
+    for tau in (0.8, 0.6):
+        got, host, exp = get(tau), hget(tau), oget(tau)
+        _same_matches(got, host)
+        _same_matches(got, exp)
+        assert "device_fallbacks" not in ds
+    assert ds["device_loops"] == 2 and len(dlog) == ds["rounds"] == hs["rounds"] > 20
+    _same_log(dlog, hlog)
+    _same_log(dlog, olog)
+    assert any(len(e["ratios"]) > 0 for e in dlog)
+
+
+def test_log_of_several_thresholds_in_one_launch_and_growing_log_arrays(ctx):
+    """A list of thresholds = several runs of one pair in ONE launch, each with a log of its own, appended in the list's
+    order; log arrays that start far too small (8 records) grow until the run fits."""
+    mc, fi, oq, ot = _build((800, 640), 3000, seed=77, ctx=ctx)
+    dlog, hlog, ds = [], [], {}
+    get = fastmatch.match(mc, fi, {"log": dlog, "context": ctx, "stats": ds})
+    get.expander().set_log(True, first_capacity=8)
+    hget = fastmatch.match(mc, fi, {"log": hlog, "context": ctx, "device_loop": False})
+    taus = [0.9, 0.5, 0.7]
+    got = get(taus)
+    host = [hget(t) for t in taus]
+    for g, h in zip(got, host):
+        _same_matches(g, h)
+    assert ds["device_loops"] == 3 and "device_fallbacks" not in ds
+    _same_log(dlog, hlog)
+
+
+def test_log_on_clustered_keypoints_with_delegated_rounds(ctx):
+    """Chunked rounds (subsets beyond the LDS tables) and rounds parked for the dense kernels keep the log in step:
+    the records of a clustered pair equal the host loop's."""
+    q, t = synth.image_pair((1200, 900), 40000, seed=4242, p=0.15, n_thumb=900, clusters=2, cluster_sigma=50.0, cluster_frac=0.5)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"], t["thumb_descriptors"], t["thumb_size"])
+    dlog, hlog, ds, hs = [], [], {}, {}
+    ctx.set_option("delegated_rounds", 0)
+    got = fastmatch.match(mc, fi, {"log": dlog, "context": ctx, "stats": ds})(0.7)
+    assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds and ctx.get_option("delegated_rounds") > 0
+    host = fastmatch.match(mc, fi, {"log": hlog, "context": ctx, "stats": hs, "device_loop": False})(0.7)
+    _same_matches(got, host)
+    _same_log(dlog, hlog)
+    assert max(len(e["ratios"]) for e in dlog) > 512
