@@ -401,8 +401,8 @@ def leg_fresh_pair(ctx, Q, T, rank, resident_counts, steps=8):
     distances): per step 12 new pairs go upload -> Metric_Cache self distances -> X1 + R1 + compaction, pipelined:
       fm_bank_refill_u8_async  24 banks of 100k rows from page-locked host memory into one of two resident bank sets,
                                on the upload stream, beside the previous step's kernels (no allocation, no host sync)
-      fm_upload_fence + fm_self_dist_batch   the 12 query banks' self distances in ONE launch of the masked-diagonal
-                               top-1 sweep, attached on the device
+      fm_upload_fence + fm_self_dist_batch   the 12 query banks' self distances in TWO launches of the triangular top-1
+                               sweep (diagonal blocks, then the rest: every distance once), attached on the device
       fm_match_accepted_batch  the headline's step on the refilled banks
     two steps in flight (fm_mark / fm_wait).  Checked: every pair's accepted count equals the resident run's.  Beside it
     the naive flow a caller without the pipeline runs per pair (two fm_bank_create_u8, fm_self_dist,
@@ -492,11 +492,13 @@ def leg_fresh_pair(ctx, Q, T, rank, resident_counts, steps=8):
             "steps": steps, "ms_per_image_pair": ms_pair, "image_pairs_per_s": 1e3 / ms_pair,
             "descriptor_pairs_per_s": 2.0 * float(NQ) * NT / (ms_pair * 1e-3),
             "frac_int8_mfma_peak_over_2e10_pairs": ops / (ms_pair * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
+            "frac_note": "r05: the self sweep is triangular and EVALUATES ~0.51e10 of its 1e10 pairs, so this figure (2e10 pairs a new image "
+                         "pair gets, per second, over the peak) is a rate of useful results, not an MFMA utilisation: see self_2nn and roofline",
             "distance_kernel_ms_per_image_pair": st["kernel_ms"] / (steps * n),
             "upload_alone_ms_per_image_pair": up_ms, "upload_gb_per_s": 2 * NQ * 128 / (up_ms * 1e-3) / 1e9,
             "naive_flow_ms_per_image_pair": naive_ms, "accepted_counts_equal_resident_run": bool(same),
-            "note": "pipelined: fm_bank_refill_u8_async (upload stream) + fm_upload_fence + fm_self_dist_batch (one launch for the "
-                    "12 query banks, masked-diagonal top-1) + fm_match_accepted_batch; naive: fm_bank_create_u8 x 2, fm_self_dist, "
+            "note": "pipelined: fm_bank_refill_u8_async (upload stream) + fm_upload_fence + fm_self_dist_batch (two launches for the "
+                    "12 query banks: triangular top-1 sweep) + fm_match_accepted_batch; naive: fm_bank_create_u8 x 2, fm_self_dist, "
                     "fm_bank_set_selfdist, fm_match_accepted per pair, each synchronous; distance_kernel_ms = both sweeps"}
 
 
@@ -735,12 +737,24 @@ def main():
                "frac_int8_mfma_peak": float(NQ) * NT * OPS_PER_PAIR / (ctx.stats()["kernel_ms"] / reps * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12),
                "note": "fm_knn2_ratio: K2 top-2 + Lowe ratio + compaction, same banks"}
 
-    # Metric_Cache build (fm_self_dist = self 2-NN, K2): the single call timed during set-up (between bank uploads,
-    # clock still ramping) and, for the kernel's own rate, the mean of ten back-to-back calls
+    # Metric_Cache build (fm_self_dist): the single call timed during set-up (between bank uploads, clock still ramping)
+    # and, for the kernel's own rate, the mean of ten back-to-back calls.  r05: the sweep is TRIANGULAR (d(i, j) = d(j, i):
+    # every tile above the diagonal is computed once and serves both of its rows), so the matrix cores evaluate about half
+    # of the n x n pairs the caller gets -- both figures are reported, the fraction of the MFMA roof over the EVALUATED ones.
+    from fastmatch_amd import _ffi
+    tri_table, _, tri_stages = _ffi.self_dist_plan(((NQ + 127) // 128) * 128)
+    evaluated = float((tri_table[:, 2] - tri_table[:, 1]).sum()) * 128.0 * 512.0       # stages x rows per stage x output rows per workgroup
+    tri_on = ctx.get_option("self_tri") == 1 and NQ >= 32768 - 127
+    if not tri_on:
+        evaluated = float(NQ) * NQ
     self2 = {"pairs_per_s": float(NQ) * NQ / (self_kernel_ms * 1e-3), "kernel_ms": self_kernel_ms, "wall_s": self_s,
-             "kernel": "fm::rowreduce_kernel<4,1,true,8,3,1,true> (K1's top-1 kernel, diagonal masked; r01-r03: the top-2 kernel)",
+             "kernel": ("fm::rowreduce_tri_kernel<1> (K1's top-1 body, triangular: launch A = the masked diagonal blocks, launch B = the "
+                        "rest, both directions of every tile; %d stages per workgroup)" % tri_stages) if tri_on else
+                       "fm::rowreduce_kernel<4,1,true,8,3,1,true> (K1's top-1 kernel, diagonal masked)",
+             "distance_evaluations": evaluated, "evaluated_fraction_of_n_squared": evaluated / (float(NQ) * NQ),
              "note": "Metric_Cache build, 100k x 100k self distances = min over j != i (the second entry of the self 2-NN), outside the "
-                     "timed region; kernel_ms = one call during set-up, kernel_ms_steady = mean of 10 back-to-back calls"}
+                     "timed region; kernel_ms = one call during set-up, kernel_ms_steady = mean of 10 back-to-back calls; pairs_per_s "
+                     "counts the n x n pairs the caller asked for, frac_int8_mfma_peak_steady the distance evaluations the kernel made"}
     if rank == 0 and legs:
         ctx.self_dist(qb)
         ctx.reset_stats()
@@ -748,7 +762,17 @@ def main():
             ctx.self_dist(qb)
         s2 = ctx.stats()
         self2["kernel_ms_steady"] = s2["kernel_ms"] / max(s2["kernel_launches"], 1)
-        self2["frac_int8_mfma_peak_steady"] = float(NQ) * NQ * OPS_PER_PAIR / (self2["kernel_ms_steady"] * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12)
+        self2["pairs_per_s_steady"] = float(NQ) * NQ / (self2["kernel_ms_steady"] * 1e-3)
+        self2["frac_int8_mfma_peak_steady"] = evaluated * OPS_PER_PAIR / (self2["kernel_ms_steady"] * 1e-3) / (INT8_DENSE_PEAK_TOPS * 1e12)
+        if tri_on:                                           # the masked full sweep of r04 beside it, same box, same process
+            ctx.set_option("self_tri", 0)
+            ctx.self_dist(qb)
+            ctx.reset_stats()
+            for _ in range(10):
+                ctx.self_dist(qb)
+            s3 = ctx.stats()
+            ctx.set_option("self_tri", 1)
+            self2["kernel_ms_steady_full_sweep"] = s3["kernel_ms"] / max(s3["kernel_launches"], 1)
 
     # ONE configs[1] call, the way a caller without a batch makes it: fm_match_accepted (K1 + election +
     # ratio test + compaction into page-locked buffers) and its synchronisation, 20 repetitions.

@@ -91,6 +91,8 @@ SYMBOLS = {
     "fm_bank_create_u8_gather": (_INT, [_P, _P, _I64, _INT, _P, _I64, ctypes.POINTER(_P)]),
     "fm_bank_create_f32_gather": (_INT, [_P, _P, _I64, _INT, _INT, _P, _I64, ctypes.POINTER(_P)]),
     "fm_bank_append_u8": (_INT, [_P, _P, _P, _I64, ctypes.POINTER(_I64)]),
+    "fm_bank_create_f32_cap": (_INT, [_P, _INT, _I64, _P, ctypes.POINTER(_P)]),
+    "fm_bank_append_f32": (_INT, [_P, _P, _P, _I64, ctypes.POINTER(_I64)]),
     "fm_expand_set_cell": (_INT, [_P, _P, ctypes.c_int32, _I64, _I64, _P]),
     "fm_expand_run_lazy": (_INT, [_P, _P, _P, _I64, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
                            ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
@@ -281,6 +283,15 @@ class Bank(object):
     def append(self, rows):
         """More uint8 rows into a bank made with room for them (``Context.bank_with_capacity``), placed at the next
         multiple of 32 rows; returns the index of the first one."""
+        if self.kind == FM_BANK_F32:            # a growing float32-route bank (Context.bank_f32_with_capacity)
+            a = np.ascontiguousarray(rows, dtype=np.float32)
+            if a.ndim != 2 or a.shape[1] != self.dim:
+                raise ValueError("rows must be [n, %d]" % self.dim)
+            first = _I64(0)
+            self.ctx._check(self.ctx.lib.fm_bank_append_f32(self.ctx.handle, self.handle, _ptr(a), a.shape[0], ctypes.byref(first)))
+            if a.shape[0]:
+                self.n = int(first.value) + a.shape[0]
+            return int(first.value)
         a = np.ascontiguousarray(rows)
         if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != self.dim:
             raise ValueError("rows must be [n, %d] uint8" % self.dim)
@@ -533,6 +544,13 @@ class Context(object):
         n, dim, kind = _I64(), _INT(), _INT()
         self._check(self.lib.fm_bank_info(h, ctypes.byref(n), ctypes.byref(dim), ctypes.byref(kind)))
         return Bank(self, h, n.value, dim.value, kind.value)
+
+    def bank_f32_with_capacity(self, dim, capacity, scale_like):
+        """An empty float32-route bank with room for ``capacity`` rows whose fp16 planes use ``scale_like``'s scale
+        (``Bank.append`` takes float32 rows): the growing target bank of a lazy pair with non-integer descriptors."""
+        h = _P()
+        self._check(self.lib.fm_bank_create_f32_cap(self.handle, int(dim), int(capacity), scale_like.handle, ctypes.byref(h)))
+        return Bank(self, h, 0, int(dim), FM_BANK_F32)
 
     # -- operators -----------------------------------------------------------------------
     def knn2(self, q, t):

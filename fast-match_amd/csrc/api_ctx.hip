@@ -813,6 +813,121 @@ extern "C" int fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows
     return FM_OK;
 }
 
+// ---- a float32-route bank that grows (r05: lazy targets with descriptors that are not integer valued) -----------------
+// Rows of the new range: largest magnitude (float bits) in stat[0], stat[1] |= 1 for a value that is not finite.
+__global__ __launch_bounds__(256)
+void bank_append_f32_kernel(const float* __restrict__ src, int64_t n, int dim, float* __restrict__ dst, int* __restrict__ stat)
+{
+    float m = 0.f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * kDim; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kDim;
+        const int k = (int)(i % kDim);
+        const float v = k < dim ? src[row * dim + k] : 0.f;
+        dst[i] = v;
+        bad |= !(fabsf(v) <= 3.0e38f);
+        m = fmaxf(m, fabsf(v));
+    }
+#pragma unroll
+    for (int mask = 1; mask < 64; mask <<= 1) m = fmaxf(m, __shfl_xor(m, mask));
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) { if ((threadIdx.x & 63) == 0) atomicOr(stat + 1, 1); }
+    else if ((threadIdx.x & 63) == 0) atomicMax(stat, (int)__float_as_uint(m));
+}
+
+// An EMPTY float32-route bank with room for `capacity` rows.  The fp16 planes of a bank are scaled by ONE power of two
+// chosen from the bank's largest magnitude (filter_f16.hip); a bank that grows cannot know its own, so it takes the
+// scale of `scale_like` -- the bank it will be matched against (the query image's: same extractor, same value range).
+// Every row is prepared as a padding row; fm_bank_append_f32 turns ranges of them into real ones.
+extern "C" int fm_bank_create_f32_cap(fm_ctx* ctx, int dim, int64_t capacity, const fm_bank* scale_like, fm_bank** out)
+{
+    if (!ctx) return fail(nullptr, FM_EINVAL, "fm_bank_create_f32_cap: ctx is NULL");
+    if (!out) return fail(ctx, FM_EINVAL, "fm_bank_create_f32_cap: bank out pointer is NULL");
+    *out = nullptr;
+    if (dim < 1 || dim > kDim || capacity < 1 || capacity > (int64_t)INT32_MAX - 2 * kStageRows)
+        return fail(ctx, FM_EINVAL, "fm_bank_create_f32_cap: bad dim / capacity");
+    if (!scale_like || scale_like->kind != FM_BANK_F32 || !scale_like->filt_ok)
+        return fail(ctx, FM_EINVAL, "fm_bank_create_f32_cap: scale_like must be a float32-route bank of finite values");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fm_bank* b = new (std::nothrow) fm_bank();
+    if (!b) return fail(ctx, FM_ENOMEM, "fm_bank_create_f32_cap: out of host memory");
+    b->kind = FM_BANK_F32;
+    b->n = 0;
+    b->dim = dim;
+    b->n_pad = kStageRows;
+    b->cap_pad = ((capacity + kStageRows - 1) / kStageRows) * kStageRows;
+    b->kscale = scale_like->kscale;
+    b->filt_ok = true;
+    b->nm_max = 0.f;
+    auto bail = [&](hipError_t e, const char* what) {
+        (void)hipGetLastError();
+        bank_free(b); delete b;
+        return fail(ctx, e == hipErrorOutOfMemory ? FM_ENOMEM : FM_EDEVICE, std::string("fm_bank_create_f32_cap: ") + what + ": " + hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&b->rowsf, (size_t)b->cap_pad * kDim * 4)) != hipSuccess) return bail(e, "rows");
+    if ((e = hipMalloc((void**)&b->rowsh, (size_t)b->cap_pad * kDim * 2)) != hipSuccess) return bail(e, "fp16 rows");
+    if ((e = hipMalloc((void**)&b->normf, (size_t)b->cap_pad * 4)) != hipSuccess) return bail(e, "norms");
+    if ((e = hipMalloc((void**)&b->auxf, (size_t)b->cap_pad * 4)) != hipSuccess) return bail(e, "aux");
+    if ((e = hipMemsetAsync(b->rowsf, 0, (size_t)b->cap_pad * kDim * 4, ctx->stream)) != hipSuccess) return bail(e, "fill");
+    int rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, 64);
+    if (rc != FM_OK) { bank_free(b); delete b; return rc; }
+    // (n = 0: every row comes out as a padding row -- zero fp16 row, norm 0, accumulator init -3.4e38)
+    hipLaunchKernelGGL(bank_prep_f16_kernel, dim3((unsigned)(b->cap_pad / 16)), dim3(256), 0, ctx->stream,
+                       (const float*)b->rowsf, (int64_t)0, b->cap_pad, b->kscale, b->rowsh, b->normf, b->auxf, (int*)ctx->ws_in);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "prepare");
+    *out = b;
+    return FM_OK;
+}
+
+// n more rows at the next multiple of 32 rows, as fm_bank_append_u8.  FM_EUNSUPPORTED (the bank unchanged, its rows past
+// bank->n rewritten as padding) when a value is not finite or, scaled by the bank's fixed power of two, leaves fp16's range.
+extern "C" int fm_bank_append_f32(fm_ctx* ctx, fm_bank* bank, const float* rows, int64_t n, int64_t* first_row)
+{
+    if (!ctx || !bank) return fail(ctx, FM_EINVAL, "fm_bank_append_f32: NULL argument");
+    if (bank->kind != FM_BANK_F32 || !bank->rowsf || !bank->rowsh || bank->cap_pad <= 0)
+        return fail(ctx, FM_EINVAL, "fm_bank_append_f32: not a float32-route bank with capacity (fm_bank_create_f32_cap)");
+    if (n < 0 || (n > 0 && !rows)) return fail(ctx, FM_EINVAL, "fm_bank_append_f32: bad rows / n");
+    const int64_t off = ((bank->n + kTileRows - 1) / kTileRows) * kTileRows;
+    if (first_row) *first_row = off;
+    if (n == 0) return FM_OK;
+    if (off + n > bank->cap_pad) return fail(ctx, FM_EINVAL, "fm_bank_append_f32: the bank's capacity is used up");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t src_bytes = (size_t)n * bank->dim * 4, flag_off = (src_bytes + 15) & ~(size_t)15;
+    int rc = ws_ensure(ctx, &ctx->ws_in, &ctx->ws_in_bytes, flag_off + 32);
+    if (rc != FM_OK) return rc;
+    int* d_flag = (int*)((char*)ctx->ws_in + flag_off);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, rows, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, 16, ctx->stream));
+    float* dst = bank->rowsf + (size_t)off * kDim;
+    hipLaunchKernelGGL(bank_append_f32_kernel, dim3((unsigned)std::min<int64_t>(1024, (n * kDim + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float*)ctx->ws_in, n, bank->dim, dst, d_flag);
+    HIP_TRY(ctx, hipGetLastError());
+    int stat[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(stat, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float vmax = 0.f;
+    memcpy(&vmax, &stat[0], 4);
+    const int64_t n16 = ((n + 15) / 16) * 16;                 // (the range's rows up to a multiple of 16: padding again)
+    const bool ok = stat[1] == 0 && ldexpf(vmax, bank->kscale) < 60000.f;
+    HIP_TRY(ctx, hipMemsetAsync(d_flag + 2, 0, 8, ctx->stream));
+    if (!ok) HIP_TRY(ctx, hipMemsetAsync(dst, 0, (size_t)n * kDim * 4, ctx->stream));
+    hipLaunchKernelGGL(bank_prep_f16_kernel, dim3((unsigned)(n16 / 16)), dim3(256), 0, ctx->stream,
+                       (const float*)dst, ok ? n : (int64_t)0, n16, bank->kscale, bank->rowsh + (size_t)off * kDim, bank->normf + off,
+                       bank->auxf + off, d_flag + 2);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(stat, d_flag + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ok)
+        return fail(ctx, FM_EUNSUPPORTED, "fm_bank_append_f32: a value is not finite or leaves the fp16 range under the bank's scale (2^" +
+                                          std::to_string(bank->kscale) + "): the growing bank cannot take these rows");
+    float nmx = 0.f;
+    memcpy(&nmx, &stat[0], 4);
+    if (nmx > bank->nm_max) bank->nm_max = nmx;
+    bank->n = off + n;
+    bank->n_pad = ((bank->n + kStageRows - 1) / kStageRows) * kStageRows;
+    return FM_OK;
+}
+
 extern "C" int fm_bank_create_f32(fm_ctx* ctx, const float* rows, int64_t n, int dim, fm_bank** bank)
 {
     return bank_create(ctx, rows, n, dim, true, bank);

@@ -195,7 +195,7 @@ extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand*
     if (d->rows > 65535 || d->cols > 65535 || d->width > 65535 || d->height > 65535)
         return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: image or grid too large for 16-bit cell keys");
     const bool lazy = d->lazy != 0;
-    if (lazy && (f32 || d->target->cap_pad <= 0)) return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: lazy targets need an integer-route target bank (fm_bank_create_u8_cap)");
+    if (lazy && d->target->cap_pad <= 0) return fail(ctx, FM_EUNSUPPORTED, "fm_expand_create: lazy targets need a target bank with capacity (fm_bank_create_u8_cap / fm_bank_create_f32_cap)");
     if ((nq > 0 && (!d->query_pos || !d->index_order)) || !d->index_start || (!lazy && (!d->cell_off || (nt > 0 && !d->target_pos))))
         return fail(ctx, FM_EINVAL, "fm_expand_create: NULL array");
     const int64_t nb = (int64_t)d->index_nbx * d->index_nby;
@@ -339,14 +339,20 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
     expand_bind_run(host, *r, ex);
     host.seeds = r->d_seeds; host.n_seeds = n_seeds; host.tau = tau; host.prof = 0;
     host.resume = resume ? 1 : 0;
-    host.tie_guard = sqrt_tie_possible(*ex->query, *ex->lazy_target) ? 1 : 0;     // (the target bank has grown since the pair was made)
+    const bool f32 = ex->query->kind == FM_BANK_F32;
+    // (the target bank has grown since the pair was made: the float32-root guard / the float32 round's scale terms are re-derived)
+    host.tie_guard = (!f32 && sqrt_tie_possible(*ex->query, *ex->lazy_target)) ? 1 : 0;
+    if (f32) {
+        if (!filter_usable(*ex->lazy_target, *ex->query)) return fail(ctx, FM_EUNSUPPORTED, "fm_expand_run_lazy: the growing float32 bank lost its fp16 planes");
+        fill_round_f32(&host.rf, *ex->query, *ex->lazy_target);
+    }
     // big rounds' cross-checks go to the dense kernels, as in fm_expand_run: the run parks with status 8 and is resumed here
     host.delegate_min = host.tie_guard ? 0 : ctx->tune.expand_delegate;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     long long res[16] = {0};
     for (int grown = 0;;) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, false, 3, ctx->stream));
+        HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, f32, 3, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

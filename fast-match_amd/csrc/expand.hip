@@ -366,7 +366,7 @@ template <bool F32, int CAND = kExpCand, bool HUGE = false, bool LAZY = false>
 __global__ __launch_bounds__(kExpThreads)
 void expand_kernel(const ExpandPair* __restrict__ pairs)
 {
-    static_assert(!LAZY || (!F32 && HUGE && CAND == kExpCand), "the lazy-target variant is built on the chunked int8 kernel");
+    static_assert(!LAZY || (HUGE && CAND == kExpCand), "the lazy-target variants are built on the chunked kernels");
     using C = ExpCfg<CAND>;
     static_assert(!F32 || CAND == kExpCand, "the float32 round needs the 512-row stage buffer");
     static_assert(!HUGE || CAND == kExpCand, "the chunked round exists for the first capacity variant");
@@ -1235,7 +1235,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 }
 
 // tier: 0 = the 2048-row kernel, 1 = the 4096-row one (int8), 2 = the chunked one (int8 without the float32-root guard, float32),
-// 3 = the lazy-target variant of tier 2 (int8)
+// 3 = the lazy-target variant of tier 2 (int8, and since r05 float32)
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream)
 {
     static bool attr_set = false;
@@ -1245,15 +1245,16 @@ hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, h
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCand, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<true, kExpCand>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCand>::kLdsBytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)expand_kernel<false, kExpCandBig>, hipFuncAttributeMaxDynamicSharedMemorySize, ExpCfg<kExpCandBig>::kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (f32 && tier == 1) return hipErrorInvalidValue;
-    if (tier == 3) {           // lazy targets (int8; the chunked kernel, so a radius subset of any size stays on the device)
-        if (f32) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((expand_kernel<false, kExpCand, true, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+    if (tier == 3) {           // lazy targets (the chunked kernels, so a radius subset of any size stays on the device)
+        if (f32) hipLaunchKernelGGL((expand_kernel<true, kExpCand, true, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
+        else     hipLaunchKernelGGL((expand_kernel<false, kExpCand, true, true>), dim3(n_pairs), dim3(kExpThreads), ExpCfg<kExpCand>::kLdsBytes, stream, (const ExpandPair*)d_pairs);
         return hipGetLastError();
     }
     if (tier == 2 && f32) {

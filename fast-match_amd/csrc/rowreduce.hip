@@ -271,10 +271,19 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     static_assert(!SELF || KTOP == 1, "the masked-diagonal sweep is a top-1");
     static_assert(!TRI || (SELF && NBUF == 3 && NW == 8 && NC == 4), "the triangular sweep is built for one shape");
     constexpr int kStride = TRI ? kStageBytesTri : kStageBytes;     // bytes of one LDS stage buffer
+    // SW ("scalar wave"): the wave number is made wave-uniform up front, the LDS-DMA goes through a scalar base + one
+    // 32-bit lane offset (issue_stage_u8) and the shared bounds through a scalar base + immediates -- the registers that
+    // the compiler's 64-bit address pairs take are what the top-2 kernel spills (r05: 5 spilled VGPRs with two stage
+    // buffers, 10 with three -> 0)
+#ifdef FM_K1_SW          // (A/B builds: the top-1 kernel in the same mode)
+    constexpr bool SW = TRI || (NW == 8 && GLDS && NC == 4);
+#else
+    constexpr bool SW = TRI || (KTOP == 2 && NW == 8 && GLDS && NC == 4);
+#endif
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = TRI ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    const int wave = SW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int g    = lane >> 4;          // lane group: rows 4g .. 4g+3 of every 16-row tile
     const unsigned dma_lo = 128u * (lane >> 3) + 16u * ((lane & 7) ^ (lane >> 4));      // (TRI: issue_stage_u8)
     const int c16  = lane & 15;
@@ -393,9 +402,9 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     }
     // prologue prefetch (issued AFTER the bound loads: vmcnt retires in order, so "at most the newest
     // stage's DMA outstanding" implies that the bound loads and every older DMA have landed)
-    if constexpr (TRI) {
+    if constexpr (SW) {
         if (st0 < st1) issue_stage_u8(p, st0, smem, wave, lane, dma_lo);
-        if (st0 + 1 < st1) issue_stage_u8(p, st0 + 1, smem + kStride, wave, lane, dma_lo);
+        if constexpr (NBUF == 3) { if (st0 + 1 < st1) issue_stage_u8(p, st0 + 1, smem + kStride, wave, lane, dma_lo); }
     } else {
         if (st0 < st1) issue_stage<GLDS, NW>(p, st0, smem, wave, lane);
         if constexpr (NBUF == 3) {
@@ -454,7 +463,8 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
             }
         }
         if constexpr (NBUF == 2) {
-            if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStride, wave, lane);
+            if constexpr (SW) { if (st + 1 < st1) issue_stage_u8(p, st + 1, smem + (BUF ^ 1) * kStride, wave, lane, dma_lo); }
+            else if (st + 1 < st1) issue_stage<GLDS, NW>(p, st + 1, smem + (BUF ^ 1) * kStride, wave, lane);
         }
         if constexpr (TRI) {
             // the words requested at the previous hand-over (LDS-DMA older than the one that wait left in flight, so they
@@ -493,7 +503,13 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int n = cb + 16 * j + c16;
-                if constexpr (NBUF == 3) {
+                if constexpr (NBUF == 3 && SW) {
+                    const unsigned boff = (unsigned)(cb + c16) * 4u;
+                    if (j == 0) load_word_untracked_s<0>(gnext[0], bound_thr, boff);
+                    if (j == 1) load_word_untracked_s<64>(gnext[1], bound_thr, boff);
+                    if (j == 2) load_word_untracked_s<128>(gnext[2], bound_thr, boff);
+                    if (j == 3) load_word_untracked_s<192>(gnext[3], bound_thr, boff);
+                } else if constexpr (NBUF == 3) {
                     // (ncols_alloc is a multiple of the chunk, so n is always inside the array)
                     load_bound_untracked(gnext[j], bound_thr + n);
                 } else {
@@ -504,7 +520,7 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         }
         if constexpr (NBUF == 3) {
             // (after the bound loads, see the prologue) into the buffer every wave left at the barrier above
-            if constexpr (TRI) { if (st + 2 < st1) issue_stage_u8(p, st + 2, smem + ((BUF + 2) % 3) * kStride, wave, lane, dma_lo); }
+            if constexpr (SW) { if (st + 2 < st1) issue_stage_u8(p, st + 2, smem + ((BUF + 2) % 3) * kStride, wave, lane, dma_lo); }
             else if (st + 2 < st1) issue_stage<GLDS, NW>(p, st + 2, smem + ((BUF + 2) % 3) * kStride, wave, lane);
         }
 
@@ -935,12 +951,14 @@ RowReducePlan plan_rowreduce(int64_t ncols_pad, int64_t nred_pad, const Tuning& 
     return pl;
 }
 
-// stage buffers: 3 for the top-1 kernel (its DMA wait leaves the hand-over), 2 for top-2 (at the
-// 128-VGPR limit the third buffer's bookkeeping spills); the plan (Tuning::nbuf) overrides
-static int nbuf_choice(int ktop, int plan_nbuf)
+// stage buffers: 3 for the top-1 kernel (its DMA wait leaves the hand-over) and, since r05, for the top-2 kernel in its
+// built-in shape (4 blocks per wave: the scalar-wave addressing, SW in rowreduce_body, freed the registers whose spills
+// made the third buffer a loss -- A/B on one box: 1.051 -> 0.983 ms per 100k x 100k pair, profiles/r05f_k2_nbuf_ab.log);
+// 2 for the other top-2 shapes; the plan (Tuning::nbuf) overrides
+static int nbuf_choice(int ktop, int plan_nbuf, int nc = 4)
 {
     if (plan_nbuf == 2 || plan_nbuf == 3) return plan_nbuf;
-    return ktop == 1 ? 3 : 2;
+    return (ktop == 1 || nc == 4) ? 3 : 2;
 }
 
 // The masked-diagonal top-1 (fm_self_dist): 16 x 4 output rows per wave only (the unit test in the sweep
@@ -967,7 +985,7 @@ static hipError_t launch_t(const RRParams& p, int grid, bool glds, int plan_nbuf
         // PRIO: s_setprio 2 while a wave issues a unit's 16 MFMAs as one burst, back to 0 for the
         // epilogue (A/B on one box: 0.897 -> 0.887 ms); Tuning::prio = 0 selects the variant without it.
         // (The two-buffer top-2 kernel gets 1 % slower with it: 1.034 -> 1.044 ms.)
-        if (glds && nbuf_choice(KTOP, plan_nbuf) == 3) {
+        if (glds && nbuf_choice(KTOP, plan_nbuf, NC) == 3) {
             if (prio) hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 1>), dim3(grid), dim3(64 * NW), 0, stream, p);
             else      hipLaunchKernelGGL((rowreduce_kernel<NC, KTOP, true, NW, 3, 0>), dim3(grid), dim3(64 * NW), 0, stream, p);
             return hipGetLastError();

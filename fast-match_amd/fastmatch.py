@@ -17,8 +17,8 @@ SURVEY.md fact 9): for a ``cache.Feature_Image`` target (every feature known up 
 launch per call, any number of (pair, threshold) runs side by side; for the reference's PIXEL
 target, whose cells are computed when the loop first reaches them (cache.pyx:102-106, 124-138), the
 kernel parks at a missing cell and the host computes it and resumes (``lazy_device_loop``).  A per-round
-``log`` (the README's flow) is written by the kernel too (r05).  Only when the descriptors are float32 with
-a pixel target or a capacity of the device loop is exceeded does the host replay the loop (``do_iter``): each round's arithmetic --
+``log`` (the README's flow) is written by the kernel too, and float32 descriptors on a pixel target stay on the
+device as well (r05).  Only when a capacity of the device loop is exceeded does the host replay the loop (``do_iter``): each round's arithmetic --
 OpenCV's ``BFMatcher(NORM_L2, crossCheck=True).knnMatch`` plus the float64 ratio -- is then one launch
 of the HIP round kernel on banks that stay resident (the query bank with its self distances, one bank
 per computed grid cell); the radius subset's row indices go up, (train index, distance, ratio) come back.
@@ -112,9 +112,11 @@ def match(query_cache, target_img, options={}):
                         ex.set_cell(need, 0, np.zeros((0, 2)))
                     else:
                         ds = np.asarray(ds)
-                        if ds.dtype != np.uint8:
+                        if t_bank.kind == _ffi.FM_BANK_F32:
+                            ds = ds.astype(np.float32, copy=False)              # the float32 route takes any finite values
+                        elif ds.dtype != np.uint8:
                             u8 = ds.astype(np.uint8)
-                            if not np.array_equal(u8.astype(ds.dtype), ds):     # not integer valued: no int8 route
+                            if not np.array_equal(u8.astype(ds.dtype), ds):     # not integer valued, the query bank is: no int8 route
                                 state["lazy"] = False
                                 return None
                             ds = u8
@@ -269,13 +271,11 @@ def _expand_launch(context, expanders, seeds, taus):
 
 
 def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None):
-    """(expander, growing target bank) for a target whose cells are computed on demand, or False (float32 query bank,
-    oversize geometry).  ``capacity``: rows the target bank has room for; default 6 x the query's keypoints (a cell's
+    """(expander, growing target bank) for a target whose cells are computed on demand, or False (oversize geometry;
+    r05: a float32 query bank gets a growing float32-route target bank).  ``capacity``: rows the target bank has room for; default 6 x the query's keypoints (a cell's
     crop includes its margins: a keypoint lands in up to four cells) + 32 per cell (cells start at multiples of 32 rows)."""
     from . import _ffi
     q_bank = query_cache.bank(context)
-    if q_bank.kind != _ffi.FM_BANK_I8:
-        return False
     ncells = target_grid.rows * target_grid.cols
     if capacity is None:
         capacity = 6 * max(q_bank.n, 4096) + 32 * ncells + 4096
@@ -283,7 +283,10 @@ def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None)
             "cell_h": target_grid.cell_height, "rows": target_grid.rows, "cols": target_grid.cols,
             "margin": target_grid.margin}
     try:
-        t_bank = context.bank_with_capacity(np.zeros((0, q_bank.dim), dtype=np.uint8), int(capacity))
+        if q_bank.kind == _ffi.FM_BANK_I8:
+            t_bank = context.bank_with_capacity(np.zeros((0, q_bank.dim), dtype=np.uint8), int(capacity))
+        else:            # r05: descriptors that are not integer valued (RootSIFT-style): a growing float32-route bank
+            t_bank = context.bank_f32_with_capacity(q_bank.dim, int(capacity), q_bank)
         ex = _ffi.Expander(context, q_bank, query_cache.original["positions"], query_cache.original["position_tree"],
                            t_bank, None, None, grid, radius, lazy=True)
     except _ffi.FastMatchHipError:

@@ -367,7 +367,8 @@ typedef struct fm_expand_desc {
                                     * features are computed when the loop first reaches it).  `target` is a bank made with
                                     * fm_bank_create_u8_cap (possibly empty), cell_off / target_pos are ignored; cells are
                                     * added with fm_bank_append_u8 + fm_expand_set_cell and the pair is driven with
-                                    * fm_expand_run_lazy.  Integer-route banks.                                         */
+                                    * fm_expand_run_lazy.  Integer-route banks, or (r05) float32-route banks:
+                                    * target from fm_bank_create_f32_cap, cells added with fm_bank_append_f32.          */
 } fm_expand_desc;
 
 #define FM_METRIC_EUCLIDEAN 0      /* "minkowski" (p = 2), "euclidean": dx^2 + dy^2 <= r^2     */
@@ -424,6 +425,13 @@ int  fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, const double
  *                           (Rounds of >= "expand_delegate" descriptor pairs are cross-checked by the dense kernels inside the call.) */
 int  fm_bank_create_u8_cap(fm_ctx* ctx, const uint8_t* rows, int64_t n, int dim, int64_t capacity, fm_bank** bank);
 int  fm_bank_append_u8(fm_ctx* ctx, fm_bank* bank, const uint8_t* rows, int64_t n, int64_t* first_row);
+/* r05, the same for descriptors that are NOT integer valued (RootSIFT-style float32 on a pixel target): an empty float32-route
+ * bank with room for `capacity` rows whose fp16 planes use the power-of-two scale of `scale_like` (the query bank the target
+ * will be matched against: a growing bank cannot derive a scale from rows it has not seen), and n more rows at the next
+ * multiple of 32.  fm_bank_append_f32 returns FM_EUNSUPPORTED -- bank unchanged -- for a value that is not finite or that
+ * leaves fp16's range under that scale (more than ~4 x the largest magnitude of scale_like).                              */
+int  fm_bank_create_f32_cap(fm_ctx* ctx, int dim, int64_t capacity, const fm_bank* scale_like, fm_bank** bank);
+int  fm_bank_append_f32(fm_ctx* ctx, fm_bank* bank, const float* rows, int64_t n, int64_t* first_row);
 int  fm_expand_set_cell(fm_ctx* ctx, fm_expand* ex, int32_t cell, int64_t first_row, int64_t n_rows, const double* pos /*[n_rows][2]*/);
 int  fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seeds, int64_t n_seeds, double tau, int32_t resume,
                         int64_t* n_matches, int64_t* n_rounds, int64_t* n_pairs, int32_t* status, int32_t* need_cell);

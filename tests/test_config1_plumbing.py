@@ -378,3 +378,71 @@ def test_readme_flow_on_the_graf_pixels_with_real_sift(ctx, tmp_path, monkeypatc
     with capsys.disabled():
         print("\n[graf img1-img4, cv2 SIFT, tau 0.7] %d keypoints/query image, %d matches, %d within 5 px of H1to4p = precision %.3f"
               % (len(dq), len(matches), int(good.sum()), float(good.mean()) if len(good) else 0.0))
+
+
+@pytest.mark.gpu
+def test_pixel_target_with_float32_descriptors_stays_on_the_device(ctx, monkeypatch):
+    """RootSIFT-style (non-integer float32) descriptors on a PIXEL target (fastmatch.pyx:154 -> cache.pyx:102-106, 124-138):
+    until r05 the one combination that always took the host-driven loop.  The target bank is a growing float32-route bank
+    (fm_bank_create_f32_cap / fm_bank_append_f32, scaled like the query bank), the lazy kernel is the float32 chunked one:
+    device loop == host loop == oracle (the device's accumulation order), same cells computed, log included."""
+    from fastmatch_amd import cache, fastmatch, _ffi
+    from oracle import fastmatch_oracle as fo
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    img1 = texture(800, 640, seed=1)
+    mild = np.array([[1.0, 0.01, 18.0], [-0.008, 1.0, -11.0], [1e-5, -5e-6, 1.0]])
+    img4 = warp(img1, mild)
+
+    def feat(data):
+        kp, ds = standin.standin_features(data)
+        if ds is None or len(ds) == 0:
+            return kp, ds
+        d = np.asarray(ds, dtype=np.float32)
+        return kp, np.sqrt(d / np.maximum(d.sum(axis=1, keepdims=True), 1.0)).astype(np.float32)
+    kq, dq = feat(img4)
+    thumb_q = imaging.get_thumbnail(img4, (600, 600))
+    ktq, dtq = feat(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    mc = cache.Metric_Cache.from_arrays(dq, pos(kq), (800, 640), dtq, pos(ktq), (thumb_q.shape[1], thumb_q.shape[0]),
+                                        options={"context": ctx})
+    assert mc.bank(ctx).kind == _ffi.FM_BANK_F32
+    calls = {"dev": 0, "host": 0}
+
+    def counting(which):
+        def f(data):
+            calls[which] += 1
+            return feat(data)
+        return f
+    dlog, hlog, ds, hs = [], [], {}, {}
+    dev = fastmatch.match(mc, img1, {"context": ctx, "feature_function": counting("dev"), "stats": ds, "log": dlog})
+    host = fastmatch.match(mc, img1, {"context": ctx, "feature_function": counting("host"), "stats": hs, "log": hlog, "device_loop": False})
+    oq = fo.OQuery(dq, pos(kq), (800, 640), thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    thumb_t = imaging.get_thumbnail(img1, (400, 400))
+    ktt, dtt = feat(thumb_t)
+    ot = {"size": (800, 640), "image": img1, "feature_function": feat,
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    oget = fo.o_match(oq, ot, {})
+    for tau in (0.8, 0.95):
+        got, ref, exp = dev(tau), host(tau), oget(tau)
+        assert len(got) == len(ref) == len(exp) > 20
+        for (ia, da), (ib, db), (ic, dc) in zip(got, ref, exp):
+            assert ia == ib == ic and da["ratio"] == db["ratio"] == dc["ratio"]
+            assert np.array_equal(da["positions"], db["positions"]) and np.array_equal(da["positions"], dc["positions"])
+    assert ds.get("device_loops") == 2 and "device_fallbacks" not in ds and ds["rounds"] == hs["rounds"]
+    assert calls["dev"] == calls["host"] > 10
+    assert len(dlog) == len(hlog) == ds["rounds"]
+    for a, b in zip(dlog, hlog):
+        assert a["target_grid"] == b["target_grid"] and np.array_equal(a["matches"], b["matches"]) and np.array_equal(a["ratios"], b["ratios"])
+    # radius 300: subsets beyond the LDS tables (chunked float32 rounds), every cross-check delegated as well
+    keep = ctx.get_option("expand_delegate")
+    try:
+        for deleg in (keep, 1):
+            ctx.set_option("expand_delegate", deleg)
+            big = {}
+            wide = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat, "stats": big, "radius": 300})(0.8)
+            wexp = fo.o_match(oq, ot, {"radius": 300})(0.8)
+            assert big.get("device_loops") == 1 and "device_fallbacks" not in big and len(wide) == len(wexp) > 20
+            for (ia, da), (ib, db) in zip(wide, wexp):
+                assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
+    finally:
+        ctx.set_option("expand_delegate", keep)

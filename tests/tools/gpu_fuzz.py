@@ -148,8 +148,10 @@ def fuzz_match(rng):
     stats = {}
     # r04: big rounds park for a dense cross-check from this many descriptor pairs on (1 = every chunked round, 0 = never)
     ctx.set_option("expand_delegate", int(rng.choice([0, 1, 200000, 1500000])))
-    get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4))))
-    oget = fo.o_match(oq, ot, dict(opts))
+    # r05: every other problem asks for the per-round log (the kernel writes it; fastmatch.pyx:79-80, 172-180)
+    log, olog = ([], []) if seed % 2 == 0 else (None, None)
+    get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4)), log=log))
+    oget = fo.o_match(oq, ot, dict(opts, log=olog))
     taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
     tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else "u8")
     if rng.integers(0, 2) and len(taus) > 1:
@@ -161,6 +163,12 @@ def fuzz_match(rng):
         assert len(got) == len(exp), tag + (x, len(got), len(exp))
         for (ia, da), (ib, db) in zip(got, exp):
             assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"]), tag + (x,)
+    if log is not None:
+        assert len(log) == len(olog), tag + ("log", len(log), len(olog))
+        for a, b in zip(log, olog):
+            assert np.array_equal(a["query_pos"], b["query_pos"]) and np.array_equal(a["target_pos"], b["target_pos"]), tag + ("log",)
+            assert a["target_grid"] == b["target_grid"] and a["radius"] == b["radius"] and a["margin"] == b["margin"], tag + ("log",)
+            assert np.array_equal(a["matches"], b["matches"]) and np.array_equal(a["ratios"], b["ratios"]), tag + ("log",)
     return tag
 
 
