@@ -205,3 +205,48 @@ def test_growing_banks_refills_and_lazy_pairs_reject_misuse(ctx):
     with pytest.raises(Err):
         lazy.set_cell(0, 0, np.zeros((5, 2)))                   # rows the target bank does not hold
     assert lazy.run_lazy(np.zeros((0, 2, 2)), 0.7, False)[3] == 0        # no seeds: done at once
+
+
+def test_r05_entry_points_reject_misuse(ctx):
+    """r05: a resume of a run that is not parked (it would restore loop state nothing had saved), the growing
+    float32-route bank (scale source, range check, capacity), the log calls on a pair that writes none, fm_self_dist_plan."""
+    from fastmatch_amd import fastmatch, _ffi
+    rng = np.random.default_rng(9)
+    q, t = synth.image_pair((300, 200), 400, seed=6)
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    grid = fastmatch.Grid_Cache(np.zeros((200, 300, 3), np.uint8), (50, 50), None, margin=25)
+    lazy, tbank = fastmatch.make_lazy_expander(mc, grid, 100, ctx)
+    seeds = np.array([[[150.0, 100.0], [150.0, 100.0]]])
+    with pytest.raises(Err):
+        lazy.run_lazy(seeds, 0.7, True)                         # nothing is parked yet
+    nm, nr, npairs, status, need = lazy.run_lazy(seeds, 0.7, False)
+    assert status == _ffi.FM_EXPAND_NEED_CELL and need >= 0     # parked at the seed's cell
+    lazy.set_cell(need, 0, np.zeros((0, 2)))
+    assert lazy.run_lazy(seeds, 0.7, True)[3] == 0              # resumed and done (the cell has no features)
+    with pytest.raises(Err):
+        lazy.run_lazy(seeds, 0.7, True)                         # ... and a finished run cannot be resumed again
+    # log calls on a pair that writes none
+    with pytest.raises(Err):
+        lazy.fetch_log()
+    # growing float32-route bank
+    F = synth.synth_sift(200, rng).astype(np.float32) + 0.25
+    fq = ctx.bank(F)
+    with pytest.raises(Err):
+        ctx.bank_f32_with_capacity(128, 1000, ctx.bank(synth.synth_sift(10, rng)))      # the scale source must be a float32-route bank
+    g = ctx.bank_f32_with_capacity(128, 300, fq)
+    assert g.kind == _ffi.FM_BANK_F32 and g.n == 0
+    assert g.append(F[:50]) == 0 and g.append(F[50:87]) == 64 and g.n == 101
+    t1, d1 = ctx.xcheck1(fq, g)
+    whole = ctx.bank(np.concatenate([F[:50], F[50:87]]), float_route=True)
+    t2, d2 = ctx.xcheck1(fq, whole)
+    remap = np.r_[0:50, 64:101]
+    assert np.array_equal(np.where(t2 >= 0, remap[np.maximum(t2, 0)], -1), t1) and np.array_equal(d1, d2)
+    with pytest.raises(Err):
+        g.append(F[:10] * 1000.0)                               # leaves fp16's range under the bank's scale
+    assert g.n == 101
+    with pytest.raises(Err):
+        g.append(np.full((3, 128), np.inf, np.float32))
+    with pytest.raises(Err):
+        g.append(np.tile(F, (3, 1)))                            # capacity (300 -> 384 rows) used up
+    assert _ffi.self_dist_plan(1024, 5)[1] == 2
