@@ -62,7 +62,7 @@ inline bool sqrt_tie_possible(const Bank& a, const Bank& b)
 // when a context is created) -------------------------------------------------------------------
 struct Tuning {
     int nb = 0, nsplit = 0, nw = 0;   // K1 launch shape overrides, 0 = the built-in rule
-    int nbuf = 0;                     // K1 LDS stage buffers: 0 = 3 for the top-1 kernel, 2 for top-2
+    int nbuf = 0;                     // K1 / K2 LDS stage buffers: 0 = 3 (top-2 shapes other than 4 blocks per wave: 2)
     int prio = 1;                     // s_setprio around a unit's MFMA burst (three-buffer kernel)
     int glds = 1;                     // LDS-DMA staging (0: through registers)
     int coop = 1;                     // cross-workgroup K-th-best bounds
@@ -104,7 +104,7 @@ struct RowReducePlan {
     int nchunks;
     int nsplit;
     int stages_per_split;
-    int nbuf = 0;      // stage buffers (0 = rule: 3 for top-1, 2 for top-2)
+    int nbuf = 0;      // stage buffers (0 = rule: rowreduce.hip nbuf_choice)
     int prio = 1;      // s_setprio around the MFMA burst
     int order = 0;     // Tuning::k1_order
     int bound_every = 1;   // Tuning::bound_every

@@ -77,7 +77,7 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *                         that enqueue the next batch before waiting for this one, fm_mark / fm_wait)
  *   "nsplit" "nb" "nw"    K1 grid shape: splits of the reduction range, 16-row blocks per wave (4 | 6 | 8),
  *                         waves per workgroup (4 | 8 | 16); 0 = built-in rule
- *   "nbuf"         0|2|3  K1 LDS stage buffers (0 = 3 for top-1, 2 for top-2)
+ *   "nbuf"         0|2|3  K1 / K2 LDS stage buffers (0 = 3; top-2 shapes other than 4 blocks per wave: 2)
  *   "prio" "glds" "coop"  0|1  s_setprio around the MFMA burst / LDS-DMA staging / cross-workgroup bounds
  *   "f32_filter"   0..2   float32 route: 0 = all-pairs kernel only, 1 = fp16 filter for large calls, 2 = always
  *   "f32_nw" "f32_nsplit" "f32_fused" "f32_lpc"   K8 launch shape (0 / -1 = rule)
