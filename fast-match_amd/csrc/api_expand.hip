@@ -445,6 +445,11 @@ extern "C" int fm_expand_info(const fm_expand* ex, int64_t* state_bytes, int32_t
         const int64_t found_cap = pow2_at_least(4 * ex->match_cap);
         *state_bytes = (int64_t)(al256((size_t)ex->stack_cap * 32) + al256((size_t)ex->seen_cap * 8) + al256((size_t)found_cap * 16) +
                                  al256((size_t)ex->match_cap * 4) + al256((size_t)ex->match_cap * 32) + al256((size_t)ex->match_cap * 8) + 256);
+        if (ex->want_log) {              // the log arrays at their first capacities (expand_run_log)
+            const int64_t rc0 = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(4096, 4 * ex->ncells);
+            const int64_t ec0 = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(65536, 4 * ex->nq);
+            *state_bytes += (int64_t)(al256((size_t)rc0 * 48) + 2 * al256((size_t)ec0 * 4) + al256((size_t)ec0 * 8));
+        }
     }
     if (n_slots) *n_slots = (int32_t)ex->runs.size();
     return FM_OK;
@@ -637,7 +642,9 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // hash table (status 1, 4, 5: thresholds above 1 accept nearly every cross-checked pair and the
     // expansion heads for every (cell, query cell) combination) in a run state four times as large, at most
     // `expand_grow` times over (default 2; the status stands after that).  The other runs keep their results.
-    for (int pass = 0; pass <= ctx->tune.expand_grow + 10; ++pass) {     // (+ 2: the capacity tiers; the rest: log arrays that started small)
+    // (the budgets are per run and per kind: a tier step or a larger log must not use up the run state's growth steps)
+    std::vector<int> cap_grows((size_t)n * 3, 0), log_grows((size_t)n, 0);       // [run][stack | result list | table]
+    for (int pass = 0; pass < 40; ++pass) {
         std::vector<int> redo;
         for (int i = 0; i < n; ++i) {
             const long long st = res[(size_t)i * 8 + 3];
@@ -652,13 +659,15 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 }
                 continue;                                 // (no memory for the tables: the status stands)
             }
-            if (st == 9 && pass < ctx->tune.expand_grow + 10) {         // the log filled: larger arrays, the run again
+            if (st == 9 && log_grows[(size_t)i] < 12) {                 // the log filled: larger arrays, the run again
                 if (expand_log_grow(ctx, pairs[i], *r) != FM_OK) continue;
+                ++log_grows[(size_t)i];
                 expand_bind_run(host[i], *r, big[(size_t)i] == 2 ? pairs[i] : nullptr);
                 redo.push_back(i);
                 continue;
             }
-            if ((st == 1 || st == 4 || st == 5) && pass < ctx->tune.expand_grow + (int)big[(size_t)i]) {
+            if ((st == 1 || st == 4 || st == 5) && cap_grows[(size_t)i * 3 + (st == 1 ? 0 : st == 4 ? 1 : 2)] < ctx->tune.expand_grow) {
+                ++cap_grows[(size_t)i * 3 + (st == 1 ? 0 : st == 4 ? 1 : 2)];
                 const int64_t limit = (int64_t)1 << 28;
                 if (st == 1) { if (r->stack_cap >= limit) continue; r->stack_cap *= 4; }
                 if (st == 4) { if (r->match_cap >= limit) continue; r->match_cap *= 4; }

@@ -354,7 +354,8 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 // with the per-train-row minimum carried from chunk to chunk in global memory (x1_round_wsplit, MERGE); the election
 // and steps 4 / 5 then read the whole subset's tables from global memory.  Rounds that fit run the code of the
 // other variants unchanged.  Still given up (status 2 -> host loop): a single bucket of more than CAND keypoints
-// (thousands at one distance), more than CAND ACCEPTED matches in one round, more than kHugeChunks chunks.
+// (thousands at one distance), more than kHugeChunks chunks.  (r05: more than CAND ACCEPTED matches in one round are
+// taken in blocks of the slot range, steps 4 / 5 below.)
 constexpr int kHugeChunks = 640;
 // LAZY (r04; the reference's own mode, cache.pyx:102-106, 124-138: a cell's features are computed -- SIFT on the crop -- when the
 // loop first reaches the cell): cells carry a `ready` flag and their own (first row, row count) in a target bank that grows as
@@ -926,6 +927,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         unsigned long long* rk = (unsigned long long*)smem;        // result keys (the stage buffer is free now)
         int n_emit = 0, na = 0;
         int log_na = 0;                                            // (uniform) accepted matches of this round that went to the log
+        bool asc_used = false;                                     // (uniform) the round pushed in ascending slot order (several chunks / blocks)
         if (nq <= kExpThreads && !huge_round) {
             // The usual size -- one thread per slot, nothing is compacted: slot order IS the order of the accepted list.
             const int i = tid;
@@ -1013,7 +1015,24 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             n_emit = etot;
             if (tid == 0) top += ptot;         // (sh_top is rewritten from `top` at the next pop)
         } else {
-            for (int s0 = 0; s0 < nq; s0 += kExpThreads) {
+          // r05: a chunked round may accept more matches than the LDS lists hold (CAND): the slots are then taken in BLOCKS --
+          // step (a) stops in front of the 512-slot pass that would overflow the list, steps (b) / (c) run on what is there,
+          // and the next block starts at that pass.  Results of an earlier block are in the found table when a later one
+          // probes it (the barrier + fence between blocks); a neighbour key pushed by two blocks is skipped at its second
+          // pop like any stale entry.  Pushes of a multi-block round go up in slot order and are reversed once at the end.
+          int s_next = 0;                    // (uniform) first slot of the next block
+          for (int blk_i = 0; s_next < nq && status == kExpOk; ++blk_i) {
+            if (blk_i > 0) {
+                __threadfence_block();
+                __syncthreads();             // the block's emits / table inserts are visible; its LDS lists are done with
+                for (int i = tid; i < kDupSlots; i += kExpThreads) {
+                    const int v = ((i >> 8) & 1) ? INT32_MAX : -1;
+                    ((v4i*)dup_tab)[i] = v4i{v, v, v, v};
+                }
+                na = 0;
+            }
+            int s0 = s_next;
+            for (; s0 < nq; s0 += kExpThreads) {
                 const int i = s0 + tid;
                 bool acc = false;
                 double ratio = 0.0, pq0 = 0, pq1 = 0, pt0 = 0, pt1 = 0;
@@ -1043,11 +1062,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 const int cnt = block_rank_flags(acc, false, &o, &o_unused, wave_cnt, rank_toggle) & 0xffff;
                 // keys[] (qbest) of slots < s0 + kExpThreads are consumed (the barrier inside the ranking separates
                 // those reads from these writes): entries na+o <= i never clobber unread ones
-                if constexpr (HUGE) { if (huge_round && na + cnt > CAND) { status = kExpCandFull; break; } }   // (uniform)
+                if constexpr (HUGE) { if (huge_round && na + cnt > CAND) break; }   // (uniform) this pass opens the next block
                 if (P.lg_round) {              // (uniform) the accepted list IS the round's record
-                    if (sh_nlog + na + cnt > P.lg_entry_cap) { status = kExpLogFull; break; }
+                    if (sh_nlog + log_na + na + cnt > P.lg_entry_cap) { status = kExpLogFull; break; }
                     if (acc) {
-                        const long long e = sh_nlog + na + o;
+                        const long long e = sh_nlog + log_na + na + o;
                         P.lg_q[e] = qrow; P.lg_t[e] = (int)(t0 + t_local); P.lg_ratio[e] = ratio;
                     }
                 }
@@ -1064,8 +1083,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 }
                 na += cnt;
             }
+            s_next = s0;
             if (status != kExpOk) break;
-            if (P.lg_round) { if (tid == 0) log_header(cell, na); log_na = na; }
+            const bool asc = blk_i > 0 || s_next < nq || na > kExpThreads;     // (uniform) pushes in slot order, reversed at the end
+            asc_used = asc_used || asc;
+            log_na += na;
+            if (P.lg_round && s_next >= nq) { if (tid == 0) log_header(cell, log_na); }
             lds_barrier();
             EXP_STAMP(4);
 #ifdef FM_PARK_PROF
@@ -1162,10 +1185,10 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     // The first accepted match must be popped first, i.e. sit on top.  One chunk
                     // (na <= kExpThreads, the usual case): write in reverse rank order.  More: chunks are
                     // written in ascending order and the whole region is reversed afterwards.
-                    const long long dst = (na <= kExpThreads) ? sh_top + (ptot - 1 - po) : sh_top + po;
+                    const long long dst = !asc ? sh_top + (ptot - 1 - po) : sh_top + po;
                     P.stack[dst * 4 + 0] = mqx; P.stack[dst * 4 + 1] = mqy;
                     P.stack[dst * 4 + 2] = nx;  P.stack[dst * 4 + 3] = ny;
-                    if (na <= kExpThreads && po == 0) {            // this entry ends up on top: cache it for the next pop
+                    if (!asc && po == 0) {            // this entry ends up on top: cache it for the next pop
                         nxt_e[0] = mqx; nxt_e[1] = mqy; nxt_e[2] = nx; nxt_e[3] = ny;
                         nxt_key = nk; nxt_slot = nslot; nxt_valid = 1;
                     }
@@ -1179,7 +1202,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     if (!found_insert(P.found, P.found_cap, rbits, k1)) sh_i[7] = 1;
                 }
                 n_emit += etot;
-                if (na <= kExpThreads) {
+                if (!asc) {
                     // the only chunk of the round (the usual case): thread 0 rewrites sh_top from its own `top` at
                     // the next pop, and the round ends with a full barrier -- none needed here
                     if (tid == 0) top += ptot;
@@ -1189,11 +1212,12 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     lds_barrier();
                 }
             }
+          }
         }
         if (status != kExpOk) break;
         // More than one chunk: the pushed region [top_before, top) is in ascending slot order;
         // reverse it in place.
-        if (na > kExpThreads) {
+        if (asc_used) {
             __syncthreads();       // entries pushed by other threads are read from global memory below
             const long long lo = sh_i_top_before, hi = sh_top;
             const long long cntp = hi - lo;

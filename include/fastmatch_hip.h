@@ -99,7 +99,7 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "delegated_rounds" 0  a COUNTER, not a setting: rounds whose cross-check the dense kernels ran (fm_expand_run,
  *                         fm_expand_run_lazy) since it was last set to 0 -- the only value it accepts
  *   "expand_grow"  0..4   K7: how often a run that fills its pending stack / result list / hash table is
- *                         repeated in a run state four times as large (2)
+ *                         repeated in a run state four times as large (2; r05: counted per array)
  *   "expand_prof"  0|1    K7: per-phase timers of the first pair of a launch on stderr
  * Unknown names and out-of-range values return FM_EINVAL.                                          */
 int  fm_ctx_set_option(fm_ctx* ctx, const char* name, int64_t value);
@@ -381,7 +381,7 @@ typedef struct fm_expand_desc {
                                       * kernel's 2048 rows are re-run by fm_expand_run in a 4096-row kernel and then in one that
                                       * takes a subset of ANY size in chunks (options expand_big / expand_huge; float32 pairs go from
                                       * 2048 straight to the chunked kernel); what is left: pairs under the float32-root guard beyond
-                                      * 4096, more than 2048 keypoints at one distance, more than 2048 ACCEPTED matches in one round */
+                                      * 4096 rows and more than 2048 keypoints at one distance (r05: a round may ACCEPT any number) */
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
 #define FM_EXPAND_MATCH_FULL    4  /* 1, 4, 5: reported only when the run state could not grow any further */
 #define FM_EXPAND_TABLE_FULL    5

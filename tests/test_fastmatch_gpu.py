@@ -754,3 +754,30 @@ def test_log_on_clustered_keypoints_with_delegated_rounds(ctx):
     _same_matches(got, host)
     _same_log(dlog, hlog)
     assert max(len(e["ratios"]) for e in dlog) > 512
+
+
+@pytest.mark.parametrize("kind", ["u8", "rootsift"])
+def test_round_with_more_accepted_matches_than_the_lds_lists_hold(ctx, monkeypatch, kind):
+    """r05: a chunked round that ACCEPTS more than 2048 matches (until r04: FM_EXPAND_SUBSET_FULL -> host loop).  Thousands of
+    keypoints of both images crowd into one cell and the threshold accepts every cross-checked match (tau 50), so the first
+    rounds on that cell keep 3000+ matches: taken in blocks of the slot range, pushed in slot order and reversed once, results
+    and log == host loop, nothing handed back."""
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1 if kind == "rootsift" else 0)
+    q, t = synth.image_pair((620, 430), 9000, 9107, p=0.6, sigma=3.0)
+    rng = np.random.default_rng(9107)
+    crowd = np.flatnonzero(q["planted"] >= 0)[:4500]
+    tp = np.stack([rng.uniform(585, 619, len(crowd)), rng.uniform(385, 429, len(crowd))], axis=1)
+    t["positions"][q["planted"][crowd]] = tp
+    q["positions"][crowd] = tp + np.array([-3.0, 2.0])
+    conv = (lambda d: d) if kind == "u8" else (lambda d: np.sqrt(d.astype(np.float32) / np.maximum(d.astype(np.float32).sum(1, keepdims=True), 1)).astype(np.float32))
+    mc = cache.Metric_Cache.from_arrays(conv(q["descriptors"]), q["positions"], q["size"], conv(q["thumb_descriptors"]),
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], conv(t["descriptors"]), t["thumb_positions"], conv(t["thumb_descriptors"]), t["thumb_size"])
+    dlog, hlog, ds, hs = [], [], {}, {}
+    got = fastmatch.match(mc, fi, {"context": ctx, "stats": ds, "log": dlog})(50.0)
+    assert ds.get("device_loops") == 1 and "device_fallbacks" not in ds
+    host = fastmatch.match(mc, fi, {"context": ctx, "stats": hs, "log": hlog, "device_loop": False})(50.0)
+    _same_matches(got, host)
+    assert ds["rounds"] == hs["rounds"]
+    _same_log(dlog, hlog)
+    assert max(len(e["ratios"]) for e in dlog) > 2048
