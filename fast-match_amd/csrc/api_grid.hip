@@ -4,7 +4,9 @@
 // 6 ms per 12.5k-keypoint image (200 ms at 300k), fifteen times the device loop's share of a 64-pair launch.
 #include "ctx_internal.h"
 
+#include <algorithm>
 #include <cmath>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -103,3 +105,73 @@ extern "C" int fm_grid_pack_cells(const double* positions, int64_t n, int32_t wi
   }
     return FM_OK;
 }
+
+// ---- fm_self_dist: the workgroup table of the triangular self sweep (kernel: rowreduce.hip, TRI) --------------------------
+namespace fm {
+
+// Workgroups of the triangular sweep of a bank of n_pad rows, in two launches.
+//   A  every output chunk k (512 rows = 4 stages) against its own rows: the square block on the diagonal, masked.
+//      After it every row's word of bound[] holds the best of 511 candidates.
+//   B  chunk k against the stages from 4 k + 4 on, cut into pieces of S stages counted from there, piece-number
+//      major: piece i of every chunk, then piece i + 1.  The column direction of a tile only pays when the
+//      streamed rows' bounds are already good -- a row that is visited by many workgroups at once (a slice-major
+//      order: 190 visits of 512 candidates each against the same stale word) fires ~1000 atomics per row instead
+//      of a handful -- so a row's visits must be spread over the whole sweep: in this order the pieces that run
+//      together stream rows at the same DISTANCE from their chunks, i.e. different rows, and a row meets its
+//      partners in order of that distance from both directions at once.
+// S = target, or (target 0) the S in 20 .. 72 whose workgroups a list schedule on the 512 resident slots finishes first.
+static int tri_pieces(int nstages, int S, std::vector<int>* table, int* n_diag)
+{
+    const int nchunks = (nstages + 3) / 4;
+    int n = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        if (table) { table->push_back(k); table->push_back(4 * k); table->push_back(std::min(nstages, 4 * k + 4)); table->push_back(0); }
+        ++n;
+    }
+    *n_diag = n;
+    for (int i = 0; 4 + i * S < nstages; ++i)
+        for (int k = 0; k < nchunks; ++k) {
+            const int lo = 4 * k + 4 + i * S, hi = std::min(nstages, lo + S);
+            if (lo >= hi) break;                       // (later chunks are shorter still)
+            if (table) { table->push_back(k); table->push_back(lo); table->push_back(hi); table->push_back(0); }
+            ++n;
+        }
+    return n;
+}
+
+TriPlan plan_tri(int64_t n_pad, int target, std::vector<int>* table)
+{
+    TriPlan pl;
+    const int nstages = (int)(n_pad / kStageRows);
+    pl.nchunks = (nstages + 3) / 4;
+    pl.ncols_alloc = pl.nchunks * 512;
+    int S = target, nd = 0;
+    if (S <= 0) {
+        double best = 1e300;
+        std::vector<int> tb;
+        for (int c = 20; c <= 72; ++c) {
+            tb.clear();
+            const int np = tri_pieces(nstages, c, &tb, &nd);
+            // list schedule of launch B in dispatch order on 512 slots; a workgroup costs its stages + ~2 (prologue, hand-over)
+            std::vector<double> slot(512, 0.0);
+            std::make_heap(slot.begin(), slot.end(), std::greater<double>());
+            double end = 0.0;
+            for (int i = nd; i < np; ++i) {
+                std::pop_heap(slot.begin(), slot.end(), std::greater<double>());
+                const double f = slot.back() + (tb[4 * i + 2] - tb[4 * i + 1]) + 2.0;
+                slot.back() = f;
+                std::push_heap(slot.begin(), slot.end(), std::greater<double>());
+                end = f > end ? f : end;
+            }
+            if (end < best) { best = end; S = c; }
+        }
+    }
+    if (S < 4) S = 4;
+    pl.stages = S;
+    if (table) table->clear();
+    pl.npieces = tri_pieces(nstages, S, table, &pl.ndiag);
+    return pl;
+}
+
+
+}  // namespace fm
