@@ -399,6 +399,13 @@ static int tri_plan_for(fm_ctx* ctx, int64_t n_pad, TriPlan* out)
     const std::pair<int64_t, int> key(n_pad, ctx->tune.tri_stages * 2048 + ctx->tune.bound_every);
     auto it = ctx->tri_plans.find(key);
     if (it != ctx->tri_plans.end()) { *out = it->second; return FM_OK; }
+    if (ctx->tri_plans.size() >= 64) {
+        // (a caller whose banks come in ever new sizes: the tables are small, but not for ever -- start over; no launch that
+        // reads one is in flight behind a synchronisation of the context's stream)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
+        ctx->tri_plans.clear();
+    }
     std::vector<int> table;
     TriPlan pl = plan_tri(n_pad, ctx->tune.tri_stages, &table);
     int* d = nullptr;
