@@ -302,7 +302,9 @@ void filter_kernel(FParams p)
                 // stage boundary (see above); the shared bounds are refreshed here, once per stage
                 if (st + 1 < st1) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef FM_ABLATE_K8_NOBARRIER      // ablation builds (scripts/gpu_k8_ablate.sh; their results are wrong): the waves' lock step
                     __syncthreads();
+#endif
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         settle(j);
@@ -356,6 +358,9 @@ void filter_kernel(FParams p)
     // emit every entry; rescore_kernel filters them against the final bound
 #pragma unroll
     for (int j = 0; j < NC; ++j) { settle(j); publish(j); }
+#ifdef FM_ABLATE_K8_NORESCORE       // ... the sweep without its fused epilogue
+    if (p.fused && p.nstages > 0) return;
+#endif
     if (p.fused) {
         // ---- exact rescoring in place (the rule of rescore_kernel below, on registers) --------------
 #pragma unroll
@@ -386,8 +391,16 @@ void filter_kernel(FParams p)
                     float sum = 0.f;
 #pragma unroll 8
                     for (int k4 = 0; k4 < kDim / 4; ++k4) {
+#ifdef FM_ABL_RS_NOA                // ... the epilogue without the loads of its output rows / of its candidates
+                        const float4 a = make_float4(sum, 1.f, 2.f, 3.f);
+#else
                         const float4 a = cp[k4];
+#endif
+#ifdef FM_ABL_RS_NOB
+                        const float4 b = make_float4(4.f, sum, 5.f, 6.f);
+#else
                         const float4 b = rp[k4];
+#endif
                         float v;
                         v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
                         v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
