@@ -53,7 +53,9 @@ def fuzz_operators(rng):
     kind, Q, T = banks(rng)
     for k, v in (("nsplit", int(rng.choice([0, 0, 1, 3, 8, 13]))), ("nbuf", int(rng.choice([0, 2, 3]))),
                  ("coop", int(rng.integers(0, 2))), ("f32_filter", int(rng.choice([0, 0, 1, 2]))),
-                 ("k1_order", int(rng.choice([0, 0, 1, 2]))), ("bound_every", int(rng.choice([1, 2, 16, 16, 64, 1024])))):
+                 ("k1_order", int(rng.choice([0, 0, 1, 2]))), ("bound_every", int(rng.choice([1, 2, 16, 16, 64, 1024]))),
+                 # r05: the triangular self sweep on every size (2 = also below its 32768-row default), random piece lengths
+                 ("self_tri", int(rng.choice([0, 1, 2, 2]))), ("tri_stages", int(rng.choice([0, 0, 4, 5, 17, 40])))):
         ctx.set_option(k, v)
     if rng.integers(0, 4) == 0 and kind != "far":         # the train bank as a device-side gather of uploaded rows
         m = rng.integers(0, len(T), size=size(rng, 40000)).astype(np.int32)
@@ -177,7 +179,7 @@ def run(budget, seed0, max_problems=None, context=None):
     Returns (problems, counts by kind); raises AssertionError at the first difference."""
     global ctx
     ctx = context if context is not None else fm.Context(0)
-    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter", "k1_order", "bound_every", "expand_delegate")}
+    saved = {k: ctx.get_option(k) for k in ("nsplit", "nbuf", "coop", "f32_filter", "k1_order", "bound_every", "expand_delegate", "self_tri", "tri_stages")}
     counts = {}
     t0, it = time.time(), 0
     try:
