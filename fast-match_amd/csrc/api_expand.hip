@@ -553,7 +553,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // the int8 and the float32 pairs are different kernels, and so are the capacity tiers of the int8 one (a pair starts
     // in the tier its last complete run needed): descriptors grouped by kernel, one launch each
     std::vector<char> big((size_t)n, 0);          // capacity tier of the run's last launch (launch_expand)
-    auto huge_ok = [&](int i) { return ctx->tune.expand_huge != 0 && (host[i].f32 || !host[i].tie_guard); };
+    auto huge_ok = [&](int i) { return ctx->tune.expand_huge != 0; };
     for (int i = 0; i < n; ++i) {
         int t = pairs[i]->tier_hint;
         if (t == 2 && (!huge_ok(i) || expand_run_huge(ctx, pairs[i], *run[(size_t)i]) != FM_OK)) t = 1;

@@ -353,10 +353,56 @@ __device__ __forceinline__ int block_rank_flags(bool a, bool b, int* rank_a, int
 // ascending, so chunk order + order inside the chunk = the order of the whole subset) and matched against the cell
 // with the per-train-row minimum carried from chunk to chunk in global memory (x1_round_wsplit, MERGE); the election
 // and steps 4 / 5 then read the whole subset's tables from global memory.  Rounds that fit run the code of the
-// other variants unchanged.  Still given up (status 2 -> host loop): a single bucket of more than CAND keypoints
-// (thousands at one distance), more than kHugeChunks chunks.  (r05: more than CAND ACCEPTED matches in one round are
-// taken in blocks of the slot range, steps 4 / 5 below.)
+// other variants unchanged.  Still given up (status 2 -> host loop): more than kHugeChunks chunks.  (r05: a single
+// bucket of more than CAND keypoints -- thousands at one distance -- is split by rank, huge_rank_pivots; pairs under the
+// float32-root guard have their ties repaired at the election; more than CAND ACCEPTED matches in one round are taken in
+// blocks of the slot range, steps 4 / 5 below.)
 constexpr int kHugeChunks = 640;
+
+// first pivot c in [1, nch) whose value, with the trial bit or'ed in, exceeds the entry (nch: none); the pivots are ordered
+__device__ __forceinline__ int rank_first_above(const unsigned long long* vk, const unsigned* vi, int nch, unsigned long long k, unsigned qi,
+                                                unsigned long long kbit, unsigned ibit)
+{
+    int lo = 1, hi = nch;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const unsigned long long tk = vk[mid] | kbit;
+        const unsigned ti = vi[mid] | ibit;
+        if (k < tk || (k == tk && qi < ti)) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Chunks of a huge round by RANK (expand_kernel, HUGE; r05): pivot c = the (key bits, keypoint index) pair of rank c * cand among
+// the nq entries (h_keys[i], h_idx[i]), for c in [1, nch); chrow[c] = c * cand.  Built bit by bit from the top -- 63 key bits,
+// then 31 index bits: a bit stays if no more than c * cand entries lie below the value with it -- one counting pass over the
+// list per bit for all pivots at once (they stay ordered, so an entry finds the first pivot above it by bisection and the
+// counts are a running sum).  ~95 passes: hundreds of microseconds for a round no image of keypoints produces.  A function of
+// its own (not inlined): the cold path keeps its registers out of the kernel's allocation.  vk / vi / vcnt: LDS, nch + 1 words each.
+__device__ __attribute__((noinline)) void huge_rank_pivots(unsigned long long* vk, unsigned* vi, int* vcnt, int* chrow, int nq, int nch, int cand,
+                                                           const unsigned long long* h_keys, const int* h_idx)
+{
+    const int tid = threadIdx.x;
+    for (int c = tid; c <= nch; c += kExpThreads) { vk[c] = 0ull; vi[c] = 0u; chrow[c] = c < nch ? c * cand : nq; }
+    for (int bit = 93; bit >= 0; --bit) {
+        const unsigned long long kbit = bit >= 31 ? 1ull << (bit - 31) : 0ull;
+        const unsigned ibit = bit >= 31 ? 0u : 1u << bit;
+        for (int c = tid; c <= nch; c += kExpThreads) vcnt[c] = 0;
+        __syncthreads();
+        for (int i = tid; i < nq; i += kExpThreads) {
+            const unsigned long long k = __hip_atomic_load(h_keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned qi = (unsigned)__hip_atomic_load(h_idx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&vcnt[rank_first_above(vk, vi, nch, k, qi, kbit, ibit)], 1);
+        }
+        __syncthreads();
+        for (int c = 1 + tid; c < nch; c += kExpThreads) {
+            int below = 0;
+            for (int j = 1; j <= c; ++j) below += vcnt[j];
+            if (below <= c * cand) { vk[c] |= kbit; vi[c] |= ibit; }
+        }
+        __syncthreads();
+    }
+}
 // LAZY (r04; the reference's own mode, cache.pyx:102-106, 124-138: a cell's features are computed -- SIFT on the crop -- when the
 // loop first reaches the cell): cells carry a `ready` flag and their own (first row, row count) in a target bank that grows as
 // the host adds cells.  A round that needs a cell which is not there SAVES the loop's state (counters, pending-stack height, seed
@@ -686,9 +732,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
         lds_barrier();
         nq = sh_i[4];
         if (nq > CAND) {
-            // (the chunked round has no float32-root repair: a pair under the guard -- re-derived per launch for a growing
-            // lazy target -- gives the round back)
-            if (HUGE && (F32 || !P.tie_guard)) huge_round = true;
+            if (HUGE) huge_round = true;
             else { status = kExpCandFull; break; }
         }
 #ifdef FM_PARK_PROF
@@ -824,10 +868,23 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                 sh_i[5] = ok ? c : -1;
             }
             lds_barrier();
-            const int nch = sh_i[5];
-            if (nch < 0) { status = kExpCandFull; break; }
-            // hist[b] becomes the chunk of bucket b; the cursor words, the chunks' entry counters of the partition, are cleared
-            {
+            int nch = sh_i[5];
+            bool by_rank = false;                                            // (uniform)
+            // pivots of the chunks by rank below: (key bits, keypoint index) pairs in the stage buffer, free until the cross-check
+            unsigned long long* const vk = (unsigned long long*)smem;
+            unsigned* const vi = (unsigned*)(vk + kHugeChunks + 1);
+            int* const vcnt = (int*)(vi + kHugeChunks + 1);
+            if (nch < 0) {
+                // r05: a sort bucket holds more than a chunk of keypoints (thousands at ONE distance from the round's position:
+                // the sort order inside is by keypoint index, which no range of buckets can split), or the greedy chunks ran
+                // out.  Chunks by RANK then: chunk c = the entries of ranks [c CAND, (c + 1) CAND) in (key bits, index) order
+                // (huge_rank_pivots); before r05 such a round handed the whole run to the host loop.
+                nch = (nq + CAND - 1) / CAND;
+                if (nch > kHugeChunks) { status = kExpCandFull; break; }
+                by_rank = true;
+                huge_rank_pivots(vk, vi, vcnt, chrow, nq, nch, CAND, (const unsigned long long*)P.h_qbest, (const int*)P.h_ucand);
+            } else {
+                // hist[b] becomes the chunk of bucket b
                 constexpr int kPer = kSortBuckets / kExpThreads;
 #pragma unroll
                 for (int q = 0; q < kPer; ++q) {
@@ -836,8 +893,9 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (chb[mid] <= bq) lo = mid; else hi = mid - 1; }
                     hist[bq] = lo;
                 }
-                for (int i = tid; i < nch; i += kExpThreads) pre[i] = 0;
             }
+            // the cursor words, the chunks' entry counters of the partition, are cleared
+            for (int i = tid; i < nch; i += kExpThreads) pre[i] = 0;
             lds_barrier();
             HUGE_STAMP(1);
             // (b) the partition: every entry to its chunk's slot range of h_pkey[] / h_cand[] (the chunk's sorted rows land in
@@ -845,7 +903,8 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             {
                 int* const chcnt = hist + kSortBuckets + 4;
                 scan([&](unsigned long long kb, int qi) {
-                    const int c = hist[bucket_of(__longlong_as_double((long long)kb))];
+                    const int c = by_rank ? rank_first_above(vk, vi, nch, kb, (unsigned)qi, 0ull, 0u) - 1
+                                          : hist[bucket_of(__longlong_as_double((long long)kb))];
                     const int at = chrow[c] + atomicAdd(&chcnt[c], 1);
                     P.h_pkey[at] = kb;
                     P.h_cand[at] = qi;
@@ -858,18 +917,29 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             // the run (the state a lazy run saves, + the subset's size); fm_expand_run gathers the subset's rows, runs the
             // dense reverse-NN kernel (K1) and the election on the whole GPU into h_qbest[] and resumes the run at steps 4 / 5.
             const bool deleg = P.delegate_min > 0 && (long long)nq * nt >= P.delegate_min;
+            __shared__ unsigned long long sh_krange[2];      // chunks by rank: smallest / largest key of the chunk being sorted
             for (int c = 0; c < nch; ++c) {
-                const int b0 = chb[c], b1 = chb[c + 1];
+                const int b0 = by_rank ? 0 : chb[c], b1 = by_rank ? 0 : chb[c + 1];
                 const unsigned base = (unsigned)chrow[c];
                 const int nc = chrow[c + 1] - chrow[c];
+                if (by_rank && tid == 0) { sh_krange[0] = ~0ull; sh_krange[1] = 0ull; }     // (read behind the load barrier below)
                 lds_barrier();                          // (everyone has read chrow / chb; the last chunk's tables are done with)
                 block_sort_clear(hist);
-                for (int i = tid; i < nc; i += kExpThreads) {
-                    keys[i] = __hip_atomic_load(P.h_pkey + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cand[i] = __hip_atomic_load(P.h_cand + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {
+                    unsigned long long kmin = ~0ull, kmax = 0ull;
+                    for (int i = tid; i < nc; i += kExpThreads) {
+                        const unsigned long long kv = __hip_atomic_load(P.h_pkey + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        keys[i] = kv;
+                        cand[i] = __hip_atomic_load(P.h_cand + base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        kmin = kv < kmin ? kv : kmin; kmax = kv > kmax ? kv : kmax;
+                    }
+                    if (by_rank && kmin != ~0ull) { atomicMin(&sh_krange[0], kmin); atomicMax(&sh_krange[1], kmax); }
                 }
                 lds_barrier();
-                block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, (double)b1 / bscale, (double)b0 / bscale);
+                // the sort's buckets spread over the chunk's key range (non-negative doubles order like their bit patterns)
+                const double s_lo = by_rank ? __longlong_as_double((long long)sh_krange[0]) : (double)b0 / bscale;
+                const double s_hi = by_rank ? __longlong_as_double((long long)sh_krange[1]) : (double)b1 / bscale;
+                block_sort_pairs<CAND>(keys, cand, nkey, tix, hist, nc, s_hi, s_lo);
                 for (int i = tid; i < nc; i += kExpThreads) P.h_cand[base + i] = cand[i];
                 if (deleg) continue;
                 if constexpr (F32) {
@@ -901,13 +971,44 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             // (b) election: train row t elects the slot its minimum names; the slot keeps its closest train row
             for (int i = tid; i < nq; i += kExpThreads) P.h_qbest[i] = ~0ull;      // (the unsorted keys are done with)
             __syncthreads();                  // the fill of h_qbest and the copies of h_cand have reached memory
-            if (tid < 128)
-                for (int t = tid; t < nt; t += 128) {
-                    const unsigned long long tb = P.h_tbest[t];
-                    if (tb != ~0ull)
-                        __hip_atomic_fetch_min(P.h_qbest + (unsigned)tb, (tb & 0xffffffff00000000ull) | (unsigned long long)(unsigned)t,
+            if (F32 || !P.tie_guard) {
+                if (tid < 128)
+                    for (int t = tid; t < nt; t += 128) {
+                        const unsigned long long tb = P.h_tbest[t];
+                        if (tb != ~0ull)
+                            __hip_atomic_fetch_min(P.h_qbest + (unsigned)tb, (tb & 0xffffffff00000000ull) | (unsigned long long)(unsigned)t,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            } else if constexpr (!F32) {
+                // Pairs under the float32-root guard (cold: never with SIFT-range descriptors; r05, the last round shape that
+                // gave a run back to the host): the keys carry the distance's float32 bits, and a train row whose best d2
+                // shares its root with d2 + 1 elects the LOWEST slot at either (round_body.h has the one-chunk form) -- the
+                // slots below the merged minimum's are rescanned exactly by the whole workgroup, one tied row at a time.
+                // (every thread reads the same words: the loop and its barriers are uniform)
+                __shared__ unsigned sh_tie;
+                for (int t = 0; t < nt; ++t) {
+                    const unsigned long long tb = __hip_atomic_load(P.h_tbest + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tb == ~0ull) continue;
+                    const unsigned d2 = (unsigned)(tb >> 32);
+                    unsigned smin = (unsigned)tb;
+                    if (d2 >= kSqrtTieMin && sqrt_ties_up(d2)) {
+                        if (tid == 0) sh_tie = smin;
+                        __syncthreads();
+                        gptr<const int8_t> trow = P.t_rows8 + (size_t)(t0 + t) * kDim;
+                        const int tn = P.t_norm[t0 + t];
+                        for (unsigned sl = tid; sl < smin; sl += kExpThreads) {
+                            const int qi = __hip_atomic_load(P.h_cand + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (exact_d2_i8(P.q_rows8 + (size_t)qi * kDim, P.q_norm[qi], trow, tn) == d2 + 1u) atomicMin(&sh_tie, sl);
+                        }
+                        __syncthreads();
+                        smin = sh_tie;
+                        __syncthreads();
+                    }
+                    if (tid == 0)
+                        __hip_atomic_fetch_min(P.h_qbest + smin, ((unsigned long long)sqrt_bits(d2) << 32) | (unsigned long long)(unsigned)t,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
             __syncthreads();
         }
         if constexpr (F32) lds_barrier();

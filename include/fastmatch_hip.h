@@ -380,8 +380,9 @@ typedef struct fm_expand_desc {
 #define FM_EXPAND_SUBSET_FULL   2  /* a radius subset the device could not take.  Integer-route pairs that exceed the first
                                       * kernel's 2048 rows are re-run by fm_expand_run in a 4096-row kernel and then in one that
                                       * takes a subset of ANY size in chunks (options expand_big / expand_huge; float32 pairs go from
-                                      * 2048 straight to the chunked kernel); what is left: pairs under the float32-root guard beyond
-                                      * 4096 rows and more than 2048 keypoints at one distance (r05: a round may ACCEPT any number) */
+                                      * 2048 straight to the chunked kernel; r05: pairs under the float32-root guard and subsets with
+                                      * thousands of keypoints at one distance too, and a round may ACCEPT any number); what is left:
+                                      * a subset beyond 640 x 2048 rows, or expand_big / expand_huge switched off */
 #define FM_EXPAND_OUT_OF_BOUNDS 3  /* a target position outside the image (cache.pyx:56-57) */
 #define FM_EXPAND_MATCH_FULL    4  /* 1, 4, 5: reported only when the run state could not grow any further */
 #define FM_EXPAND_TABLE_FULL    5

@@ -235,6 +235,84 @@ def test_device_loop_chunks_radius_subsets_of_any_size(ctx):
             assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"] and len(got) > 300
 
 
+def test_device_loop_chunks_radius_subsets_in_the_sqrt_tie_range(ctx):
+    """r05: radius subsets beyond 4096 rows of a pair under the float32-root guard (every query/target d2 >= 4 197 200,
+    kat.far_image_pair) stay on the device too: the chunked round merges (d2, slot) minima per train row, and its election
+    repairs the rows whose best d2 shares its float32 root with d2 + 1 (the lowest slot at either wins, as in
+    cv::batchDistance's float32 comparison) -- before r05 such a pair gave the whole run back to the host loop."""
+    from kat import far_image_pair
+    q, t = synth.image_pair((400, 300), 6000, 79)
+    q, t = far_image_pair(q, t)
+    pos = q["positions"]
+    assert ((pos[:, 0] - 200.0) ** 2 + (pos[:, 1] - 150.0) ** 2 <= 200.0 ** 2).sum() > 4096
+    mc = cache.Metric_Cache.from_arrays(q["descriptors"], pos, q["size"], q["thumb_descriptors"],
+                                        q["thumb_positions"], q["thumb_size"], options={"context": ctx})
+    fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
+                             t["thumb_descriptors"], t["thumb_size"])
+    oq = fo.OQuery(q["descriptors"], pos, q["size"],
+                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
+          "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    for tau in (1100.0, 1138.0):       # (ratios are d / self distance = 2550 / 2.449 .. 2550 / 1: 1041, 1140, 1275 ...)
+        stats, hs = {}, {}
+        exp = fo.o_match(oq, ot, {"radius": 200})(tau)
+        got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(tau)
+        assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats, stats
+        _same_matches(got, exp)
+        host = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": hs, "device_loop": False})(tau)
+        _same_matches(host, exp)
+        assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"]
+        print("tie-range chunked rounds: tau %g, %d matches, %d rounds" % (tau, len(got), stats["rounds"]))
+    assert len(got) > 100
+
+
+@pytest.mark.parametrize("rootsift", [False, True])
+def test_device_loop_chunks_by_rank_when_thousands_of_keypoints_share_one_sort_key(ctx, monkeypatch, rootsift):
+    """r05: 3000 of 6000 query keypoints sit at ONE position, so every radius subset that holds them has 3000 entries with
+    the same sort key (one histogram bucket larger than a 2048-row chunk; inside it the order is by keypoint index).  The
+    chunked round then splits the subset by RANK in (key bits, index) order (expand.hip, huge_rank_pivots) instead of
+    giving the run back to the host loop: device == host loop == oracle, no fallback; uint8 and RootSIFT-style float32."""
+    from fastmatch_amd import _ffi
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1 if rootsift else 0)
+    q, t = synth.image_pair((400, 300), 6000, 81)
+    rng = np.random.default_rng(81)
+    same = rng.choice(6000, 3000, replace=False)
+    q["positions"] = q["positions"].copy()
+    q["positions"][same] = (203.25, 148.5)
+
+    def conv(d):
+        if not rootsift:
+            return d
+        d = d.astype(np.float32)
+        return np.sqrt(d / np.maximum(d.sum(1, keepdims=True), 1)).astype(np.float32)
+
+    qd, td, qtd, ttd = conv(q["descriptors"]), conv(t["descriptors"]), conv(q["thumb_descriptors"]), conv(t["thumb_descriptors"])
+    mc = cache.Metric_Cache.from_arrays(qd, q["positions"], q["size"], qtd, q["thumb_positions"], q["thumb_size"],
+                                        options={"context": ctx})
+    assert mc.bank(ctx).kind == (_ffi.FM_BANK_F32 if rootsift else _ffi.FM_BANK_I8)
+    fi = cache.Feature_Image(t["size"], t["positions"], td, t["thumb_positions"], ttd, t["thumb_size"])
+    oq = fo.OQuery(qd, q["positions"], q["size"],
+                   thumb={"descriptors": qtd, "positions": q["thumb_positions"], "size": q["thumb_size"]})
+    ot = {"size": t["size"], "positions": t["positions"], "descriptors": td,
+          "thumb": {"descriptors": ttd, "positions": t["thumb_positions"], "size": t["thumb_size"]}}
+    for dmin in ((0,) if rootsift else (0, 1)):          # every cross-check in the run's own workgroup / every one delegated
+        ctx.set_option("expand_delegate", dmin)
+        try:
+            for tau in (0.8, 0.95):
+                stats, hs = {}, {}
+                exp = fo.o_match(oq, ot, {"radius": 200})(tau)
+                got = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": stats})(tau)
+                assert stats.get("device_loops") == 1 and "device_fallbacks" not in stats, stats
+                _same_matches(got, exp)
+                host = fastmatch.match(mc, fi, {"context": ctx, "radius": 200, "stats": hs, "device_loop": False})(tau)
+                _same_matches(host, exp)
+                assert stats["rounds"] == hs["rounds"] and stats["pairs"] == hs["pairs"]
+                print("one sort key: rootsift %s, delegate %d, tau %g: %d matches, %d rounds" % (rootsift, dmin, tau, len(got), stats["rounds"]))
+        finally:
+            ctx.set_option("expand_delegate", 1500000)
+    assert len(got) > 50
+
+
 def test_device_loop_chunks_radius_subsets_of_float32_banks(ctx, monkeypatch):
     """RootSIFT-style float32 banks with radius subsets far beyond the float32 round's 2048 rows: the chunked variant of
     the float32 kernel (fp16 filter + exact chain per chunk, per-train-row (distance bits, slot) minimum merged across the

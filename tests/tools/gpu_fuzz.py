@@ -13,7 +13,7 @@ import fastmatch_amd as fm
 from fastmatch_amd import synth, cache, fastmatch
 import oracle
 from oracle import fastmatch_oracle as fo
-from kat import far_banks
+from kat import far_banks, far_image_pair
 
 ctx = None                      # set by run()
 ONLY = os.environ.get("FM_FUZZ_ONLY", "")      # "match": image pairs through fastmatch.match() only
@@ -131,6 +131,13 @@ def fuzz_match(rng):
     if rng.integers(0, 3) == 0:                               # r04: clustered keypoints
         kw = {"clusters": int(rng.integers(1, 5)), "cluster_sigma": float(rng.uniform(8.0, 60.0)), "cluster_frac": float(rng.uniform(0.2, 0.9))}
     q, t = synth.image_pair((w, h), n, seed, n_thumb=min(600, n), **kw)
+    if rng.integers(0, 10) == 0:                              # r05: a share of the query keypoints at ONE position (one sort key:
+        k = int(len(q["positions"]) * rng.uniform(0.2, 0.8))  # the chunked round's split by rank), sometimes of the target's too
+        q["positions"] = q["positions"].copy()
+        q["positions"][rng.choice(len(q["positions"]), k, replace=False)] = (float(rng.uniform(0, w - 1)), float(rng.uniform(0, h - 1)))
+        if rng.integers(0, 3) == 0:
+            t["positions"] = t["positions"].copy()
+            t["positions"][rng.choice(len(t["positions"]), len(t["positions"]) // 3, replace=False)] = (float(rng.uniform(0, w - 1)), float(rng.uniform(0, h - 1)))
     rootsift = rng.integers(0, 5) == 0                        # r04: float32 descriptors (the float32 round, its chunks, its delegation)
     if rootsift:
         for side in (q, t):
@@ -138,6 +145,9 @@ def fuzz_match(rng):
                 d = side[k].astype(np.float32)
                 side[k] = np.sqrt(d / np.maximum(d.sum(axis=1, keepdims=True), 1.0)).astype(np.float32)
     fo.FLOAT_ORDER = 1 if rootsift else 0                     # (the oracle in the device's accumulation order for those)
+    far = (not rootsift) and rng.integers(0, 8) == 0          # r05: every d2 in the float32-root tie range (kat.far_image_pair)
+    if far:
+        q, t = far_image_pair(q, t, seed=seed)
     mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
                                         q["thumb_positions"], q["thumb_size"], options=dict(opts, context=ctx))
     fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
@@ -155,7 +165,11 @@ def fuzz_match(rng):
     get = fastmatch.match(mc, fi, dict(opts, context=ctx, stats=stats, device_loop=bool(rng.integers(0, 4)), log=log))
     oget = fo.o_match(oq, ot, dict(opts, log=olog))
     taus = sorted(float(x) for x in rng.choice([0.3, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97], int(rng.integers(1, 4)), replace=False))
-    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else "u8")
+    if far:                                                   # (ratios there are ~2550 / self distance: 1041, 1140, 1275, 1472 ...)
+        taus = sorted(float(x) for x in rng.choice([900.0, 1045.0, 1100.0, 1150.0, 1300.0], int(rng.integers(1, 3)), replace=False))
+        if n > 1200:
+            taus = [x for x in taus if x < 1140.0] or [1100.0]         # (above that nearly every row is accepted: minutes of oracle)
+    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else ("far" if far else "u8"))
     if rng.integers(0, 2) and len(taus) > 1:
         got_all = get(taus)
     else:
