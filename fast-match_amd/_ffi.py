@@ -37,7 +37,7 @@ class fm_stats_ex(ctypes.Structure):
                 ("bytes_moved", ctypes.c_int64)]
 
 
-FM_ABI_VERSION = 6          # include/fastmatch_hip.h: the revision this binding was written against
+FM_ABI_VERSION = 7          # include/fastmatch_hip.h: the revision this binding was written against
 
 
 class fm_expand_desc(ctypes.Structure):

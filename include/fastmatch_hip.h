@@ -41,9 +41,11 @@ typedef struct fm_bank fm_bank;
 
 /* ABI revision of this header.  It changes whenever an existing signature or struct layout does (revision 3, r03:
  * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only; revision 5, r04:
- * fm_expand_desc gained the trailing `lazy`).  A binding
+ * fm_expand_desc gained the trailing `lazy`; revision 7, r05: additions -- fm_self_dist_plan, fm_bank_create_f32_cap,
+ * fm_bank_append_f32, fm_expand_set_log / _log_counts / _fetch_log -- and fm_expand_run_lazy refuses to resume a run
+ * that did not park).  A binding
  * compares fm_abi_version() with the FM_ABI_VERSION it was written against before its first call.            */
-#define FM_ABI_VERSION 6
+#define FM_ABI_VERSION 7
 int  fm_abi_version(void);
 
 typedef struct fm_stats {
