@@ -829,8 +829,10 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& 
     }
     // (one instantiation, with the s_setprio around the MFMA burst: the one without it does not fit 128 VGPRs)
     (void)prio;
+    const bool merge = getenv("FM_TRI_MERGE") != nullptr;       // (measurement: both phases in ONE grid, diagonal blocks first)
     for (int phase = 0; phase < 2; ++phase) {
-        const int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
+        int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
+        if (merge) { if (phase == 1) break; first = 0; count = plan.npieces; }
         if (count <= 0) continue;
         for (int i = 0; i < n; ++i) b.p[i].tri = (const int4*)plan.d_table + first;
         if (n == 1) {
