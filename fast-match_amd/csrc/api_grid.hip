@@ -145,25 +145,25 @@ TriPlan plan_tri(int64_t n_pad, int target, std::vector<int>* table)
     const int nstages = (int)(n_pad / kStageRows);
     pl.nchunks = (nstages + 3) / 4;
     pl.ncols_alloc = pl.nchunks * 512;
-    int S = target, nd = 0;
+    int S = target;
     if (S <= 0) {
+        // Piece length by arithmetic, O(chunks) per candidate (r05, last: the first version list-scheduled every candidate's
+        // pieces on a heap -- 2.3 ms of host time for a 100k-row bank, four times the kernel it plans, 340 ms for 1M rows;
+        // a dataset's images all differ in size, so the plan of a new size must cost microseconds).  Launch B's pieces are
+        // dispatched round by round onto 512 resident workgroups and all but each chunk's last one take S stages (+ ~2 for
+        // prologue and hand-over): what decides is how full the LAST wave of 512 is, so the candidate with the smallest
+        // ceil(pieces / 512) * (S + 2), i.e. the least idle tail, is taken; ties go to the longer piece (fewer prologues).
         double best = 1e300;
-        std::vector<int> tb;
         for (int c = 20; c <= 72; ++c) {
-            tb.clear();
-            const int np = tri_pieces(nstages, c, &tb, &nd);
-            // list schedule of launch B in dispatch order on 512 slots; a workgroup costs its stages + ~2 (prologue, hand-over)
-            std::vector<double> slot(512, 0.0);
-            std::make_heap(slot.begin(), slot.end(), std::greater<double>());
-            double end = 0.0;
-            for (int i = nd; i < np; ++i) {
-                std::pop_heap(slot.begin(), slot.end(), std::greater<double>());
-                const double f = slot.back() + (tb[4 * i + 2] - tb[4 * i + 1]) + 2.0;
-                slot.back() = f;
-                std::push_heap(slot.begin(), slot.end(), std::greater<double>());
-                end = f > end ? f : end;
+            long long np = 0;
+            for (int k = 0; k < pl.nchunks; ++k) {
+                const int rem = nstages - (4 * k + 4);
+                if (rem <= 0) break;
+                np += (rem + c - 1) / c;
             }
-            if (end < best) { best = end; S = c; }
+            const double waves = (double)((np + 511) / 512);
+            const double cost = waves * (c + 2.0);
+            if (cost <= best) { best = cost; S = c; }
         }
     }
     if (S < 4) S = 4;
