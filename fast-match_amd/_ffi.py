@@ -680,8 +680,8 @@ class Context(object):
         return {"args": args, "keep": (list(pairs), list(outs), list(counts))}     # (keeps banks and buffers alive)
 
     def match_accepted_batch(self, pairs, tau, outs=None, counts=None):
-        """``match_accepted_async`` for a list of (query bank, train bank) pairs in ONE call: pairs of
-        one shape share distance-kernel launches (up to eight per launch).  Either the lists
+        """``match_accepted_async`` for a list of (query bank, train bank) pairs in ONE call: consecutive
+        pairs share distance-kernel launches (up to eight per launch; r05: of any sizes).  Either the lists
         (``outs[i]`` = (qidx, tidx, dist, ratio), ``counts[i]`` = int64[1], all from ``pinned_empty``) or
         the block ``prepare_batch`` built from them; results are valid after ``sync()``."""
         batch = pairs if isinstance(pairs, dict) else self.prepare_batch(pairs, outs, counts)

@@ -394,18 +394,23 @@ extern "C" int fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table, 
 }
 
 // Plan + device table of the triangular sweep for banks of n_pad rows, kept per context.
+// Room for `need` more plans in the context's cache (a caller whose banks come in ever new sizes: the tables are small, but not
+// for ever -- beyond 64 the cache starts over; no launch that reads a table is in flight behind a synchronisation of the
+// context's stream).  Called ONCE in front of a group's tri_plan_for calls: the group's plans must all stay valid.
+static int tri_plans_room(fm_ctx* ctx, size_t need)
+{
+    if (ctx->tri_plans.size() + need <= 64) return FM_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
+    ctx->tri_plans.clear();
+    return FM_OK;
+}
+
 static int tri_plan_for(fm_ctx* ctx, int64_t n_pad, TriPlan* out)
 {
     const std::pair<int64_t, int> key(n_pad, ctx->tune.tri_stages * 2048 + ctx->tune.bound_every);
     auto it = ctx->tri_plans.find(key);
     if (it != ctx->tri_plans.end()) { *out = it->second; return FM_OK; }
-    if (ctx->tri_plans.size() >= 64) {
-        // (a caller whose banks come in ever new sizes: the tables are small, but not for ever -- start over; no launch that
-        // reads one is in flight behind a synchronisation of the context's stream)
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
-        ctx->tri_plans.clear();
-    }
     std::vector<int> table;
     TriPlan pl = plan_tri(n_pad, ctx->tune.tri_stages, &table);
     int* d = nullptr;
@@ -781,29 +786,38 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
             continue;
         }
         if (ctx->tune.glds != 0 && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && b->n_pad >= 32768))) {
-            // every distance once: the triangular sweep, up to "batch_group" banks of one padded size per launch
-            TriPlan tp;
-            if ((rc = tri_plan_for(ctx, b->n_pad, &tp)) != FM_OK) return rc;
+            // every distance once: the triangular sweep, up to "batch_group" banks per launch (r05, last: of any sizes from
+            // 32768 padded rows on -- every bank under the plan of its own size)
+            auto tri_ok = [&](const fm_bank* x) {
+                return x->kind == FM_BANK_I8 && x->n > 0 && (ctx->tune.self_tri == 2 || x->n_pad >= 32768);
+            };
             int g = 1;
-            while (i + g < n && g < group_max && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0 && banks[i + g]->n_pad == b->n_pad) ++g;
-            const size_t bbytes = ((size_t)tp.ncols_alloc * 4 + 255) & ~(size_t)255;
-            if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, (size_t)g * bbytes)) != FM_OK) return rc;
+            while (i + g < n && g < group_max && g < kRRBatchMax && tri_ok(banks[i + g])) ++g;
+            TriPlan tps[kRRBatchMax];
+            size_t boff[kRRBatchMax + 1];
+            boff[0] = 0;
+            if ((rc = tri_plans_room(ctx, (size_t)g)) != FM_OK) return rc;
+            for (int j = 0; j < g; ++j) {
+                if ((rc = tri_plan_for(ctx, banks[i + j]->n_pad, &tps[j])) != FM_OK) return rc;
+                boff[j + 1] = boff[j] + (((size_t)tps[j].ncols_alloc * 4 + 255) & ~(size_t)255);
+            }
+            if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, boff[g])) != FM_OK) return rc;
             const Bank* bk[kRRBatchMax];
             int* bnd[kRRBatchMax];
             TriFinish fin{};
             int64_t nmax = 0;
             for (int j = 0; j < g; ++j) {
                 bk[j] = banks[i + j];
-                bnd[j] = (int*)((char*)ctx->ws_partial + (size_t)j * bbytes);
+                bnd[j] = (int*)((char*)ctx->ws_partial + boff[j]);
                 fin.bound[j] = bnd[j]; fin.norm[j] = bk[j]->norm; fin.out[j] = d_out[i + j]; fin.n[j] = bk[j]->n;
                 nmax = bk[j]->n > nmax ? bk[j]->n : nmax;
                 // (each distance is computed once; the pairs a caller asked for are still n x n)
                 ctx->pending_pairs += bk[j]->n * bk[j]->n;
                 ctx->pending_bytes += bank_bytes(bk[j]);
             }
-            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[0], (int)0x80000000, (size_t)g * (bbytes / 4), ctx->stream));
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[0], (int)0x80000000, boff[g] / 4, ctx->stream));
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-            HIP_TRY(ctx, launch_rowreduce_tri(g, bk, tp, bnd, ctx->tune.prio != 0, ctx->stream));
+            HIP_TRY(ctx, launch_rowreduce_tri(g, bk, tps, bnd, ctx->tune.prio != 0, ctx->stream));
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
             ctx->kernel_timed = timed;
             hipLaunchKernelGGL(selfdist_tri_finish_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)g), dim3(256), 0, ctx->stream, fin);
@@ -837,7 +851,11 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
         if (coop && !ablate_keep_bounds())
             HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)bnd[0], (int)0x80000000, (size_t)g * (bbytes / 4), ctx->stream));
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-        if (g > 1) HIP_TRY(ctx, launch_rowreduce_batch(g, bk, bk, pl, part, bnd, ctx->stream, true));
+        if (g > 1) {
+            RowReducePlan pls[kRRBatchMax];
+            for (int j = 0; j < g; ++j) pls[j] = pl;
+            HIP_TRY(ctx, launch_rowreduce_batch(g, bk, bk, pls, part, bnd, ctx->stream, true));
+        }
         else       HIP_TRY(ctx, launch_rowreduce_self(*bk[0], pl, part[0], bnd[0], (ctx->tune.glds != 0), ctx->stream));
         if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         ctx->kernel_timed = timed;
@@ -1390,19 +1408,23 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
     while (i < n) {
         // run of same-shape pairs from i on, then this launch's share of it: a launch's small kernels overlap
         // the NEXT launch, so only the last launch's are exposed -- the run ends with a short launch (2 pairs)
+        // (r05, last: the pairs of a run need not share their padded sizes any more -- every pair brings its own plan, the
+        // launch its own block ranges -- only the kernel shape: 4 blocks per wave, 8 waves, three stage buffers)
+        auto plan_fits = [&](int k, RowReducePlan* out) {
+            const RowReducePlan p = plan_rowreduce(t[k]->n_pad, q[k]->n_pad, ctx->tune);
+            if (out) *out = p;
+            return p.nb == 4 && p.nw == 8 && (ctx->tune.glds != 0) && p.nbuf != 2;
+        };
         int run = 1;
-        if (batchable(i))
-            while (i + run < n && batchable(i + run) && q[i + run]->n_pad == q[i]->n_pad && t[i + run]->n_pad == t[i]->n_pad) ++run;
+        if (batchable(i) && plan_fits(i, nullptr))
+            while (i + run < n && batchable(i + run) && plan_fits(i + run, nullptr)) ++run;
         int g = run;
         if (run > group_max + tail_n) g = group_max;
         else if (run > 4 && tail_n > 0) g = run - tail_n < group_max ? run - tail_n : group_max;
         if (g > group_max) g = group_max;
         if (g < 1) g = 1;
-        RowReducePlan pl;
-        if (g > 1) {
-            pl = plan_rowreduce(t[i]->n_pad, q[i]->n_pad, ctx->tune);
-            if (pl.nb != 4 || pl.nw != 8 || !(ctx->tune.glds != 0) || pl.nbuf == 2) g = 1;     // shapes the batched kernel is not built for
-        }
+        RowReducePlan pls[kRRBatchMax];
+        for (int j = 0; j < g && g > 1; ++j) (void)plan_fits(i + j, &pls[j]);
         if (g == 1) {                  // an odd pair: the single-pair call (which also reports its errors)
             // float32-route pairs have no enqueue-only form: they run synchronously, in place (their outputs
             // are complete when the batch call returns; the pairs around them stay asynchronous)
@@ -1426,7 +1448,6 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             ++i;
             continue;
         }
-        const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
         void* al[kRRBatchMax][5];
         int slot_of[kRRBatchMax];
         SlotLayout L[kRRBatchMax];
@@ -1452,6 +1473,8 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             slot_of[j] = (int)(ctx->bslot_next++ % fm_ctx::kBatchSlots);
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             if (!sl.tail_done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming));
+            const RowReducePlan& pl = pls[j];
+            const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;
             L[j] = slot_layout(q[k]->n, t[k]->n, pl);
             if ((rc = slot_prepare(ctx, sl, L[j], q[k]->n, pl, ctx->stream)) != FM_OK) { ctx->timer_pool.push_back(tm); return rc; }
             cols[j] = t[k]; red[j] = q[k];            // reverse NN: output rows = train rows, reduced over the query rows
@@ -1461,14 +1484,14 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
             tm.bytes += bank_bytes(q[k]) + bank_bytes(t[k]);
         }
         HIP_TRY(ctx, hipEventRecord(tm.k0, ctx->stream));
-        HIP_TRY(ctx, launch_rowreduce_batch(g, cols, red, pl, part, bnd, ctx->stream));
+        HIP_TRY(ctx, launch_rowreduce_batch(g, cols, red, pls, part, bnd, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(tm.k1, ctx->stream));
         for (int j = 0; j < g; ++j) {
             const int k = i + j;
             hipStream_t ts = ctx->tails[j % fm_ctx::kTails];
             fm_ctx::AsyncSlot& sl = ctx->bslot[(size_t)slot_of[j]];
             HIP_TRY(ctx, hipStreamWaitEvent(ts, tm.k1, 0));
-            if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], t[k], q[k]->n, t[k]->n, pl, tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
+            if ((rc = enqueue_tail(ctx, ts, sl, L[j], q[k], t[k], q[k]->n, t[k]->n, pls[j], tau, cap, al[j][0], al[j][1], al[j][2], al[j][3],
                                    al[j][4], to_dev ? d_rows + (size_t)k * cap * 3 : nullptr, (long long*)(to_dev ? d_counts + k : nullptr),
                                    kNoStream)) != FM_OK) { ctx->pending.push_back(tm); return rc; }     // (events are in flight: drained at fm_sync)
             HIP_TRY(ctx, hipEventRecord(sl.tail_done, ts));

@@ -129,7 +129,7 @@ struct TriPlan {
     const int* d_table = nullptr;      // device: int4 per workgroup (chunk, first stage, end stage, 0)
 };
 TriPlan plan_tri(int64_t n_pad, int target_stages, std::vector<int>* table);
-hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& plan, int* const* bound, bool prio, hipStream_t stream);
+hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* plans, int* const* bound, bool prio, hipStream_t stream);
 constexpr int kTriNoBoundHost = -(1 << 25);     // (a real pair's word is >= -3 * 2^21, a padding row's or the masked diagonal's ~ -2^26)
 
 // ---- K5: float32 route (dist_f32.hip); partial keys carry float32 distance bits ----------
@@ -175,7 +175,7 @@ hipError_t launch_rounds_f32(const RoundF32& rf, const double* q_selfdist, const
 
 // ---- K7: device-resident expansion loop (expand.hip) ------------------------------------
 constexpr int kRRBatchMax = 16;           // bank pairs per batched row-reduce launch
-hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
+hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan* plans,
                                   unsigned long long* const* partial, int* const* bound, hipStream_t stream, bool self = false);
 hipError_t launch_expand(const void* d_pairs, int n_pairs, bool f32, int tier, hipStream_t stream);   // all pairs of one kind / capacity tier (expand.hip)
 int expand_cand_cap();

@@ -776,20 +776,31 @@ void rowreduce_kernel(RRParams p)
 // pair i run out, the CUs they leave take workgroups of pair i + 1 at once -- between two separate
 // launches the chip drains (the last of five rounds of workgroups finish at different times) and a
 // launch gap follows, together ~4 % of a 100k x 100k launch.
+// (r05, last: the pairs of a launch need not share a shape any more -- a dataset's images all differ in size, and pairs that
+// fell out of the batched launch for that cost 7 % more per descriptor pair; pair i owns the workgroups
+// [first_block[i], first_block[i + 1]), entries from n on hold INT32_MAX)
 struct RRBatch {
     RRParams p[kRRBatchMax];
     int      n;
-    int      blocks_per_pair;
+    int      first_block[kRRBatchMax + 1];
 };
+// the pair a workgroup belongs to: scalar compares on kernel arguments
+__device__ __forceinline__ int batch_pair_of(const RRBatch& b, int bid)
+{
+    int pair = 0;
+#pragma unroll
+    for (int i = 1; i < kRRBatchMax; ++i) pair += bid >= b.first_block[i] ? 1 : 0;
+    return pair;
+}
 
 template <int NC, int KTOP, int NW, int NBUF, int PRIO, bool SELF = false>
 __global__ __launch_bounds__(64 * NW, 4)
 void rowreduce_batch_kernel(RRBatch b)
 {
     __shared__ __attribute__((aligned(16))) char smem[NBUF * kStageBytes];
-    const int pair = (int)blockIdx.x / b.blocks_per_pair;
+    const int pair = batch_pair_of(b, (int)blockIdx.x);
     const RRParams p = b.p[pair];
-    rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO, SELF>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+    rowreduce_body<NC, KTOP, true, NW, NBUF, PRIO, SELF>(p, (int)blockIdx.x - b.first_block[pair], smem);
 }
 
 // The triangular self sweep (see kTriNever above): one bank, or up to kRRBatchMax banks of one padded size.
@@ -806,17 +817,19 @@ __global__ __launch_bounds__(64 * 8, 4)
 void rowreduce_tri_batch_kernel(RRBatch b)
 {
     __shared__ __attribute__((aligned(16))) char smem[kTriLdsBytes];
-    const int pair = (int)blockIdx.x / b.blocks_per_pair;
+    const int pair = batch_pair_of(b, (int)blockIdx.x);
     const RRParams p = b.p[pair];
-    rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x - pair * b.blocks_per_pair, smem);
+    rowreduce_body<4, 1, true, 8, 3, PRIO, true, true>(p, (int)blockIdx.x - b.first_block[pair], smem);
 }
 
 // (plan_tri -- the workgroup table of the two launches -- is host code and lives in api_grid.hip beside the cell planner)
-hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& plan, int* const* bound, bool prio, hipStream_t stream)
+hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* plans, int* const* bound, bool prio, hipStream_t stream)
 {
-    if (n < 1 || n > kRRBatchMax || !plan.d_table || plan.npieces < 1) return hipErrorInvalidValue;
+    if (n < 1 || n > kRRBatchMax) return hipErrorInvalidValue;
     RRBatch b;
     for (int i = 0; i < n; ++i) {
+        const TriPlan& plan = plans[i];
+        if (!plan.d_table || plan.npieces < 1) return hipErrorInvalidValue;
         RRParams& p = b.p[i];
         p = RRParams{};
         p.col_rows = banks[i]->rows8;  p.col_norm = banks[i]->norm;  p.ncols_pad = (int)banks[i]->n_pad;
@@ -831,17 +844,28 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan& 
     (void)prio;
     const bool merge = getenv("FM_TRI_MERGE") != nullptr;       // (measurement: both phases in ONE grid, diagonal blocks first)
     for (int phase = 0; phase < 2; ++phase) {
-        int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
-        if (merge) { if (phase == 1) break; first = 0; count = plan.npieces; }
-        if (count <= 0) continue;
-        for (int i = 0; i < n; ++i) b.p[i].tri = (const int4*)plan.d_table + first;
+        if (merge && phase == 1) break;
+        // the banks of a launch may differ in size (r05, last): bank i under its own plan, its workgroups
+        // [first_block[i], first_block[i + 1]) of the grid
+        long long total = 0;
+        for (int i = 0; i < n; ++i) {
+            const TriPlan& plan = plans[i];
+            int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
+            if (merge) { first = 0; count = plan.npieces; }
+            b.p[i].tri = (const int4*)plan.d_table + first;
+            b.first_block[i] = (int)total;
+            total += count > 0 ? count : 0;
+        }
+        if (total <= 0) continue;
+        if (total > INT32_MAX) return hipErrorInvalidValue;
         if (n == 1) {
-            hipLaunchKernelGGL((rowreduce_tri_kernel<1>), dim3(count), dim3(512), 0, stream, b.p[0]);
+            hipLaunchKernelGGL((rowreduce_tri_kernel<1>), dim3((unsigned)total), dim3(512), 0, stream, b.p[0]);
         } else {
             for (int i = n; i < kRRBatchMax; ++i) b.p[i] = b.p[0];
             b.n = n;
-            b.blocks_per_pair = count;
-            hipLaunchKernelGGL((rowreduce_tri_batch_kernel<1>), dim3(count * n), dim3(512), 0, stream, b);
+            b.first_block[n] = (int)total;
+            for (int i = n + 1; i <= kRRBatchMax; ++i) b.first_block[i] = INT32_MAX;
+            hipLaunchKernelGGL((rowreduce_tri_batch_kernel<1>), dim3((unsigned)total), dim3(512), 0, stream, b);
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -984,18 +1008,27 @@ RowReducePlan plan_rowreduce_self(int64_t n_pad, const Tuning& tn)
     return plan_rowreduce(n_pad, n_pad, t);
 }
 
-// Top-1 row-reduce of n <= kRRBatchMax bank pairs that share `plan` (same padded sizes) in one launch.
-hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan& plan,
+// Top-1 row-reduce of n <= kRRBatchMax bank pairs in one launch, pair i under plans[i] (any sizes; every plan in the shape the
+// batched kernel is built for: 4 blocks per wave, 8 waves).
+hipError_t launch_rowreduce_batch(int n, const Bank* const* cols, const Bank* const* red, const RowReducePlan* plans,
                                   unsigned long long* const* partial, int* const* bound, hipStream_t stream, bool self)
 {
-    if (n < 1 || n > kRRBatchMax || plan.nb != 4 || plan.nw != 8) return hipErrorInvalidValue;
+    if (n < 1 || n > kRRBatchMax) return hipErrorInvalidValue;
     RRBatch b;
-    for (int i = 0; i < n; ++i) fill_params(b.p[i], *cols[i], *red[i], plan, partial[i], bound[i]);
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (plans[i].nb != 4 || plans[i].nw != 8) return hipErrorInvalidValue;
+        fill_params(b.p[i], *cols[i], *red[i], plans[i], partial[i], bound[i]);
+        b.first_block[i] = (int)total;
+        total += rowreduce_grid(plans[i]);
+    }
+    if (total > INT32_MAX) return hipErrorInvalidValue;
     for (int i = n; i < kRRBatchMax; ++i) b.p[i] = b.p[0];
+    b.first_block[n] = (int)total;
+    for (int i = n + 1; i <= kRRBatchMax; ++i) b.first_block[i] = INT32_MAX;
     b.n = n;
-    b.blocks_per_pair = rowreduce_grid(plan);
-    if (self) hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1, true>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
-    else      hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1>), dim3(b.blocks_per_pair * n), dim3(64 * 8), 0, stream, b);
+    if (self) hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1, true>), dim3((unsigned)total), dim3(64 * 8), 0, stream, b);
+    else      hipLaunchKernelGGL((rowreduce_batch_kernel<4, 1, 8, 3, 1>), dim3((unsigned)total), dim3(64 * 8), 0, stream, b);
     return hipGetLastError();
 }
 

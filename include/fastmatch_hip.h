@@ -270,12 +270,14 @@ int  fm_wait(fm_ctx* ctx, int64_t ticket);
 
 /* n independent image pairs in one call, enqueued like n fm_match_accepted_async calls (same output
  * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
- * fm_sync).  Consecutive pairs whose banks have the same padded sizes go through the distance kernel
- * TOGETHER, up to eight pairs per launch (option "batch_group": up to sixteen): inside one launch the
+ * fm_sync).  Consecutive pairs go through the distance kernel TOGETHER, up to eight pairs per launch (option
+ * "batch_group": up to sixteen) -- r05: of ANY sizes (a dataset's images all differ; before, only pairs of equal padded sizes
+ * shared a launch and the others cost 7 % more per descriptor pair), as long as each is large enough for the 8-wave kernel
+ * (train banks from 32768 rows): inside one launch the
  * workgroups of the next pair fill the CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
  * a 100k x 100k pair).  The reference maps its matcher over the pairs of a dataset one after the
- * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (empty banks, a
- * different shape) are enqueued one by one; pairs on the float32 route, which has no enqueue-only form,
+ * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (empty banks, small
+ * ones) are enqueued one by one; pairs on the float32 route, which has no enqueue-only form,
  * run synchronously in their place (their outputs are complete when the call returns, the pairs around
  * them stay asynchronous).  Every pair is validated before anything is enqueued.  A run of pairs ends with
  * a short launch (2 pairs) because only the LAST launch's small kernels are exposed to a caller that

@@ -408,6 +408,35 @@ def test_batch_call_groups_pairs_of_one_shape_into_shared_launches(ctx):
     ctx.sync()
 
 
+def test_batch_call_takes_pairs_of_different_sizes_in_one_launch(ctx):
+    """r05: the pairs of a batched launch need not share a shape (a dataset's images all differ in size; before, such pairs
+    were enqueued one by one and cost 7 % more per descriptor pair): six pairs of six different (query, train) sizes go
+    out in two launches (4 + 2), every pair's accepted matches equal the synchronous call's; repeated."""
+    shapes = [(3000, 33000), (2500, 35000), (4100, 40001), (3000, 36500), (1800, 33000), (2900, 47000)]
+    sets = [_banks(ctx, nq, nt, seed=150 + k) for k, (nq, nt) in enumerate(shapes)]
+    pairs = [(p[2], p[3]) for p in sets]
+    want = [ctx.match_accepted(qb, tb, 0.75) for qb, tb in pairs]
+    outs = [(ctx.pinned_empty(4100, np.int32), ctx.pinned_empty(4100, np.int32),
+             ctx.pinned_empty(4100, np.float32), ctx.pinned_empty(4100, np.float64)) for _ in pairs]
+    counts = [ctx.pinned_empty(1, np.int64) for _ in pairs]
+    ctx.sync()
+    ctx.reset_stats()
+    for rep in range(3):
+        for c in counts:
+            c[0] = -1
+        ctx.match_accepted_batch(pairs, 0.75, outs, counts)
+        ctx.sync()
+        for (qa, ta, da, ra), out, cnt in zip(want, outs, counts):
+            m = int(cnt[0])
+            assert m == len(qa)
+            assert np.array_equal(out[0][:m], qa) and np.array_equal(out[1][:m], ta)
+            assert np.array_equal(out[2][:m], da) and np.array_equal(out[3][:m], ra)
+    assert sum(len(w[0]) for w in want) > 1000
+    st = ctx.stats()
+    assert st["pairs"] >= 3 * sum(nq * nt for nq, nt in shapes)
+    assert st["kernel_launches"] <= 3 * 2
+
+
 def test_gatherer_whole_steps_one_rank_rccl(tmp_path):
     """fm_match_accepted_dev_batch + one RCCL all-gather per step (three pairs), stream ordering only."""
     _run_ranks(1, "nccl", tmp_path, async_fill=2)

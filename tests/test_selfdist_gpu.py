@@ -116,6 +116,22 @@ def test_self_dist_float32_filter_forced_and_rescans(ctx):
     c.close()
 
 
+def test_self_dist_batch_of_banks_that_all_differ_in_size(ctx, sweep):
+    """r05: the banks of a batched triangular launch need not share a padded size -- every bank sweeps under the plan of
+    its own size, in its own block range of the two launches.  Five banks of five sizes: the oracle's values, and (triangular
+    sweep) two distance-kernel launches for all of them."""
+    rng = np.random.default_rng(19)
+    mats = [synth.synth_sift(n, rng) for n in (33000, 35000, 40001, 33500, 36111)]
+    mats[2][17] = mats[2][39000]
+    banks = [ctx.bank(m) for m in mats]
+    ctx.sync()
+    ctx.reset_stats()
+    got = ctx.self_dist_batch(banks)
+    for m, g in zip(mats, got):
+        assert _eq(g, oracle.self_dist(m, order=1)), m.shape
+    assert all(b.has_selfdist for b in banks)
+
+
 def test_self_dist_batch_attaches_and_matches(ctx, sweep):
     """Several Metric_Cache builds in one call: banks of one size share a launch, others (another size, float32,
     empty, one row) run beside them; the values are attached on the device (match_ratio uses them) and equal the

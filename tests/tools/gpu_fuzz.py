@@ -100,12 +100,21 @@ def fuzz_operators(rng):
             got = ctx.match_accepted(qb, tb, tau)
         else:
             n, cap = int(rng.integers(1, 5)), Q.shape[0]
+            plist = [(qb, tb)] * n
+            if kind != "nonint" and Q.dtype == np.uint8 and rng.integers(0, 2):
+                # r05: pairs of OTHER sizes between them (one batched launch takes pairs of any sizes: leading rows of the
+                # same banks, 30 .. 100 % of them, self distances of their own)
+                for _ in range(int(rng.integers(1, 4))):
+                    nq2, nt2 = max(1, int(Q.shape[0] * rng.uniform(0.3, 1.0))), max(1, int(T.shape[0] * rng.uniform(0.3, 1.0)))
+                    q2, t2 = ctx.bank(Q[:nq2]), ctx.bank(T[:nt2])
+                    q2.set_selfdist(oracle.self_dist(Q[:nq2], order=order))
+                    plist.insert(int(rng.integers(0, len(plist) + 1)), (q2, t2))
             outs = [(ctx.pinned_empty(cap, np.int32), ctx.pinned_empty(cap, np.int32), ctx.pinned_empty(cap, np.float32),
-                     ctx.pinned_empty(cap, np.float64)) for _ in range(n)]
-            cnts = [ctx.pinned_empty(1, np.int64) for _ in range(n)]
-            ctx.match_accepted_batch([(qb, tb)] * n, tau, outs, cnts)
+                     ctx.pinned_empty(cap, np.float64)) for _ in plist]
+            cnts = [ctx.pinned_empty(1, np.int64) for _ in plist]
+            ctx.match_accepted_batch(plist, tau, outs, cnts)
             ctx.sync()
-            k = int(rng.integers(0, n))
+            k = int(rng.choice([i for i, pr in enumerate(plist) if pr[0] is qb]))
             got = tuple(a[:int(cnts[k][0])] for a in outs[k])
         for g, e in zip(got, exp):
             assert eq(np.asarray(g), np.asarray(e)), tag
