@@ -119,7 +119,7 @@ namespace fm {
 //      of a handful -- so a row's visits must be spread over the whole sweep: in this order the pieces that run
 //      together stream rows at the same DISTANCE from their chunks, i.e. different rows, and a row meets its
 //      partners in order of that distance from both directions at once.
-// S = target, or (target 0) the S in 20 .. 72 whose workgroups a list schedule on the 512 resident slots finishes first.
+// S = target, or (target 0) the S in 20 .. 72 whose pieces leave the last wave of 512 resident workgroups fullest (plan_tri).
 static int tri_pieces(int nstages, int S, std::vector<int>* table, int* n_diag)
 {
     const int nchunks = (nstages + 3) / 4;
