@@ -566,7 +566,8 @@ class Context(object):
 
     def self_dist_batch(self, banks, want_host=True):
         """Metric_Cache builds of several images in one call (``fm_self_dist_batch``): the self distances of
-        every bank, attached to it on the device; banks of one size share a distance-kernel launch.
+        every bank, attached to it on the device; runs of integer banks (of any sizes, r05) share the
+        triangular sweep's launches, up to ``batch_group`` banks each.
         ``want_host``: also return them (list of float64 arrays; synchronous); False = enqueue only."""
         n = len(banks)
         if n == 0:

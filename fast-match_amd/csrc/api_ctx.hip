@@ -374,7 +374,6 @@ extern "C" int fm_ctx_destroy(fm_ctx* ctx)
     for (auto& m : ctx->marks) for (hipEvent_t ev : m.ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& sl : ctx->aslot) free_slot(sl);
     for (auto& sl : ctx->bslot) free_slot(sl);
-    for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
     if (ctx->upload) { (void)hipStreamSynchronize(ctx->upload); (void)hipStreamDestroy(ctx->upload); }
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->ev_consumer) (void)hipEventDestroy(ctx->ev_consumer);

@@ -394,30 +394,16 @@ extern "C" int fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table, 
 }
 
 // Plan + device table of the triangular sweep for banks of n_pad rows, kept per context.
-// Room for `need` more plans in the context's cache (a caller whose banks come in ever new sizes: the tables are small, but not
-// for ever -- beyond 64 the cache starts over; no launch that reads a table is in flight behind a synchronisation of the
-// context's stream).  Called ONCE in front of a group's tri_plan_for calls: the group's plans must all stay valid.
-static int tri_plans_room(fm_ctx* ctx, size_t need)
-{
-    if (ctx->tri_plans.size() + need <= 64) return FM_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto& kv : ctx->tri_plans) if (kv.second.d_table) (void)hipFree((void*)kv.second.d_table);
-    ctx->tri_plans.clear();
-    return FM_OK;
-}
-
+// The triangular sweep's plan of a bank size: piece length and workgroup counts by arithmetic (plan_tri, api_grid.hip); the
+// workgroups themselves follow from (chunks, stages, piece length) in the kernel (tri_entry, rowreduce.hip), so a plan owns
+// no device memory (r05, last) and the context keeps plans only to spare the arithmetic of a size it has seen.
 static int tri_plan_for(fm_ctx* ctx, int64_t n_pad, TriPlan* out)
 {
     const std::pair<int64_t, int> key(n_pad, ctx->tune.tri_stages * 2048 + ctx->tune.bound_every);
     auto it = ctx->tri_plans.find(key);
     if (it != ctx->tri_plans.end()) { *out = it->second; return FM_OK; }
-    std::vector<int> table;
-    TriPlan pl = plan_tri(n_pad, ctx->tune.tri_stages, &table);
-    int* d = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d, table.size() * sizeof(int)));
-    hipError_t e = hipMemcpy(d, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); HIP_TRY(ctx, e); }
-    pl.d_table = d;
+    if (ctx->tri_plans.size() >= 4096) ctx->tri_plans.clear();
+    TriPlan pl = plan_tri(n_pad, ctx->tune.tri_stages, nullptr);
     pl.bound_every = 1;
     for (int b = 2; b <= 1024; b <<= 1) if (ctx->tune.bound_every == b) pl.bound_every = b;
     ctx->tri_plans[key] = pl;
@@ -785,18 +771,17 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
             ++i;
             continue;
         }
-        if (ctx->tune.glds != 0 && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && b->n_pad >= 32768))) {
-            // every distance once: the triangular sweep, up to "batch_group" banks per launch (r05, last: of any sizes from
-            // 32768 padded rows on -- every bank under the plan of its own size)
-            auto tri_ok = [&](const fm_bank* x) {
-                return x->kind == FM_BANK_I8 && x->n > 0 && (ctx->tune.self_tri == 2 || x->n_pad >= 32768);
-            };
-            int g = 1;
-            while (i + g < n && g < group_max && g < kRRBatchMax && tri_ok(banks[i + g])) ++g;
+        // Every distance once: the triangular sweep, up to "batch_group" banks per launch, every bank under the plan of its
+        // own size.  Rule ("self_tri" 1): a bank of 32768 padded rows or more, or ANY run of two or more integer banks -- a
+        // dataset of small images (r05, last: 64 banks of ~12.5k rows took 65 us each one by one through the full sweep and
+        // take 23 us each in batched triangular launches; ~3k rows: 35 -> 9.5 us).
+        int g = 1;
+        if (ctx->tune.glds != 0 && ctx->tune.self_tri != 0)
+            while (i + g < n && g < group_max && g < kRRBatchMax && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0) ++g;
+        if (ctx->tune.glds != 0 && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && (b->n_pad >= 32768 || g >= 2)))) {
             TriPlan tps[kRRBatchMax];
             size_t boff[kRRBatchMax + 1];
             boff[0] = 0;
-            if ((rc = tri_plans_room(ctx, (size_t)g)) != FM_OK) return rc;
             for (int j = 0; j < g; ++j) {
                 if ((rc = tri_plan_for(ctx, banks[i + j]->n_pad, &tps[j])) != FM_OK) return rc;
                 boff[j + 1] = boff[j] + (((size_t)tps[j].ncols_alloc * 4 + 255) & ~(size_t)255);
@@ -826,7 +811,7 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
             continue;
         }
         const RowReducePlan pl = plan_rowreduce_self(b->n_pad, ctx->tune);
-        int g = 1;
+        g = 1;
         if (pl.nw == 8 && (ctx->tune.glds != 0) && pl.nbuf != 2)
             while (i + g < n && g < group_max && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0 && banks[i + g]->n_pad == b->n_pad) ++g;
         const bool coop = (ctx->tune.coop != 0) && pl.nsplit > 1;

@@ -75,7 +75,7 @@ struct fm_ctx {
     // fm_bank_refill_u8_async / fm_upload_fence: uploads run on a stream of their own beside the kernels
     hipStream_t upload = nullptr;
     hipEvent_t ev_upload = nullptr;
-    // fm_self_dist: plans of the triangular sweep by (padded rows, stages per workgroup); d_table is freed with the context
+    // fm_self_dist: plans of the triangular sweep by (padded rows, stages per workgroup) -- numbers only, no device memory
     std::map<std::pair<int64_t, int>, fm::TriPlan> tri_plans;
 };
 

@@ -126,7 +126,6 @@ struct TriPlan {
     int nchunks = 0, ncols_alloc = 0, npieces = 0, stages = 0;
     int ndiag = 0;                     // the first ndiag workgroups of the table are launch A (the diagonal blocks)
     int bound_every = 16;              // Tuning::bound_every (a power of two)
-    const int* d_table = nullptr;      // device: int4 per workgroup (chunk, first stage, end stage, 0)
 };
 TriPlan plan_tri(int64_t n_pad, int target_stages, std::vector<int>* table);
 hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* plans, int* const* bound, bool prio, hipStream_t stream);

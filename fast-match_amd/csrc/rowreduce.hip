@@ -72,8 +72,29 @@ struct RRParams {
     int            bound_mask;    // shared bounds are re-read at every stage of a sweep's first 8 and then at the stages
                                   // whose number & bound_mask == 0 (0: every stage; option "bound_every" 1 | 2 | 4 | 8)
     int            tri_nocol;     // TRI, measurements only (FM_TRI_NOCOL=1, WRONG results): the column direction never fires
-    const int4*    tri;           // TRI kernels: workgroup -> (output chunk, first stage, end stage, -), plan_tri's table
+    int            tri_first;     // TRI kernels: workgroup bid of a launch is entry tri_first + bid of the bank's workgroup list
+    int            tri_S;         // ... whose entries follow from (nchunks, nstages, tri_S) by arithmetic: tri_entry below
 };
+
+// Entry e of the triangular sweep's workgroup list (plan_tri / tri_pieces in api_grid.hip build the same list on the host, for
+// fm_self_dist_plan and the tests): the first nchunks entries are the diagonal blocks (chunk e against its own four stages);
+// then piece-number major -- round i holds piece i of every chunk k that still has stages from 4 k + 4 + i S on, i.e. the first
+// ceil((nstages - 4 - i S) / 4) chunks.  (r05, last: a device table per bank size -- hipMalloc, upload, a cache of 64 -- made
+// the plan of a NEW size cost ~50 us; a dataset of small images has a new size per image.)  Scalar: at most nstages / S rounds.
+__device__ __forceinline__ void tri_entry(int e, int nchunks, int nstages, int S, int& chunk, int& st0, int& st1)
+{
+    if (e < nchunks) { chunk = e; st0 = 4 * e; st1 = min(nstages, 4 * e + 4); return; }
+    int r = e - nchunks, i = 0;
+    for (;;) {
+        const int cnt = (nstages - 4 - i * S + 3) >> 2;       // chunks of round i (> 0 for every entry of the list)
+        if (r < cnt || cnt <= 0) break;
+        r -= cnt;
+        ++i;
+    }
+    chunk = r;
+    st0 = 4 * r + 4 + i * S;
+    st1 = min(nstages, st0 + S);
+}
 
 // Accumulator value of a masked (output row == reduced row) pair in the SELF kernels: below the padding
 // rows' -2^25, so the diagonal never beats anything, and (value << 5) still fits int32.
@@ -292,8 +313,8 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
     // workgroups (which reduce other slices for the same output rows) from their first tile on.
     int chunk, split, st0, st1;
     if constexpr (TRI) {
-        const int4 e = p.tri[bid];          // (uniform: scalar loads)
-        chunk = e.x; st0 = e.y; st1 = e.z; split = 0;
+        tri_entry(__builtin_amdgcn_readfirstlane(p.tri_first + bid), p.nchunks, p.nstages, p.tri_S, chunk, st0, st1);   // (uniform: scalar)
+        split = 0;
     } else {
         if (!map_block(p, bid, chunk, split)) return;
         st0 = split * p.stages_per_split;
@@ -829,7 +850,7 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* 
     RRBatch b;
     for (int i = 0; i < n; ++i) {
         const TriPlan& plan = plans[i];
-        if (!plan.d_table || plan.npieces < 1) return hipErrorInvalidValue;
+        if (plan.npieces < 1 || plan.stages < 4) return hipErrorInvalidValue;
         RRParams& p = b.p[i];
         p = RRParams{};
         p.col_rows = banks[i]->rows8;  p.col_norm = banks[i]->norm;  p.ncols_pad = (int)banks[i]->n_pad;
@@ -837,7 +858,7 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* 
         p.nstages = (int)(banks[i]->n_pad / kStageRows);
         p.nsplit = 1;  p.nchunks = plan.nchunks;  p.stages_per_split = p.nstages;  p.ncols_alloc = plan.ncols_alloc;
         p.partial = nullptr;  p.bound = bound[i];  p.order = 0;  p.bound_mask = plan.bound_every > 1 ? plan.bound_every - 1 : 0;
-        p.tri = (const int4*)plan.d_table;
+        p.tri_first = 0;  p.tri_S = plan.stages;
         p.tri_nocol = getenv("FM_TRI_NOCOL") ? 1 : 0;
     }
     // (one instantiation, with the s_setprio around the MFMA burst: the one without it does not fit 128 VGPRs)
@@ -852,7 +873,7 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* 
             const TriPlan& plan = plans[i];
             int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
             if (merge) { first = 0; count = plan.npieces; }
-            b.p[i].tri = (const int4*)plan.d_table + first;
+            b.p[i].tri_first = first;
             b.first_block[i] = (int)total;
             total += count > 0 ? count : 0;
         }

@@ -132,6 +132,29 @@ def test_self_dist_batch_of_banks_that_all_differ_in_size(ctx, sweep):
     assert all(b.has_selfdist for b in banks)
 
 
+def test_metric_caches_of_a_dataset_in_batched_launches(ctx):
+    """Metric_Cache.from_arrays_many: the caches of a dataset of small images (every image another size) with ALL self
+    distances -- originals and thumbnails -- from batched triangular launches: the same caches as from_arrays image by
+    image (values, attached banks), in a handful of distance-kernel launches instead of two per image."""
+    from fastmatch_amd import cache
+    images = []
+    for k, n in enumerate((2500, 3100, 1800, 4000, 2999, 3500)):
+        q, _ = synth.image_pair((500, 400), n, 300 + k, n_thumb=200 + 10 * k)
+        images.append({"descriptors": q["descriptors"], "positions": q["positions"], "size": q["size"],
+                       "thumb_descriptors": q["thumb_descriptors"], "thumb_positions": q["thumb_positions"],
+                       "thumb_size": q["thumb_size"]})
+    one_by_one = [cache.Metric_Cache.from_arrays(options={"context": ctx}, **im) for im in images]
+    ctx.sync()
+    ctx.reset_stats()
+    many = cache.Metric_Cache.from_arrays_many(images, {"context": ctx})
+    launches = ctx.stats()["kernel_launches"]
+    for a, b, im in zip(one_by_one, many, images):
+        assert _eq(a.original["distances"], b.original["distances"]) and _eq(a.thumb["distances"], b.thumb["distances"])
+        assert _eq(b.original["distances"], oracle.self_dist(im["descriptors"], order=1))
+        assert b.bank(ctx).has_selfdist and b.thumb_bank(ctx).has_selfdist and b.bank(ctx).n == len(im["descriptors"])
+    assert launches <= 2, launches          # twelve banks: one group of the triangular sweep (timed as one launch pair)
+
+
 def test_self_dist_batch_attaches_and_matches(ctx, sweep):
     """Several Metric_Cache builds in one call: banks of one size share a launch, others (another size, float32,
     empty, one row) run beside them; the values are attached on the device (match_ratio uses them) and equal the

@@ -29,6 +29,33 @@ def test_every_chunk_meets_every_later_stage_once(n_pad, stages):
     assert np.array_equal(cover, want.astype(np.int32))
 
 
+def _entry(e, nchunks, nstages, S):
+    """rowreduce.hip tri_entry, statement by statement: the kernel derives its workgroup from these numbers (no table)."""
+    if e < nchunks:
+        return e, 4 * e, min(nstages, 4 * e + 4)
+    r, i = e - nchunks, 0
+    while True:
+        cnt = (nstages - 4 - i * S + 3) >> 2
+        if r < cnt or cnt <= 0:
+            break
+        r -= cnt
+        i += 1
+    st0 = 4 * r + 4 + i * S
+    return r, st0, min(nstages, st0 + S)
+
+
+@pytest.mark.parametrize("n_pad", [128, 256, 512, 640, 1024, 3072, 12544, 33024, 100096, 250112])
+@pytest.mark.parametrize("stages", [0, 4, 5, 17, 39, 72, 400])
+def test_the_kernels_arithmetic_names_the_planners_workgroups(n_pad, stages):
+    """The device has no table (r05: a table per bank size made a NEW size cost a hipMalloc and an upload): entry e of the
+    host planner's list == what the kernel computes from (chunks, stages, piece length)."""
+    table, n_diag, used = _ffi.self_dist_plan(n_pad, stages)
+    nstages = n_pad // 128
+    nchunks = (nstages + 3) // 4
+    got = np.array([_entry(e, nchunks, nstages, used) for e in range(len(table))], dtype=np.int32).reshape(-1, 3)
+    assert np.array_equal(got, table[:, :3])
+
+
 def test_plan_rejects_bad_sizes():
     for n_pad in (0, 100, -128):
         with pytest.raises(fastmatch_amd.FastMatchHipError):
