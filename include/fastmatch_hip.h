@@ -90,7 +90,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "bound_every"  1..1024  K1 / K2: workgroups re-read the shared K-th-best bounds at every stage of a sweep's first
  *                         eight and then at every n-th (a power of two; 16).  A stale bound is merely weaker
  *   "self_tri"     0..2   fm_self_dist / fm_self_dist_batch on integer banks: 1 = the triangular sweep from 32768 padded rows
- *                         on (1), 0 = always the masked full sweep, 2 = always the triangular one
+ *                         on and for every run of two or more integer banks in a batch call, whatever their sizes (1),
+ *                         0 = always the masked full sweep, 2 = always the triangular one
  *   "tri_stages"   0..    ... 128-row stages per workgroup of its launch B (0 = chosen per bank size: fm_self_dist_plan)
  *   "refill_grid"  1..    fm_bank_refill_u8_async: workgroups of its preparation kernel (128: few, long-lived ones beside
  *                         the distance kernels)
@@ -188,6 +189,7 @@ int  fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, 
  * computed once and used for both of its rows' minima (rowreduce.hip, "TRI"); same values, bit for bit.        */
 int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
 /* HOST code, no context: the workgroups of that triangular sweep for a bank padded to n_pad rows (a multiple of 128)
+ * (the kernel itself holds no table: it derives workgroup i by the same arithmetic, rowreduce.hip tri_entry)
  * -- table[4 i .. 4 i + 3] = (output chunk of 512 rows, first 128-row stage, end stage, 0) of workgroup i, the first
  * *n_diag of them the diagonal blocks (launch A), the rest launch B; stages == 0 lets the library choose the piece
  * length (returned in *stages_used).  Writes min(cap, *n_workgroups) entries.  Every (chunk k, stage >= 4 k) is
@@ -195,8 +197,9 @@ int  fm_self_dist(fm_ctx* ctx, const fm_bank* bank, double* selfdist /*[n]*/);
 int  fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table /*[cap][4]*/, int64_t cap, int32_t* n_workgroups,
                        int32_t* n_diag, int32_t* stages_used);
 /* The Metric_Cache builds of n images in one call: self distances of every bank, ATTACHED to it on the device
- * (as fm_bank_set_selfdist would, without the trip through the host); consecutive integer-route banks of one
- * padded size share a distance-kernel launch (option "batch_group").  out == NULL (or every out[i] NULL):
+ * (as fm_bank_set_selfdist would, without the trip through the host); consecutive integer-route banks -- of any
+ * sizes (r05) -- share the triangular sweep's two launches, up to "batch_group" banks each: a dataset of small
+ * images builds its caches 2 - 3.7 x faster this way than bank by bank.  out == NULL (or every out[i] NULL):
  * enqueue only, complete after fm_sync / fm_wait; otherwise out[i] (may be NULL per bank) also receives bank i's
  * values and the call is synchronous.  A bank must not be read by work still in flight (see fm_bank_refill).  */
 int  fm_self_dist_batch(fm_ctx* ctx, int32_t n, fm_bank* const* banks, double* const* out /*[n] of [n_i], or NULL*/);
