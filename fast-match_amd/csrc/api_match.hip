@@ -1395,10 +1395,19 @@ static int batch_common(fm_ctx* ctx, int32_t n, const fm_bank* const* q, const f
         // the NEXT launch, so only the last launch's are exposed -- the run ends with a short launch (2 pairs)
         // (r05, last: the pairs of a run need not share their padded sizes any more -- every pair brings its own plan, the
         // launch its own block ranges -- only the kernel shape: 4 blocks per wave, 8 waves, three stage buffers)
+        // (a SMALL pair -- train bank below 32768 rows -- is planned with 4-wave workgroups when it runs alone, to fill the chip;
+        // in a batched launch the other pairs do that, so it is planned again in the batched kernel's shape: 64 pairs of
+        // ~12.5k x 12.5k rows 79 -> 44 us per pair, ~3k x 3k 49 -> 28, scripts/gpu_small_pairs.py)
         auto plan_fits = [&](int k, RowReducePlan* out) {
-            const RowReducePlan p = plan_rowreduce(t[k]->n_pad, q[k]->n_pad, ctx->tune);
+            if (ctx->tune.glds == 0) return false;
+            RowReducePlan p = plan_rowreduce(t[k]->n_pad, q[k]->n_pad, ctx->tune);
+            if (!(p.nb == 4 && p.nw == 8 && p.nbuf != 2) && ctx->tune.nb == 0 && ctx->tune.nw == 0) {
+                Tuning shaped = ctx->tune;
+                shaped.nb = 4; shaped.nw = 8;
+                p = plan_rowreduce(t[k]->n_pad, q[k]->n_pad, shaped);
+            }
             if (out) *out = p;
-            return p.nb == 4 && p.nw == 8 && (ctx->tune.glds != 0) && p.nbuf != 2;
+            return p.nb == 4 && p.nw == 8 && p.nbuf != 2;
         };
         int run = 1;
         if (batchable(i) && plan_fits(i, nullptr))
