@@ -393,7 +393,6 @@ extern "C" int fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table, 
     return FM_OK;
 }
 
-// Plan + device table of the triangular sweep for banks of n_pad rows, kept per context.
 // The triangular sweep's plan of a bank size: piece length and workgroup counts by arithmetic (plan_tri, api_grid.hip); the
 // workgroups themselves follow from (chunks, stages, piece length) in the kernel (tri_entry, rowreduce.hip), so a plan owns
 // no device memory (r05, last) and the context keeps plans only to spare the arithmetic of a size it has seen.
@@ -730,8 +729,9 @@ extern "C" int fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, do
 static int take_timer(fm_ctx* ctx, fm_ctx::PendingTimer* tm);
 
 // Self distances of n banks on the context's stream, each into d_out[i] (device, [banks[i]->n] float64).
-// Integer-valued banks: the masked-diagonal top-1 sweep (K1's top-1 kernel; launch_rowreduce_self), runs of
-// consecutive banks of one padded size through ONE launch (rowreduce_batch_kernel, up to "batch_group" banks);
+// Integer-valued banks: the triangular sweep (launch_rowreduce_tri: from 32768 padded rows on, and for every run of two or
+// more integer banks, of any sizes, up to "batch_group" banks per launch pair) or the masked-diagonal top-1 sweep (K1's top-1
+// kernel; launch_rowreduce_self; consecutive banks of one padded size through ONE launch of rowreduce_batch_kernel);
 // float32 banks: the float32 route with the diagonal masked (K8 filter + exact rescoring, or K5), one by one.
 // Banks with non-finite values keep the literal form (2-NN, second column).  Enqueue only; the split partials
 // live in ws_partial, which every user touches on ctx->stream only.  timed: record ev_k0 / ev_k1 around the
