@@ -87,8 +87,8 @@ extern "C" int fm_grid_pack_cells(const double* positions, int64_t n, int32_t wi
     for (int64_t p = 0; p < n; ++p) {
         const double x = positions[2 * p], y = positions[2 * p + 1];
         for (int k = 0; k < (int)n_member[(size_t)p]; ++k) {
-            const int64_t c = member[at_m++];
-            const int row = (int)(c % rows), col = (int)(c / rows);
+            const int32_t c = member[at_m++];
+            const int col = c / rows, row = c - col * rows;          // (32-bit: one short division per row of the packed bank)
             const int64_t at = cnt[(size_t)c]++;
             src_row[at] = (int32_t)p;
             // crop-local position (the crop starts at x_min = max(row * cell_w - margin, 0) along x), then the offset
