@@ -32,6 +32,7 @@ Extra option keys (additions): ``"context"``/``"device"`` select the GPU,
 """
 from collections import deque
 
+import os
 import numpy as np
 
 from . import matchutil
@@ -181,7 +182,7 @@ def match(query_cache, target_img, options={}):
     return get_matches
 
 
-def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_cap=0):
+def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_cap=0, plan=None):
     """Device-resident expansion state for (query_cache, target_grid), or False when the
     pair cannot use the device loop (oversize geometry, float32 banks the fp16 filter cannot
     take).  Integer-valued descriptors run the int8 round, others (RootSIFT-style float32)
@@ -190,7 +191,8 @@ def make_expander(query_cache, target_grid, radius, context, match_cap=0, stack_
     q_bank = query_cache.bank(context)
     if hasattr(target_grid.fun, "pack_plan") and target_grid.fun is target_grid.data:
         # pre-extracted target: each descriptor crosses PCIe once, the cells' copies are made by the upload kernel
-        src_row, t_pos, cell_off = target_grid.fun.pack_plan(target_grid)
+        # (``plan``: the same triple computed ahead of time -- match_many plans the pairs of a dataset on several host threads)
+        src_row, t_pos, cell_off = plan if plan is not None else target_grid.fun.pack_plan(target_grid)
         t_bank = context.bank_gather(target_grid.fun.descriptors, src_row, float_route=(q_bank.kind == _ffi.FM_BANK_F32))
     else:
         descs, t_pos, cell_off = target_grid.pack_cells()
@@ -375,11 +377,20 @@ def match_many(pairs, tau, options={}):
     prepared = options.get("prepared")
     if prepared is None:
         prepared = []
-        for query_cache, target in pairs:
-            grid = Grid_Cache(target, (grid_x, grid_y), target, margin=margin)
+        grids = [Grid_Cache(target, (grid_x, grid_y), target, margin=margin) for _, target in pairs]
+        # The cell plans of the pairs (which keypoint lands in which cells: host code of the library, 0.8 ms per 12.5k keypoints,
+        # twice the device loop's share of such a pair) on a few host threads: the call leaves the interpreter lock.
+        plans = [None] * len(pairs)
+        packable = [i for i, g in enumerate(grids) if hasattr(g.fun, "pack_plan") and g.fun is g.data]
+        if len(packable) >= 4:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+                for i, pl in zip(packable, pool.map(lambda i: grids[i].fun.pack_plan(grids[i]), packable)):
+                    plans[i] = pl
+        for (query_cache, target), grid, plan in zip(pairs, grids, plans):
             pos, ratios = match_thumbs(target, query_cache, thumb_x=thumb_x, thumb_y=thumb_y, context=context)
             prepared.append({"query": query_cache, "grid": grid, "seeds": pos, "ratios": ratios,
-                             "expander": make_expander(query_cache, grid, radius, context)})
+                             "expander": make_expander(query_cache, grid, radius, context, plan=plan)})
         if "prepared_out" in options:
             options["prepared_out"].extend(prepared)
     thumb_tau = thumb_strategy(tau)
