@@ -468,7 +468,7 @@ class Context(object):
 
     def set_option(self, name, value):
         """Per-context tuning / batch shape (fm_ctx_set_option): "batch_group", "batch_tail", "nsplit", "nb",
-        "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc",
+        "nw", "nbuf", "prio", "glds", "coop", "f32_filter", "f32_nw", "f32_nsplit", "f32_fused", "f32_lpc", "f32_bound_every",
         "async_time_every", "k1_order", "bound_every", "self_tri", "tri_stages", "refill_grid", "expand_big", "expand_huge", "expand_delegate", "expand_grow", "expand_prof".  Results never depend on them."""
         self._check(self.lib.fm_ctx_set_option(self.handle, name.encode(), int(value)))
 

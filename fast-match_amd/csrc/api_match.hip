@@ -430,16 +430,18 @@ static int rowreduce_f32_route(fm_ctx* ctx, const fm_bank* cols, const fm_bank* 
         return FM_OK;
     }
     const FilterPlan fp = plan_filter(cols->n_pad, red->n_pad, ctx->tune);
-    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part + fp.slots_bytes() + fp.bound_bytes() + 64);
+    const size_t bnd = (fp.bound_bytes() + 255) & ~(size_t)255;
+    int rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part + fp.slots_bytes() + bnd + fp.aux_bytes() + 64);
     if (rc != FM_OK) return rc;
     unsigned long long* d_part = (unsigned long long*)ctx->ws_partial;
     unsigned long long* d_slots = (unsigned long long*)((char*)ctx->ws_partial + part);
     int* d_bound = (int*)((char*)d_slots + fp.slots_bytes());
+    float* d_aux = (float*)((char*)d_bound + bnd);
     HIP_TRY(ctx, hipMemsetAsync(d_part, 0xff, pl.partial_bytes(ktop), ctx->stream));
     HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, filter_empty_bound(), (size_t)fp.ncols_alloc * 2, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(ctx, launch_filter(*cols, *red, ktop, fp, d_slots, d_bound, ctx->d_counters, d_part, ctx->stream, self));
+    HIP_TRY(ctx, launch_filter(*cols, *red, ktop, fp, d_slots, d_bound, ctx->d_counters, d_part, ctx->stream, self, d_aux));
     HIP_TRY(ctx, launch_rowreduce_f32(*cols, *red, ktop, pl, d_part, ctx->d_counters, ctx->stream, self));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     ctx->filter_launches += 1;

@@ -31,9 +31,11 @@
 //
 // Layout: rowsh [n_pad][128] fp16 (256 B per row); auxf [n_pad] float32 = -|m|^2/2 of the
 // scaled row (padding rows: -3.4e38, below every real accumulator value).
-// Staging: 128 rows (32 KiB) + 512 B aux per step by global_load_lds_dwordx4, double buffered;
-// the 16-byte chunk index of a row is XORed with (row & 15) on the source side so that the
-// ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
+// Staging: 128 rows (32 KiB) + 512 B aux per step by global_load_lds_dwordx4, double buffered
+// (LDS: rows of buffer 0 | rows of buffer 1 | aux 0 | aux 1, so that the buffers alternate by an XOR on
+// the address registers and the stage loop is a real loop); the 16-byte chunk index of a row is XORed
+// with (row & 15) on the source side so that the ds_read_b128 fragment reads of 16 consecutive rows
+// hit 16 different bank groups.
 #include "tile_ops.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -76,6 +78,8 @@ struct FParams {
     const float* col_rowsf;
     const float* red_rowsf;
     unsigned long long* partial;   // [n][KTOP] packed keys (split 0 of the caller's layout)
+    int          bound_mask;    // filter2_kernel: the shared bounds are re-read at every stage of a sweep's first 8, then at
+                                // the stages whose number & bound_mask == 0
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -93,21 +97,36 @@ __device__ __forceinline__ float fmax3(float a, float b, float c)
 }
 __device__ __forceinline__ float funmap(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
 
+constexpr int kFAuxBase = 2 * kFStageRowBytes;       // LDS offset of the aux words (512 B per buffer)
+
+// LDS-DMA of one stage: 32 pieces of 4 rows (1 KiB) + the aux words.  Scalar base + ONE 32-bit lane offset per piece and
+// the LDS destination in M0 straight from scalars (`wave` must be wave-uniform): the builtin's selection keeps a 64-bit
+// address pair per piece in VGPRs, which this kernel does not have.  Source chunk (lane & 15) ^ (row & 15) of row
+// 4 g + (lane >> 4) lands at chunk position lane & 15; (row & 15) = 4 (g & 3) | (lane >> 4), so a piece's lane offsets
+// are dma_lo ^ 64 (g & 3).
+// (M0 is a reserved register to the compiler and not accepted as a clobber: every use here sets it first, and the kernel
+// uses no builtin that reads it.)
+__device__ __forceinline__ void f_lds_dma_16(unsigned lds_addr, const void* sbase, unsigned voff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
 template <int NW>
-__device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char* buf, int wave, int lane)
+__device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char* smem, int buf, int wave, int lane)
 {
     const char* src_rows = p.red_rows + (size_t)stage * kFStageRowBytes;
-    constexpr int kPieces = (kFStageRows / 4) / NW;    // 1-KiB pieces (4 rows) per wave
+    const unsigned dma_lo = 256u * (unsigned)(lane >> 4) + 16u * (unsigned)((lane & 15) ^ (lane >> 4));
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    constexpr int kPieces = (kFStageRows / 4) / NW;    // pieces per wave
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-        const int g   = wave * kPieces + i;
-        const int row = g * 4 + (lane >> 4);
-        const int c   = (lane & 15) ^ (row & 15);       // source chunk stored at LDS chunk position lane & 15
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src_rows + row * kFRowBytes + c * 16), LDS_PTR(buf + g * 1024), 16, 0, 0);
+        const int g = wave * kPieces + i;
+        unsigned vo;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(vo) : "s"(64 * (g & 3)), "v"(dma_lo));
+        f_lds_dma_16(lds0 + (unsigned)buf * kFStageRowBytes + 1024u * (unsigned)g, src_rows + 1024 * g, vo);
     }
     if (wave == NW - 1 && lane < kFStageRows / 4)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p.red_aux + (size_t)stage * kFStageRows + lane * 4),
-                                         LDS_PTR(buf + kFStageRowBytes), 16, 0, 0);
+        f_lds_dma_16(lds0 + kFAuxBase + 512u * (unsigned)buf, p.red_aux + (size_t)stage * kFStageRows, 16u * (unsigned)lane);
 }
 
 // SELF (K = 1): both banks are the same bank and the pair (n, n) is masked -- the top-1 over the OTHER rows,
@@ -121,7 +140,7 @@ void filter_kernel(FParams p)
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g    = lane >> 4;
     const int c16  = lane & 15;
     const int chunk = blockIdx.x % p.nchunks;        // split major, as in rowreduce.hip
@@ -131,7 +150,7 @@ void filter_kernel(FParams p)
     const int st0 = split * p.stages_per_split;
     const int st1 = min(st0 + p.stages_per_split, p.nstages);
     // the first stage is in flight while the stationary operand is loaded
-    if (st0 < st1) f_issue_stage<NW>(p, st0, smem, wave, lane);
+    if (st0 < st1) f_issue_stage<NW>(p, st0, smem, 0, wave, lane);
 
     // Stationary operand: NC x 16 output rows, 4 K-steps of 32.
     v8h bh[NC][4];
@@ -161,10 +180,17 @@ void filter_kernel(FParams p)
     // returned values are consumed at the next hand-over: nothing issued in between is waited
     // for, and the wait of the hand-over finds only a stage-old LDS-DMA, loads and atomics.
     // The lane's threshold thr[] only ever rises.
+    // r06: a publish happens only for what CHANGED since the last hand-over (flag bits set by the visits;
+    // r05 re-published the K-th best of every owner lane at every stage: in the 2-NN shape of config 5 --
+    // 2560 workgroups x 122 stages -- that, the per-stage refresh and the per-tile rescaling of the
+    // accumulator inits were 0.4 ms of 2.4: profiles/r06a_*), and the shared bounds are re-read at every
+    // stage of a sweep's first 8, then at the stages whose number & bound_mask == 0.
+    // flags: bits 0-3 best changed (per block j; K = 2), 4-7 K-th best changed, 20-23 (K = 2) the value a
+    // publish to bound1 returned is pending in pend[j].
     float thr[NC];
-    int   gnext[NC];             // bound of rank K, loaded one stage ahead
+    int   gnext[NC];             // bound of rank K, loaded ahead
     int   pend[NC];              // K = 2: value returned by this lane's last bound1 publish
-    float last1[NC];             // K = 2: best acc this lane has published to bound1
+    unsigned flags = 0u;
     int* const bound1 = p.bound;
     int* const boundk = p.bound + (KTOP == 2 ? p.ncols_alloc : 0);
     const int kNone = fmap(kFEmpty);
@@ -174,190 +200,199 @@ void filter_kernel(FParams p)
         for (int i = 0; i < kFP; ++i) { ea[j][i] = kFEmpty; ei[j][i] = -1; }
         thr[j] = kFEmpty;
         pend[j] = kNone;
-        last1[j] = kFEmpty;
         gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // K = 2: turn the value returned by the last bound1 publish into a bound2 publish
-    auto settle = [&](int j) __attribute__((always_inline)) {
-        if constexpr (KTOP == 2) {
-            if (pend[j] != kNone) {
-                const float v2 = fminf(funmap(pend[j]), ea[j][0]);
-                __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pend[j] = kNone;
+    auto publish_all = [&]() __attribute__((always_inline)) {
+        if (__builtin_amdgcn_ballot_w64((flags & 0xf000ffu) != 0u) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if constexpr (KTOP == 2) {
+                    // turn the value returned by the last bound1 publish into a bound2 publish
+                    if (flags & (0x100000u << j)) {
+                        const float v2 = fminf(funmap(pend[j]), ea[j][0]);
+                        __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                // the lane's K-th best if that is what its threshold rests on
+                if ((flags & (0x10u << j)) && ea[j][KTOP - 1] - marg[j] >= thr[j])
+                    __hip_atomic_fetch_max(boundk + cb + 16 * j + c16, fmap(ea[j][KTOP - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (KTOP == 2) {
+                    // a new best row (only a CHANGED best: one published twice would meet its own first publish in bound1
+                    // and pass for two rows)
+                    if (flags & (1u << j)) {
+                        pend[j] = __hip_atomic_fetch_max(bound1 + cb + 16 * j + c16, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flags |= 0x100000u << j;
+                    } else {
+                        flags &= ~(0x100000u << j);
+                    }
+                }
             }
-        }
-    };
-    // publish what this lane knows and the others may not: its K-th best if that is what its
-    // threshold rests on (re-publishing an unchanged value is harmless), K = 2: a new best row
-    auto publish = [&](int j) __attribute__((always_inline)) {
-        int* const bk = boundk + cb + 16 * j + c16;
-        if (ea[j][KTOP - 1] - marg[j] >= thr[j] && ea[j][KTOP - 1] > kFEmpty)
-            __hip_atomic_fetch_max(bk, fmap(ea[j][KTOP - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (KTOP == 2) {
-            if (ea[j][0] > last1[j]) {
-                last1[j] = ea[j][0];
-                pend[j] = __hip_atomic_fetch_max(bound1 + cb + 16 * j + c16, fmap(ea[j][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            flags &= ~0xffu;
         }
     };
 
-    // per-lane LDS offsets of the A fragments: row c16 (+16 for the second tile), chunk (4s+g) ^ c16
+    // per-lane LDS addresses of the A fragments of the CURRENT half stage (bit 14) of the CURRENT buffer (bit 15):
+    // row c16, chunk (4s+g) ^ c16; the tiles of a half are the immediates 0, 4096, 8192, 12288
     int aoff[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) aoff[s] = c16 * kFRowBytes + 16 * ((4 * s + g) ^ c16);
-    const int xoff = kFStageRowBytes + 16 * g;
+    int xoff = kFAuxBase + 16 * g;      // aux words: + 64 per tile, bit 8 = half, bit 9 = buffer
+    int cur = 0;                        // (uniform) buffer being consumed
 
-    // Software pipeline.  The A fragments (and accumulator inits) of 16-row tile k+1 are read
-    // from LDS while the MFMAs of tile k run, so no MFMA waits on an LDS read.  The step from
-    // stage st to st+1 happens in front of the LAST tile of stage st: by then that tile's
-    // fragments are in registers, so after "my share of stage st+1 has landed" + one barrier
-    // every wave may read stage st+1 and buffer st&1 may be refilled with stage st+2.
-    constexpr int kTiles = kFStageRows / 16;
-    v8h fs[2][4];                 // fragment set k & 1 holds 16-row tile k of the stage
-    v4f cs[2];
-    auto load_tile = [&](int set, const char* buf, int k) __attribute__((always_inline)) {
-        const char* rows = buf + k * 16 * kFRowBytes;
-        cs[set] = *(const v4f*)(buf + xoff + k * 64);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fs[set][s] = __builtin_bit_cast(v8h, *(const v4i*)(rows + aoff[s]));
-    };
+    // ONE fragment set: fragment register s of the next tile is re-read from LDS right behind the four MFMAs that consume
+    // it (12 MFMAs = ~190 cycles before its next use).  TWO accumulator sets: the MFMAs of tile t and the reduce of tile
+    // t - 1 are one basic block (the compiler interleaves them), so a wave's next MFMAs never wait for a reduce chain.
+    // A stage is two passes over a chain of four tiles (the halves differ by an XOR on the address registers, as the
+    // buffers do): four copies of the visit.  (r06: this loop against r05's -- two fragment sets, reduce per 32-row unit
+    // behind a scheduling barrier, eight unrolled tiles -- 1.82-1.89 against 2.2 ms without visits in the 2-NN shape of
+    // config 5, profiles/r06a_*.)
+    v8h fs[4];
+    v4f cs;
+    // (red_aux is in accumulator units already: launch_filter rescales it into a scratch array for banks of different scales)
     if (st0 < st1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (st0 + 1 < st1) f_issue_stage<NW>(p, st0 + 1, smem + kFStageBytes, wave, lane);
-        load_tile(0, smem, 0);
+        if (st0 + 1 < st1) f_issue_stage<NW>(p, st0 + 1, smem, 1, wave, lane);
+        cs = *(const v4f*)(smem + xoff);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fs[s] = __builtin_bit_cast(v8h, *(const v4i*)(smem + aoff[s]));
         // bounds other workgroups have published already (loaded at the top) apply from the first tile on
 #pragma unroll
         for (int j = 0; j < NC; ++j) thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
     }
 
     v4f acc[2][NC];
-    // reduce epilogue of one 32-row unit (two tiles' accumulators)
-    auto reduce_unit = [&](int st, int u) __attribute__((always_inline)) {
-            float tmax[NC];
-            bool any = false;
+    unsigned long long hit[NC];         // the lanes whose fast test fired for block j (of the tile reduced last)
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                // v_maximum3_f32 (no NaN-quieting pre-pass as fmaxf needs); NaN cannot occur here
-                const float m0 = fmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
-                const float m1 = fmax3(acc[0][j][3], acc[1][j][0], acc[1][j][1]);
-                tmax[j] = fmax3(fmax3(acc[1][j][2], acc[1][j][3], m0), m1, m1);
-                any |= tmax[j] >= thr[j];
-            }
-#ifdef FM_ABLATE_F32_NOEXACT
-            // ablation build only (scripts/README.md): what the filter costs when NO unit takes the exact path -- the
-            // ceiling of anything a different lane mapping could save there.  Results are wrong in this build.
-            any = any && p.nstages < 0;         // (never true; a constant would let the compiler drop the MFMAs with the path)
-#endif
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                const int row0 = (st * (kFStageRows / 16) + 2 * u) * 16 + 4 * g;
+    for (int j = 0; j < NC; ++j) acc[1][j] = v4f{-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // "tile -1": nothing fires
+    // reduce of the tile in set S (number tile_no): hit[]
+    auto reduce_tile = [&](auto s_tag, int tile_no) __attribute__((always_inline)) -> bool {
+        constexpr int S = decltype(s_tag)::value;
+        if constexpr (SELF) {
+            // 16-row tile d of the wave's own rows faces block j = d: lane (c16, g) holds the pair (row 4 g + reg, output
+            // row c16), so the diagonal is reg = c16 & 3 of lane group c16 >> 2
+            const unsigned d = (unsigned)(tile_no - (cb >> 4));
+            if (d < (unsigned)NC) {
+                const bool dl = g == (c16 >> 2);
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
-                    if (__builtin_amdgcn_ballot_w64(tmax[j] >= thr[j]) != 0ull) {
-                        // A unit reaches this point because SOME lane of the wave holds a row at
-                        // or above its threshold -- typically one lane and one of its 8 rows.  The
-                        // P-step insertion costs ~6 VALU per step, so it runs only for the rows
-                        // that some lane actually wants (wave-uniform skip; a row below the lane's
-                        // threshold leaves its list unchanged either way).
-                        // (r04: the eight wave-wide tests first, back to back, as scalar masks -- the loop below then branches
-                        // on SGPRs.  Written as "compare, ballot, branch" per row the compiler emitted v_cmp -> vcc ->
-                        // s_cbranch_vccz eight times in a row, every branch waiting for the vector compare in front of it.)
-                        // (r05, tried and dropped: when the eight masks are disjoint -- scalar popcounts -- ONE straight-line
-                        // insertion of the lane's unit maximum instead of this loop: 2.82 -> 2.86-2.89 ms on one box,
-                        // profiles/r05b_k8_single_insertion_ab.log.  The branches are not what a visit costs.)
-                        unsigned long long wm[8];
+                    if ((unsigned)j == d) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) wm[r] = __builtin_amdgcn_ballot_w64(acc[r >> 2][j][r & 3] >= thr[j]);
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {                   // ascending row order
-                            if (wm[r] == 0ull) continue;
-                            const float av = acc[r >> 2][j][r & 3];
-                            const bool want = av >= thr[j];
-                            float a = want ? av : -INFINITY;
-                            int id = row0 + 16 * (r >> 2) + (r & 3);
-#pragma unroll
-                            for (int i = 0; i < kFP; ++i) {
-                                const bool b = a > ea[j][i];
-                                const float ta = b ? ea[j][i] : a;
-                                const int ti = b ? ei[j][i] : id;
-                                ea[j][i] = b ? a : ea[j][i];
-                                ei[j][i] = b ? id : ei[j][i];
-                                a = ta; id = ti;
-                            }
-                        }
-                        thr[j] = fmaxf(thr[j], ea[j][KTOP - 1] - marg[j]);
+                        for (int r = 0; r < 4; ++r)
+                            acc[S][j][r] = (dl && (c16 & 3) == r) ? -INFINITY : acc[S][j][r];
                     }
                 }
             }
-    };
-
-    auto stage = [&](auto buf_tag, int st) __attribute__((always_inline)) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        char* buf = smem + BUF * kFStageBytes;
+        }
 #pragma unroll
-        for (int k = 0; k < kTiles; ++k) {
-            if (k + 1 < kTiles) {
-                load_tile((k + 1) & 1, buf, k + 1);
-            } else {
-                // stage boundary (see above); the shared bounds are refreshed here, once per stage
-                if (st + 1 < st1) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifndef FM_ABLATE_K8_NOBARRIER      // ablation builds (scripts/gpu_k8_ablate.sh; their results are wrong): the waves' lock step
-                    __syncthreads();
+        for (int j = 0; j < NC; ++j)        // v_maximum3_f32 (no NaN-quieting pre-pass as fmaxf needs); NaN cannot occur here
+            hit[j] = __builtin_amdgcn_ballot_w64(fmax3(fmax3(acc[S][j][0], acc[S][j][1], acc[S][j][2]), acc[S][j][3], acc[S][j][3]) >= thr[j]);
+#ifdef FM_ABLATE_F32_NOEXACT
+        // ablation build only (scripts/README.md): what the filter costs when NO tile takes the exact path.  Results are wrong.
+        return (hit[0] | hit[1] | hit[2] | hit[3]) != 0ull && p.nstages < 0;
+#else
+        return (hit[0] | hit[1] | hit[2] | hit[3]) != 0ull;
 #endif
+    };
+    // tile K of half h of stage st: its MFMAs into set K & 1 and, in the same block, the reduce of the tile before it
+    auto tile = [&](auto k_tag, int st, int h) __attribute__((always_inline)) -> bool {
+        constexpr int K = decltype(k_tag)::value;
+        constexpr int KN = (K + 1) & 3;
+        constexpr int S = K & 1;
+        if constexpr (K == 3) {
+            if (h != 0 && st + 1 < st1) {
+                // stage boundary: this tile's fragments are in registers; behind "my share of stage st + 1 has landed" + one
+                // barrier every wave may read stage st + 1, and buffer `cur` may be refilled with stage st + 2
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef FM_ABLATE_K8_NOBARRIER      // ablation builds (scripts/gpu_k8_ablate.sh; their results are wrong): the waves' lock step
+                __syncthreads();
+#endif
+                const bool fresh = (st - st0 < 8) || (((st - st0) & p.bound_mask) == 0);
+                publish_all();
+                if (fresh) {
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        settle(j);
-                        thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
-                        publish(j);
-                    }
-                    if (st + 2 < st1) f_issue_stage<NW>(p, st + 2, buf, wave, lane);
-                    load_tile(0, smem + (BUF ^ 1) * kFStageBytes, 0);
+                    for (int j = 0; j < NC; ++j) thr[j] = fmaxf(thr[j], funmap(gnext[j]) - marg[j]);
+                }
+                if (st + 2 < st1) f_issue_stage<NW>(p, st + 2, smem, cur, wave, lane);
+                cur ^= 1;
+                if (fresh) {
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
                         gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int t = k & 1;
-                const v4f ci = cs[t] * p.aux_mul;
+            // the next tile is the first of the other half -- of the other buffer behind the second half
+            const int tog = h != 0 ? (kFStageRowBytes | (kFStageRowBytes >> 1)) : (kFStageRowBytes >> 1);
 #pragma unroll
-                for (int j = 0; j < NC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[t][0], bh[j][0], ci, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) aoff[s] ^= tog;
+            xoff ^= h != 0 ? (512 | 256) : 256;
+        }
 #pragma unroll
-                for (int s = 1; s < 4; ++s)
+        for (int j = 0; j < NC; ++j) acc[S][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[0], bh[j][0], cs, 0, 0, 0);
+        cs = *(const v4f*)(smem + xoff + KN * 64);
+        fs[0] = __builtin_bit_cast(v8h, *(const v4i*)(smem + aoff[0] + KN * 16 * kFRowBytes));
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[t][s], bh[j][s], acc[t][j], 0, 0, 0);
-                if constexpr (SELF) {
-                    // 16-row tile d of the wave's own rows faces block j = d: lane (c16, g) holds the pair (row
-                    // 4 g + reg, output row c16), so the diagonal is reg = c16 & 3 of lane group c16 >> 2
-                    const unsigned d = (unsigned)(st * kTiles + k - (cb >> 4));
-                    if (d < (unsigned)NC) {
-                        const bool dl = g == (c16 >> 2);
+        for (int s = 1; s < 4; ++s) {
 #pragma unroll
-                        for (int j = 0; j < NC; ++j) {
-                            if ((unsigned)j == d) {
+            for (int j = 0; j < NC; ++j) acc[S][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[s], bh[j][s], acc[S][j], 0, 0, 0);
+            fs[s] = __builtin_bit_cast(v8h, *(const v4i*)(smem + aoff[s] + KN * 16 * kFRowBytes));
+        }
+        return reduce_tile(std::integral_constant<int, S ^ 1>{}, st * (kFStageRows / 16) + 4 * h + K - 1);
+    };
+    // the exact path of one tile (number tile_no, accumulators in set S) whose fast test fired for some lane
+    auto visit = [&](auto s_tag, int tile_no) __attribute__((always_inline)) {
+        constexpr int S = decltype(s_tag)::value;
+        const int row0 = tile_no * 16 + 4 * g;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    acc[t][j][r] = (dl && (c16 & 3) == r) ? -INFINITY : acc[t][j][r];
-                            }
-                        }
-                    }
+        for (int j = 0; j < NC; ++j) {
+            if (hit[j] == 0ull) continue;
+            // A tile reaches this point because SOME lane of the wave holds a row at or above its threshold -- typically
+            // one lane and one of its 4 rows.  The P-step insertion costs ~6 VALU per step, so it runs only for the rows
+            // that some lane actually wants (wave-uniform skip; a row below the lane's threshold leaves its list unchanged).
+            // The wave-wide tests first, back to back, as scalar masks: the loop below then branches on SGPRs.
+            unsigned long long wm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wm[r] = __builtin_amdgcn_ballot_w64(acc[S][j][r] >= thr[j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                   // ascending row order
+                if (wm[r] == 0ull) continue;
+                const float av = acc[S][j][r];
+                float a = av >= thr[j] ? av : -INFINITY;
+                int id = row0 + r;
+#pragma unroll
+                for (int i = 0; i < kFP; ++i) {
+                    const bool b = a > ea[j][i];
+                    const float ta = b ? ea[j][i] : a;
+                    const int ti = b ? ei[j][i] : id;
+                    ea[j][i] = b ? a : ea[j][i];
+                    ei[j][i] = b ? id : ei[j][i];
+                    if (KTOP == 2 && i == 0) flags |= b ? (1u << j) : 0u;
+                    if (i == KTOP - 1) flags |= b ? (0x10u << j) : 0u;
+                    a = ta; id = ti;
                 }
             }
-            if (k & 1) reduce_unit(st, k >> 1);
+            thr[j] = fmaxf(thr[j], ea[j][KTOP - 1] - marg[j]);
         }
     };
 
-    for (int st = st0; st < st1; st += 2) {
-        stage(std::integral_constant<int, 0>{}, st);
-        if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+    int t0 = st0 * (kFStageRows / 16);
+#pragma unroll 1
+    for (int st = st0; st < st1; ++st) {
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h, t0 += 4) {
+            if (tile(std::integral_constant<int, 0>{}, st, h)) visit(std::integral_constant<int, 1>{}, t0 - 1);
+            if (tile(std::integral_constant<int, 1>{}, st, h)) visit(std::integral_constant<int, 0>{}, t0);
+            if (tile(std::integral_constant<int, 2>{}, st, h)) visit(std::integral_constant<int, 1>{}, t0 + 1);
+            if (tile(std::integral_constant<int, 3>{}, st, h)) visit(std::integral_constant<int, 0>{}, t0 + 2);
+        }
     }
+    // the last tile of the sweep
+    if (st0 < st1 && reduce_tile(std::integral_constant<int, 1>{}, t0 - 1)) visit(std::integral_constant<int, 1>{}, t0 - 1);
 
-    // last publishes (K = 2: the value returned now is needed, so this one is waited for), then
-    // emit every entry; rescore_kernel filters them against the final bound
-#pragma unroll
-    for (int j = 0; j < NC; ++j) { settle(j); publish(j); }
+    // last publishes: what changed since the last hand-over (K = 2: the value a publish returns is needed, so twice);
+    // then emit every entry; rescore_kernel filters them against the final bound
+    publish_all();
+    if constexpr (KTOP == 2) publish_all();
 #ifdef FM_ABLATE_K8_NORESCORE       // ... the sweep without its fused epilogue
     if (p.fused && p.nstages > 0) return;
 #endif
@@ -365,7 +400,6 @@ void filter_kernel(FParams p)
         // ---- exact rescoring in place (the rule of rescore_kernel below, on registers) --------------
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-            settle(j);
             const int n = cb + 16 * j + c16;
             const bool ok = n < p.ncols;
             // K-th best accumulator over the four lane groups (disjoint rows of the same output rows)
@@ -436,7 +470,6 @@ void filter_kernel(FParams p)
     }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        settle(j);
         const int n = cb + 16 * j + c16;
         unsigned long long* out = p.slots + (((size_t)split * p.ncols_alloc + n) * 4 + g) * kFP;
 #pragma unroll
@@ -482,9 +515,10 @@ void rescore_kernel(RParams p)
         unsigned long long slot = ~0ull;
         if (live && s < nslots) slot = p.slots[((size_t)(s >> 4) * p.ncols_alloc + nn) * (4 * kFP) + (s & 15)];
         const bool valid = slot != ~0ull && __uint_as_float((unsigned)(slot >> 32)) >= thr;
-        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
         // a lane's last (smallest) entry inside the margin: rows it dropped may be inside too
         incomplete |= valid && (s & (kFP - 1)) == kFP - 1;
+        if (vm == 0ull) continue;
         if (valid) {
             const unsigned idx = (unsigned)slot;
             const float4* rp = (const float4*)(p.red_rowsf + (size_t)idx * kDim);
@@ -601,6 +635,15 @@ void rescan_kernel(RParams p, int nred)
     }
 }
 
+// Accumulator inits of a reduced bank in the accumulator units of a pair of banks of different scales (times 2^(kc - km),
+// exact); padding rows keep their -3.4e38 so that no scale brings them above an empty threshold.
+__global__ __launch_bounds__(256)
+void aux_rescale_kernel(const float* __restrict__ aux, float* __restrict__ out, int64_t n, float mul)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float a = aux[i]; out[i] = a <= kFEmpty ? a : a * mul; }
+}
+
 FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
 {
     FilterPlan pl;
@@ -608,15 +651,17 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
     pl.fused = tn.f32_fused;
     pl.lpc = tn.f32_lpc;
     pl.nc = 4;                                        // (NC = 2 at 4 waves/SIMD was tried: it spills)
+    pl.bound_every = tn.f32_bound_every;
     const int cb = 16 * pl.nc * pl.nw;
     pl.nchunks = (int)((ncols_pad + cb - 1) / cb);
     if (pl.nchunks < 1) pl.nchunks = 1;
     pl.ncols_alloc = pl.nchunks * cb;
     const int64_t nstages = nred_pad / kFStageRows;
-    int64_t want = 5 * 256 * (8 / pl.nw);             // ~5 rounds of the workgroups the chip holds (2 / CU at nw = 4)
+    // workgroups the chip holds at once: 2 per CU at 4 waves, 1 at 8
+    const int64_t slots = 256 * (pl.nw == 8 ? 1 : 2);
+    int64_t want = 5 * slots;                         // ~5 rounds of them
     // a workgroup should sweep >= 64 stages (8192 rows: prologue and cold thresholds amortised),
     // unless that leaves fewer workgroups than the chip holds; never fewer than 4 stages
-    const int64_t slots = 256 * (8 / pl.nw);
     int64_t nsplit = (want + pl.nchunks - 1) / pl.nchunks;
     if (nsplit > nstages / 64) nsplit = nstages / 64;
     if (nsplit < 1) nsplit = 1;
@@ -633,6 +678,7 @@ FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn)
     if (nsplit < 1) nsplit = 1;
     pl.nsplit = (int)nsplit;
     pl.stages_per_split = (int)per;
+    pl.aux_elems = nred_pad;
     return pl;
 }
 
@@ -654,9 +700,10 @@ bool filter_usable(const Bank& cols, const Bank& red)
 
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& pl,
                          unsigned long long* slots, int* bound, int* flag,
-                         unsigned long long* partial, hipStream_t stream, bool self)
+                         unsigned long long* partial, hipStream_t stream, bool self, float* aux_scratch)
 {
     if (self && (ktop != 1 || &cols != &red)) return hipErrorInvalidValue;
+    if (cols.kscale != red.kscale && !aux_scratch) return hipErrorInvalidValue;
     const float eps = 1.1f / 1024.0f;
     const int dk = cols.kscale - red.kscale;          // acc units are 2^(kc + km)
     FParams p;
@@ -683,6 +730,13 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
     p.col_rowsf = cols.rowsf;
     p.red_rowsf = red.rowsf;
     p.partial = partial;
+    p.bound_mask = 0;
+    for (int b = 2; b <= 64; b <<= 1) if (pl.bound_every == b) p.bound_mask = b - 1;
+    if (dk != 0) {
+        hipLaunchKernelGGL(aux_rescale_kernel, dim3((unsigned)((red.n_pad + 255) / 256)), dim3(256), 0, stream,
+                           (const float*)red.auxf, aux_scratch, (int64_t)red.n_pad, p.aux_mul);
+        p.red_aux = aux_scratch;
+    }
     const int grid = pl.nchunks * pl.nsplit;
 #define FM_LAUNCH_FILTER(NC_, NW_)                                                                         \
     do {                                                                                                   \

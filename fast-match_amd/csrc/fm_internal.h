@@ -70,6 +70,7 @@ struct Tuning {
     int f32_nw = 0, f32_nsplit = 0;   // K8 launch shape overrides
     int f32_fused = -1;               // K8: rescoring inside the filter (-1 = when the plan has one split)
     int f32_lpc = 0;                  // K8 rescoring: lanes per output row (0 = rule)
+    int f32_bound_every = 4;          // K8: re-read the shared bounds every n-th stage once a sweep is 8 stages old (a power of two)
     int batch_group = 8;              // fm_match_accepted_batch: most pairs per distance-kernel launch (<= kRRBatchMax)
     int batch_tail = 2;               // ... pairs of the short launch a run ends with (0 = none)
     int async_time_every = 4;         // async calls: every n-th call carries kernel timing events (0 = none)
@@ -151,7 +152,10 @@ struct FilterPlan {
     int nsplit;
     int stages_per_split;   // 128-row stages
     int fused = -1, lpc = 0; // Tuning::f32_fused / f32_lpc
+    int bound_every = 4;     // Tuning::f32_bound_every
+    int64_t aux_elems = 0;   // floats of the rescaled accumulator inits (banks of different scales)
     size_t slots_bytes() const { return (size_t)nsplit * ncols_alloc * 16 * 8; }
+    size_t aux_bytes() const { return ((size_t)aux_elems * 4 + 255) & ~(size_t)255; }
     size_t bound_bytes() const { return (size_t)ncols_alloc * 8; }   // best and 2nd best
 };
 FilterPlan plan_filter(int64_t ncols_pad, int64_t nred_pad, const Tuning& tn);
@@ -160,7 +164,7 @@ size_t filter_flag_bytes();       // size of the device words launch_filter's `f
 bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry filter planes of compatible scale
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
-                         unsigned long long* partial, hipStream_t stream, bool self = false);
+                         unsigned long long* partial, hipStream_t stream, bool self = false, float* aux_scratch = nullptr);
 
 // ---- K4: one workgroup per expansion round (rounds.hip) --------------------------------
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,

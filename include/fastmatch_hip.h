@@ -83,6 +83,7 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *   "prio" "glds" "coop"  0|1  s_setprio around the MFMA burst / LDS-DMA staging / cross-workgroup bounds
  *   "f32_filter"   0..2   float32 route: 0 = all-pairs kernel only, 1 = fp16 filter for large calls, 2 = always
  *   "f32_nw" "f32_nsplit" "f32_fused" "f32_lpc"   K8 launch shape (0 / -1 = rule)
+ *   "f32_bound_every"    K8: re-read the shared bounds every n-th stage once a sweep is 8 stages old (1 .. 64, a power of two; 4)
  *   "async_time_every"    every n-th async call carries kernel-timing events (4; 0 = none)
  *   "k1_order"     0..2   K1: how workgroups map to (output chunk, split of the reduction range): 0 split major,
  *                         1 the workgroups of one XCD own a set of output chunks for all splits, 2 they own a

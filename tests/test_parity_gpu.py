@@ -865,6 +865,35 @@ def test_full_size_float32_route_config5(monkeypatch):
     assert _eq(i8[rows], oi) and _eq(d8[rows], od)
 
 
+def test_float32_route_results_do_not_depend_on_the_options(filter_ctx):
+    """The K8 launch-shape / tuning options (waves per workgroup, splits, fused or separate rescoring, lanes per output row,
+    how often the shared bounds are re-read) leave the 2-NN lists, the cross-check and the self distances bit-identical."""
+    c = filter_ctx
+    Q, T = _f32_kind("rootsift", 2300, 9100, 4242)
+    Q[5] = T[11]; T[12] = T[11]                              # an exact zero distance and a duplicate train row
+    qb, tb = c.bank(Q), c.bank(T)
+
+    def run():
+        return c.knn2(qb, tb) + c.xcheck1(qb, tb) + c.knn2(tb, qb) + (c.self_dist(tb),)
+    ref = run()
+    oi, od = oracle.bf_knn(Q, T, 2, order=1)
+    assert _eq(ref[0], oi) and _eq(ref[1], od)
+    domains = {"f32_nw": [0, 4, 8], "f32_nsplit": [0, 1, 2, 7], "f32_fused": [-1, 0, 1], "f32_lpc": [0, 1, 16, 64],
+               "f32_bound_every": [1, 2, 4, 16, 64]}
+    defaults = {k: c.get_option(k) for k in domains}
+    rng = np.random.default_rng(11)
+    settings = [{k: v} for k, vs in domains.items() for v in vs]
+    settings += [{k: int(rng.choice(vs)) for k, vs in domains.items()} for _ in range(8)]
+    for s in settings:
+        for k, v in defaults.items():
+            c.set_option(k, v)
+        for k, v in s.items():
+            c.set_option(k, v)
+        got = run()
+        assert all(_eq(a, b) for a, b in zip(got, ref)), s
+    assert c.f32_filter_stats()[1] == 0                     # never through the all-pairs kernel
+
+
 def test_results_do_not_depend_on_the_options():
     """fm_ctx_set_option: every launch-shape / tuning option, alone and in random combinations, leaves the
     2-NN lists, the cross-check and the accepted matches bit-identical (the header promises it)."""
