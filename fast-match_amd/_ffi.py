@@ -5,6 +5,7 @@ the HIP kernels.  There is no CPU fallback: if the library is missing, or no gfx
 device is present, every compute entry point raises ``FastMatchHipError``.
 """
 import ctypes
+import weakref
 import importlib.util
 import os
 import sys
@@ -37,7 +38,7 @@ class fm_stats_ex(ctypes.Structure):
                 ("bytes_moved", ctypes.c_int64)]
 
 
-FM_ABI_VERSION = 7          # include/fastmatch_hip.h: the revision this binding was written against
+FM_ABI_VERSION = 8          # include/fastmatch_hip.h: the revision this binding was written against
 
 
 class fm_expand_desc(ctypes.Structure):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "fm_upload_fence": (_INT, [_P]),
     "fm_self_dist_batch": (_INT, [_P, ctypes.c_int32, _P, _P]),
     "fm_knn2": (_INT, [_P, _P, _P, _P, _P]),
+    "fm_knn": (_INT, [_P, _P, _P, ctypes.c_int32, _P, _P]),
     "fm_xcheck1_keys": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_xcheck1_keys_dev": (_INT, [_P, _P, _P, _I64, _P]),
     "fm_knn2_ratio": (_INT, [_P, _P, _P, ctypes.c_double, _I64, _P, _P, _P, _P, ctypes.POINTER(_I64)]),
@@ -259,6 +261,7 @@ class Bank(object):
     def __init__(self, ctx, handle, n, dim, kind):
         self.ctx, self.handle, self.n, self.dim, self.kind = ctx, handle, n, dim, kind
         self.has_selfdist = False
+        ctx._children.add(self)           # (a context that is closed first destroys what was made through it)
 
     def set_selfdist(self, selfdist):
         sd = np.ascontiguousarray(selfdist, dtype=np.float64)
@@ -344,6 +347,7 @@ class Expander(object):
         h = _P()
         ctx._check(ctx.lib.fm_expand_create(ctx.handle, ctypes.byref(d), ctypes.byref(h)))
         self.handle = h
+        ctx._children.add(self)
         self._banks = (q_bank, t_bank)            # the banks must outlive the expander
         # host copies of the positions the log's records are rebuilt from (fetch_log)
         self.q_pos = q_pos
@@ -361,7 +365,7 @@ class Expander(object):
 
     def fetch_log(self, slot=0):
         """The log of the last run in ``slot``: (query_pos f64[n, 2], target_pos f64[n, 2], cell i64[n], n_accepted i64[n]
-        (-1: the cell had no features), query_row i32[m], target_row i32[m], ratio f64[m]) -- rounds in order, the accepted
+        (-1: the cell had no features, -2: no cross-checked pair), query_row i32[m], target_row i32[m], ratio f64[m]) -- rounds in order, the accepted
         matches of all rounds back to back."""
         nr, ne = _I64(0), _I64(0)
         self.ctx._check(self.ctx.lib.fm_expand_log_counts(self.ctx.handle, self.handle, int(slot), ctypes.byref(nr), ctypes.byref(ne)))
@@ -444,6 +448,10 @@ class Context(object):
                                     % (device, rc, msg.decode() if msg else "?"))
         self.handle = h
         self.device = int(device)
+        # banks and expanders made through this context (weak references): fm_bank_destroy / fm_expand_destroy need a live
+        # context, so close() destroys the ones still open first -- r06's memory soak found 9.5 MB of device memory per
+        # context left behind by `c.close()` with banks open (their own close() could no longer reach the library)
+        self._children = weakref.WeakSet()
 
     def _check(self, rc):
         if rc != 0:
@@ -454,6 +462,13 @@ class Context(object):
 
     def close(self):
         if self.handle is not None:
+            kids = list(getattr(self, "_children", ()))
+            for k in kids:                        # expanders first: they borrow their banks
+                if isinstance(k, Expander):
+                    k.close()
+            for k in kids:
+                if not isinstance(k, Expander):
+                    k.close()
             for p in getattr(self, "_pinned", []):
                 self.lib.fm_host_free(self.handle, p)
             self._pinned = []
@@ -557,6 +572,13 @@ class Context(object):
         idx = np.empty((q.n, 2), dtype=np.int32)
         dist = np.empty((q.n, 2), dtype=np.float32)
         self._check(self.lib.fm_knn2(self.handle, q.handle, t.handle, _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def knn(self, q, t, k):
+        """``fm_knn``: k-NN lists for 1 <= k <= 8 (idx int32[nq, k], dist float32[nq, k]; -1 / inf where t has fewer rows)."""
+        idx = np.empty((q.n, int(k)), dtype=np.int32)
+        dist = np.empty((q.n, int(k)), dtype=np.float32)
+        self._check(self.lib.fm_knn(self.handle, q.handle, t.handle, int(k), _ptr(idx), _ptr(dist)))
         return idx, dist
 
     def self_dist(self, bank):

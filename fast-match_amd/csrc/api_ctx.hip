@@ -352,6 +352,9 @@ extern "C" int fm_ctx_create(int device_id, fm_ctx** out)
     for (const OptionDef& o : kOptions)
         if (o.env) if (const char* s = getenv(o.env)) { const long v = atol(s); if (v >= o.lo && v <= o.hi) ctx->tune.*(o.field) = (int)v; }
     if (getenv("FM_EXPAND_NO_BIG")) ctx->tune.expand_big = 0;
+    ctx->dbg_f32 = getenv("FM_F32_DEBUG") != nullptr;
+    ctx->dbg_expand = getenv("FM_EXPAND_DEBUG") != nullptr;
+    ctx->dbg_park = ctx->dbg_expand && getenv("FM_PARK_PROF") != nullptr;
     if (hipMalloc((void**)&ctx->d_counters, filter_flag_bytes()) != hipSuccess || hipMemset(ctx->d_counters, 0, filter_flag_bytes()) != hipSuccess) {
         (void)hipGetLastError();
         ctx->d_counters = nullptr;
@@ -508,7 +511,7 @@ extern "C" int fm_f32_filter_stats(fm_ctx* ctx, int64_t* launches, int64_t* fall
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, 16, hipMemcpyDeviceToHost));
     }
-    if (getenv("FM_F32_DEBUG")) fprintf(stderr, "[fm] filter: launches %lld, redone by K5 %d, output rows rescanned %d\n",
+    if (ctx->dbg_f32) fprintf(stderr, "[fm] filter: launches %lld, redone by K5 %d, output rows rescanned %d\n",
                                         (long long)ctx->filter_launches, c[2], c[3]);
     if (launches) *launches = ctx->filter_launches;
     if (fallbacks) *fallbacks = c[2];

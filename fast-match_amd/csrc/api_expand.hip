@@ -165,13 +165,20 @@ static void expand_bind_run(ExpandPair& P, const ExpandRun& r, const fm_expand* 
 }
 
 // A run that ended with FM_EXPAND_LOG_FULL gets log arrays four times as large (both: which one filled is not told).
+// The larger arrays are allocated FIRST; the old ones and their capacities stand when that fails (the run then keeps its
+// FM_EXPAND_LOG_FULL status and the caller is not asked to try again at 16 times the size).
 static int expand_log_grow(fm_ctx* ctx, const fm_expand* ex, ExpandRun& r)
 {
     const int64_t limit = (int64_t)1 << 28;
     if (r.lg_entry_cap >= limit || r.lg_round_cap >= limit) return FM_ENOMEM;
-    if (r.logb) { (void)hipFree(r.logb); r.logb = nullptr; }
-    r.lg_round_cap *= 4; r.lg_entry_cap *= 4;
-    return expand_run_log(ctx, ex, r);
+    ExpandRun bigger = r;
+    bigger.logb = nullptr;
+    bigger.lg_round_cap = r.lg_round_cap * 4; bigger.lg_entry_cap = r.lg_entry_cap * 4;
+    const int rc = expand_run_log(ctx, ex, bigger);
+    if (rc != FM_OK) return rc;
+    if (r.logb) (void)hipFree(r.logb);
+    r.logb = bigger.logb; r.lg_round_cap = bigger.lg_round_cap; r.lg_entry_cap = bigger.lg_entry_cap;
+    return FM_OK;
 }
 
 extern "C" int fm_expand_create(fm_ctx* ctx, const fm_expand_desc* d, fm_expand** out)
@@ -350,13 +357,14 @@ extern "C" int fm_expand_run_lazy(fm_ctx* ctx, fm_expand* ex, const double* seed
     host.delegate_min = host.tie_guard ? 0 : ctx->tune.expand_delegate;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     long long res[16] = {0};
+    bool log_stuck = false;              // no memory for a larger log: FM_EXPAND_LOG_FULL stands
     for (int grown = 0;;) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->ws_in, &host, sizeof(ExpandPair), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, launch_expand(ctx->ws_in, 1, f32, 3, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(res, r->result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (res[3] == 9 && grown < 12 && expand_log_grow(ctx, ex, *r) == FM_OK) {
+        if (res[3] == 9 && grown < 12 && !log_stuck && (log_stuck = expand_log_grow(ctx, ex, *r) != FM_OK) == false) {
             // the log filled: larger arrays and the run from its start (the cells computed so far stay)
             ++grown;
             HIP_TRY(ctx, hipMemsetAsync(r->seen, 0xff, (size_t)((char*)r->found - (char*)r->seen) + (size_t)r->found_cap * 16, ctx->stream));
@@ -444,7 +452,8 @@ extern "C" int fm_expand_info(const fm_expand* ex, int64_t* state_bytes, int32_t
     if (state_bytes) {
         const int64_t found_cap = pow2_at_least(4 * ex->match_cap);
         *state_bytes = (int64_t)(al256((size_t)ex->stack_cap * 32) + al256((size_t)ex->seen_cap * 8) + al256((size_t)found_cap * 16) +
-                                 al256((size_t)ex->match_cap * 4) + al256((size_t)ex->match_cap * 32) + al256((size_t)ex->match_cap * 8) + 256);
+                                 al256((size_t)ex->match_cap * 4) + al256((size_t)ex->match_cap * 32) + al256((size_t)ex->match_cap * 8) +
+                                 al256((size_t)kExpResultWords * 8) + 256);       // (result words + resume state: expand_run_alloc)
         if (ex->want_log) {              // the log arrays at their first capacities (expand_run_log)
             const int64_t rc0 = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(4096, 4 * ex->ncells);
             const int64_t ec0 = ex->log_cap0 > 0 ? ex->log_cap0 : std::max<int64_t>(65536, 4 * ex->nq);
@@ -602,7 +611,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
     // h_cand[], the round's (subset size, first train row, train rows) in its resume state; K1 + the election fill its
     // h_qbest[] on the whole GPU, then the parked runs are launched again with resume = 2 -- until none parks.
     int64_t delegated = 0;
-    const bool dbg = getenv("FM_EXPAND_DEBUG") != nullptr;
+    const bool dbg = ctx->dbg_expand;
     double t_dense = 0.0, t_launch = 0.0, t_wait = 0.0;      // host seconds: enqueueing the dense kernels / the resumed runs / waiting
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto settle_parked = [&](const std::vector<int>& among) -> int {
@@ -660,7 +669,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
                 continue;                                 // (no memory for the tables: the status stands)
             }
             if (st == 9 && log_grows[(size_t)i] < 12) {                 // the log filled: larger arrays, the run again
-                if (expand_log_grow(ctx, pairs[i], *r) != FM_OK) continue;
+                if (expand_log_grow(ctx, pairs[i], *r) != FM_OK) { log_grows[(size_t)i] = 12; continue; }   // (no memory: the status stands)
                 ++log_grows[(size_t)i];
                 expand_bind_run(host[i], *r, big[(size_t)i] == 2 ? pairs[i] : nullptr);
                 redo.push_back(i);
@@ -697,7 +706,7 @@ extern "C" int fm_expand_run(fm_ctx* ctx, int32_t n, fm_expand* const* pairs, co
         if (res[(size_t)i * 8 + 3] == 0 && (int)big[(size_t)i] > pairs[i]->tier_hint) pairs[i]->tier_hint = (int)big[(size_t)i];
     }
     ctx->tune.delegated_rounds = (int)std::min<int64_t>((int64_t)INT32_MAX, (int64_t)ctx->tune.delegated_rounds + delegated);
-    if (dbg && getenv("FM_PARK_PROF")) {               // (a library built with -DFM_PARK_PROF: expand.hip)
+    if (ctx->dbg_park) {               // (a library built with -DFM_PARK_PROF: expand.hip)
         long long pr[kExpResultWords];
         (void)hipMemcpy(pr, run[0]->result, sizeof(pr), hipMemcpyDeviceToHost);
         static const char* hn[7] = {"pop + radius walk", "list + histogram + bounds", "partition", "chunk sorts (+ x-check)", "step 4", "step 5", "rounds that fit"};

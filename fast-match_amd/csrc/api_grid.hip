@@ -168,8 +168,21 @@ TriPlan plan_tri(int64_t n_pad, int target, std::vector<int>* table)
     }
     if (S < 4) S = 4;
     pl.stages = S;
-    if (table) table->clear();
-    pl.npieces = tri_pieces(nstages, S, table, &pl.ndiag);
+    if (table) {
+        table->clear();
+        pl.npieces = tri_pieces(nstages, S, table, &pl.ndiag);
+        return pl;
+    }
+    // the counts alone by arithmetic, in 64 bits (counted in an int by walking every piece, the count of a
+    // bank beyond ~140M rows went negative; such a bank is kept off this sweep altogether: kTriMaxRows)
+    long long np = pl.nchunks;
+    for (int k = 0; k < pl.nchunks; ++k) {
+        const int rem = nstages - (4 * k + 4);
+        if (rem <= 0) break;
+        np += (rem + S - 1) / S;
+    }
+    pl.ndiag = pl.nchunks;
+    pl.npieces = np <= INT32_MAX ? (int)np : 0;         // (0: launch_rowreduce_tri refuses the plan)
     return pl;
 }
 

@@ -381,15 +381,20 @@ __global__ void selfdist_tri_finish_kernel(TriFinish m)
 extern "C" int fm_self_dist_plan(int64_t n_pad, int32_t stages, int32_t* table, int64_t cap, int32_t* n_workgroups,
                                  int32_t* n_diag, int32_t* stages_used)
 {
-    if (n_pad < kStageRows || n_pad % kStageRows != 0 || n_pad > (int64_t)1 << 30 || stages < 0 || cap < 0 || (cap > 0 && !table))
-        return fail(nullptr, FM_EINVAL, "fm_self_dist_plan: n_pad must be a positive multiple of 128, stages >= 0");
-    std::vector<int> tb;
-    const TriPlan pl = plan_tri(n_pad, stages, &tb);
-    if (n_workgroups) *n_workgroups = pl.npieces;
-    if (n_diag) *n_diag = pl.ndiag;
-    if (stages_used) *stages_used = pl.stages;
-    const int64_t m = cap < pl.npieces ? cap : pl.npieces;
-    for (int64_t i = 0; i < 4 * m; ++i) table[i] = tb[(size_t)i];
+    if (n_pad < kStageRows || n_pad % kStageRows != 0 || n_pad > kTriMaxRows || stages < 0 || cap < 0 || (cap > 0 && !table))
+        return fail(nullptr, FM_EINVAL, "fm_self_dist_plan: n_pad must be a positive multiple of 128 up to 2^26, stages >= 0");
+    try {
+        // (the count-only call -- cap 0 -- builds no table: 16 bytes per workgroup, a million of them for a 3M-row bank)
+        std::vector<int> tb;
+        const TriPlan pl = plan_tri(n_pad, stages, cap > 0 ? &tb : nullptr);
+        if (n_workgroups) *n_workgroups = pl.npieces;
+        if (n_diag) *n_diag = pl.ndiag;
+        if (stages_used) *stages_used = pl.stages;
+        const int64_t m = cap < pl.npieces ? cap : pl.npieces;
+        for (int64_t i = 0; i < 4 * m; ++i) table[i] = tb[(size_t)i];
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, FM_ENOMEM, "fm_self_dist_plan: out of host memory");
+    }
     return FM_OK;
 }
 
@@ -681,6 +686,48 @@ extern "C" int fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t*
     return cs.finish();
 }
 
+// knnMatch(dt1, dt2, k) for any k the signature of the reference's bf_match / flann_match admits (matchutil.py:39-43, 46-67).
+extern "C" int fm_knn(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t k, int32_t* idx, float* dist)
+{
+    int rc = check_pair(ctx, q, t, "fm_knn");
+    if (rc != FM_OK) return rc;
+    if (k < 1) return fail(ctx, FM_EINVAL, "fm_knn: k must be at least 1");
+    if (k > 8) return fail(ctx, FM_EUNSUPPORTED, "fm_knn: k above 8 is not built (cv2.BFMatcher.knnMatch takes any k; the reference calls it with 1 and 2)");
+    const int64_t nq = q->n;
+    if (nq > 0 && (!idx || !dist)) return fail(ctx, FM_EINVAL, "fm_knn: output pointer is NULL");
+    if (nq == 0) return FM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t out_bytes = (size_t)nq * (size_t)(k < 2 ? 2 : k) * 4;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, 2 * ((out_bytes + 255) & ~(size_t)255) + 64)) != FM_OK) return rc;
+    int32_t* d_idx = (int32_t*)ctx->ws_out;
+    float* d_dist = (float*)((char*)ctx->ws_out + ((out_bytes + 255) & ~(size_t)255));
+    CallScope cs(ctx);
+    if (k <= 2) {
+        // the matrix-core path; k = 1 is the first column of the 2-NN lists
+        if ((rc = knn2_device(ctx, q, t, d_idx, d_dist)) != FM_OK) return rc;
+        if (k == 2) {
+            HIP_TRY(ctx, d2h(ctx, idx, d_idx, (size_t)nq * 8));
+            HIP_TRY(ctx, d2h(ctx, dist, d_dist, (size_t)nq * 8));
+        } else {
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_idx + 2 * nq, 4, d_idx, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_dist + 2 * nq, 4, d_dist, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, d2h(ctx, idx, d_idx + 2 * nq, (size_t)nq * 4));
+            HIP_TRY(ctx, d2h(ctx, dist, d_dist + 2 * nq, (size_t)nq * 4));
+        }
+        return cs.finish();
+    }
+    if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, knnk_partial_bytes(nq, t->n, k) + 64)) != FM_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(ctx, launch_knnk(*q, *t, k, (unsigned long long*)ctx->ws_partial, d_idx, d_dist, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    ctx->kernel_timed = true;
+    ctx->pending_pairs += nq * t->n;
+    ctx->pending_bytes += bank_bytes(q) + bank_bytes(t);
+    HIP_TRY(ctx, d2h(ctx, idx, d_idx, (size_t)nq * k * 4));
+    HIP_TRY(ctx, d2h(ctx, dist, d_dist, (size_t)nq * k * 4));
+    return cs.finish();
+}
+
 extern "C" int fm_knn2_ratio(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, double tau, int64_t cap,
                              int32_t* qidx, int32_t* tidx, float* dist, double* ratio, int64_t* n_accepted)
 {
@@ -778,9 +825,11 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
         // dataset of small images (r05, last: 64 banks of ~12.5k rows took 65 us each one by one through the full sweep and
         // take 23 us each in batched triangular launches; ~3k rows: 35 -> 9.5 us).
         int g = 1;
-        if (ctx->tune.glds != 0 && ctx->tune.self_tri != 0)
-            while (i + g < n && g < group_max && g < kRRBatchMax && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0) ++g;
-        if (ctx->tune.glds != 0 && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && (b->n_pad >= 32768 || g >= 2)))) {
+        const bool tri_fits = b->n_pad <= kTriMaxRows;
+        if (ctx->tune.glds != 0 && ctx->tune.self_tri != 0 && tri_fits)
+            while (i + g < n && g < group_max && g < kRRBatchMax && banks[i + g]->kind == FM_BANK_I8 && banks[i + g]->n > 0 &&
+                   banks[i + g]->n_pad <= kTriMaxRows) ++g;
+        if (ctx->tune.glds != 0 && tri_fits && (ctx->tune.self_tri == 2 || (ctx->tune.self_tri == 1 && (b->n_pad >= 32768 || g >= 2)))) {
             TriPlan tps[kRRBatchMax];
             size_t boff[kRRBatchMax + 1];
             boff[0] = 0;

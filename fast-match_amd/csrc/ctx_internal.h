@@ -22,6 +22,9 @@ struct fm_ctx {
     hipEvent_t ev_call0 = nullptr, ev_call1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
     std::string err;
     std::string devname;
+    // diagnostics on stderr, read from the environment ONCE when the context is created (FM_F32_DEBUG, FM_EXPAND_DEBUG,
+    // FM_PARK_PROF); they print, they change nothing that is computed
+    bool dbg_f32 = false, dbg_expand = false, dbg_park = false;
     // growable device workspaces
     void*  ws_partial = nullptr; size_t ws_partial_bytes = 0;
     void*  ws_out = nullptr;     size_t ws_out_bytes = 0;

@@ -513,12 +513,17 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
 
     // per-round log: entries written so far (thread 0 updates it at the end of a round, everyone reads it behind barriers)
     __shared__ long long sh_nlog;
-    if (tid == 0) sh_nlog = 0;
-    // the record of the round in progress (thread 0): its entry, the cell it fetched, its accepted matches
+    __shared__ int sh_anyx;       // logging runs: some pair of the round in progress passed the cross-check
+    if (tid == 0) { sh_nlog = 0; sh_anyx = 0; }
+    // the record of the round in progress (thread 0): its entry, the cell it fetched, its accepted matches.
+    // n_acc: -1 = a cell without features, -2 = no cross-checked pair at all (an empty radius subset included) -- in both
+    // cases the reference's match_position returns arrays of shape (0,), not (0, 2, 2) (fastmatch.pyx:155-156, 162-167:
+    // numpy.array([]) of an empty list), and log_round keeps that shape
     auto log_header = [&](int cell_id, int n_acc) {
         gptr<long long> rec = P.lg_round + (n_rounds - 1) * 6;
         for (int k = 0; k < 4; ++k) rec[k] = __double_as_longlong(cur[k]);
-        rec[4] = cell_id; rec[5] = n_acc;
+        rec[4] = cell_id; rec[5] = (n_acc == 0 && sh_anyx == 0) ? -2 : n_acc;
+        sh_anyx = 0;
     };
     bool skip_pop = false;        // (uniform) the first round of a resumed run takes the saved entry
     bool skip_x = false;          // (uniform) ... and, resumed behind a DELEGATED cross-check (P.resume == 2), goes straight to steps 4 / 5
@@ -1040,6 +1045,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
             if (i < nq) {
                 const unsigned long long qb = keys[i];
                 if (qb != ~0ull) {
+                    if (P.lg_round) sh_anyx = 1;          // (read by thread 0 behind the barriers of the ranking below)
                     const float d = F32 ? __uint_as_float((unsigned)(qb >> 32)) : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);
                     qrow_idx = cand[i];
                     t_local = (int)(unsigned)qb;
@@ -1145,6 +1151,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
                     if (HUGE && huge_round) qb = __hip_atomic_load(P.h_qbest + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else qb = keys[i];
                     if (qb != ~0ull) {
+                        if (P.lg_round) sh_anyx = 1;      // (read by thread 0 behind the barriers of the ranking below)
                         // high word: the float32 distance bits (float32 route; int8 route with tie_guard) or the integer d2
                         const float d = (F32 || (HUGE && fkeys)) ? __uint_as_float((unsigned)(qb >> 32))
                                                                  : x1_key_distance((unsigned)(qb >> 32), P.tie_guard);

@@ -129,6 +129,8 @@ struct TriPlan {
     int bound_every = 16;              // Tuning::bound_every (a power of two)
 };
 TriPlan plan_tri(int64_t n_pad, int target_stages, std::vector<int>* table);
+constexpr int64_t kTriMaxRows = (int64_t)1 << 26;      // banks beyond this take the masked full sweep (the workgroup count of
+                                                        // the triangular one grows with the square of the rows: int32 from ~75M on)
 hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* plans, int* const* bound, bool prio, hipStream_t stream);
 constexpr int kTriNoBoundHost = -(1 << 25);     // (a real pair's word is >= -3 * 2^21, a padding row's or the masked diagonal's ~ -2^26)
 
@@ -165,6 +167,10 @@ bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry fil
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
                          unsigned long long* partial, hipStream_t stream, bool self = false, float* aux_scratch = nullptr);
+
+// ---- K9: exact k-NN lists for k up to 8 on the vector ALUs (knn_k.hip; the reference's own calls -- k = 1, 2 -- stay on K1 / K8)
+size_t knnk_partial_bytes(int64_t nq, int64_t nt, int k);
+hipError_t launch_knnk(const Bank& q, const Bank& t, int k, unsigned long long* partial, int32_t* d_idx, float* d_dist, hipStream_t stream);
 
 // ---- K4: one workgroup per expansion round (rounds.hip) --------------------------------
 hipError_t launch_rounds(const Bank& q, const Bank& t, const int32_t* d_q_rows, const int64_t* d_q_off,

@@ -71,7 +71,9 @@ struct RRParams {
     int            order;         // workgroup -> (chunk, split) mapping, see map_block
     int            bound_mask;    // shared bounds are re-read at every stage of a sweep's first 8 and then at the stages
                                   // whose number & bound_mask == 0 (0: every stage; option "bound_every" 1 | 2 | 4 | 8)
-    int            tri_nocol;     // TRI, measurements only (FM_TRI_NOCOL=1, WRONG results): the column direction never fires
+#ifdef FM_ABLATE
+    int            tri_nocol;     // TRI, -DFM_ABLATE builds only (FM_TRI_NOCOL=1, WRONG results): the column direction never fires
+#endif
     int            tri_first;     // TRI kernels: workgroup bid of a launch is entry tri_first + bid of the bank's workgroup list
     int            tri_S;         // ... whose entries follow from (nchunks, nstages, tri_S) by arithmetic: tri_entry below
 };
@@ -228,6 +230,10 @@ __device__ __forceinline__ void issue_stage(const RRParams& p, int stage, char* 
 // builtin keeps a 64-bit address pair per piece and the LDS addresses in VGPRs (8 registers the TRI kernel lacks).
 // lo = 128 (lane >> 3) + 16 ((lane & 7) ^ (lane >> 4)): a wave's pieces g = 2 wave, 2 wave + 1 differ in the
 // swizzle term (row >> 1) & 7 by 4 (g & 1) only, i.e. in bit 6 of the byte offset.
+// (M0 is a reserved register to the compiler and is refused in a clobber list ("may lead to undefined behaviour"), so the
+// statements below change it behind the compiler's back.  That is safe while every use sets M0 in the same statement and
+// no kernel that uses them also holds a compiler-generated reader of M0 -- the builtin's global_load_lds, movrel,
+// sendmsg: tests/test_isa_hazards.py reads the generated ISA for exactly that.)
 __device__ __forceinline__ void lds_dma_16(unsigned lds_addr, const void* sbase, unsigned voff)
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -380,7 +386,10 @@ __device__ __forceinline__ void rowreduce_body(const RRParams& p, const int bid,
         const int lane = lane_now();
         const int rho = 64 * wave + lane;
         int X = (b < kTriAlways) ? kTriAlways : b - nm + (nm & 1);
-        if (stg * kStageRows + rho >= p.nred || stg < diag_end || p.tri_nocol) X = kTriNever;
+        if (stg * kStageRows + rho >= p.nred || stg < diag_end) X = kTriNever;
+#ifdef FM_ABLATE
+        if (p.tri_nocol) X = kTriNever;
+#endif
         *(int*)(sbuf + kTriXRow + 4 * rho) = X;
         // (lane exchanges addressed from `lane` above, not __shfl_xor: its lane number is hoisted out of the stage loop and spilled)
         int m8 = min(X, __builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, X));
@@ -859,11 +868,17 @@ hipError_t launch_rowreduce_tri(int n, const Bank* const* banks, const TriPlan* 
         p.nsplit = 1;  p.nchunks = plan.nchunks;  p.stages_per_split = p.nstages;  p.ncols_alloc = plan.ncols_alloc;
         p.partial = nullptr;  p.bound = bound[i];  p.order = 0;  p.bound_mask = plan.bound_every > 1 ? plan.bound_every - 1 : 0;
         p.tri_first = 0;  p.tri_S = plan.stages;
+#ifdef FM_ABLATE          // (measurement builds: no variable of the environment changes what the product library computes)
         p.tri_nocol = getenv("FM_TRI_NOCOL") ? 1 : 0;
+#endif
     }
     // (one instantiation, with the s_setprio around the MFMA burst: the one without it does not fit 128 VGPRs)
     (void)prio;
+#ifdef FM_ABLATE
     const bool merge = getenv("FM_TRI_MERGE") != nullptr;       // (measurement: both phases in ONE grid, diagonal blocks first)
+#else
+    constexpr bool merge = false;
+#endif
     for (int phase = 0; phase < 2; ++phase) {
         if (merge && phase == 1) break;
         // the banks of a launch may differ in size (r05, last): bank i under its own plan, its workgroups

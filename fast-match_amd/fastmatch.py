@@ -320,8 +320,8 @@ def _append_device_log(log, ex, slot, grid, radius, before, mark_computed):
             if mark_computed:
                 grid.get_cell(col, row)
         k = int(n_acc[i])
-        if k < 0:                    # a cell without features: match_position's empty arrays (fastmatch.pyx:155-156)
-            matches, ratios = np.array([]), np.array([])
+        if k < 0:                    # -1 a cell without features, -2 no cross-checked pair: match_position's arrays of
+            matches, ratios = np.array([]), np.array([])     # shape (0,) (fastmatch.pyx:155-156, 162-167)
         else:
             matches = np.stack([ex.q_pos[q_row[at:at + k]], tp[t_row[at:at + k]]], axis=1) if k else np.zeros((0, 2, 2))
             ratios = ratio[at:at + k].copy()
@@ -566,8 +566,8 @@ def _match_position(pos, query_cache, target, radius, context):
     float_route = q_bank.kind == _ffi.FM_BANK_F32
     t_bank = target.cell_bank(col, row, context, float_route=float_route)
     nq, nt = len(query_idx), len(target_ds)
-    if nq == 0:
-        return (np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64), 0)
+    if nq == 0:                      # knnMatch of an empty query set: matches = [], numpy.array([]) (fastmatch.pyx:162-167)
+        return empty
     offset_x, offset_y = target.offset(target_x, target_y)
 
     tidx = None
@@ -595,9 +595,10 @@ def _match_position(pos, query_cache, target, radius, context):
         finally:
             sub.close()
     m = tidx >= 0
+    if not m.any():                  # no cross-checked pair: the reference builds its arrays from an empty list -> shape (0,)
+        return (np.array([]), np.array([]), np.array([]), nq * nt)
     target_pos = keypoint_positions(target_kp) + np.array([offset_x, offset_y], dtype=np.float64)
-    positions = np.stack([query_cache.original["positions"][query_idx[m]], target_pos[tidx[m]]], axis=1) \
-        if m.any() else np.zeros((0, 2, 2))
+    positions = np.stack([query_cache.original["positions"][query_idx[m]], target_pos[tidx[m]]], axis=1)
     return positions, ratio[m], query_idx[m], nq * nt
 
 

@@ -84,15 +84,21 @@ def bf_match_arrays(dt1, dt2, k=1, options={}):
     crossCheck (k == 1 only): returns ``(tidx int32[nq], dist float32[nq])`` with
     ``tidx == -1`` where OpenCV returns an empty inner list.
     Otherwise returns ``(idx int32[nq, k], dist float32[nq, k])`` with ``-1`` / ``inf``
-    where the train set has fewer than k rows."""
-    if k not in (1, 2):
-        raise ValueError("bf_match: only k = 1 or 2 is supported on the HIP path (the reference uses no other)")
+    where the train set has fewer than k rows (1 <= k <= 8; ``matchutil.py:39-43`` passes any k to cv2)."""
+    k = int(k)
+    if k < 1:
+        raise ValueError("bf_match: k must be at least 1")
+    if k > 8:
+        # cv2.BFMatcher.knnMatch takes any k; the reference calls k = 1 and 2 (fastmatch.pyx:122-123, 161-162, cache.pyx:250)
+        raise ValueError("bf_match: k = %d: the HIP path builds k-NN lists up to k = 8 (FM_EUNSUPPORTED beyond)" % k)
     crossCheck = k == 1 and options.get("crossCheck", False) == True   # noqa: E712  (reference semantics)
     ctx = _context(options)
     qb, q_tmp, tb, t_tmp = _as_bank_pair(ctx, dt1, dt2)
     try:
         if crossCheck:
             return ctx.xcheck1(qb, tb)
+        if k > 2:
+            return ctx.knn(qb, tb, k)                   # exact lists off the matrix cores (fm_knn)
         idx, dist = ctx.knn2(qb, tb)
         return idx[:, :k], dist[:, :k]
     finally:

@@ -43,9 +43,10 @@ typedef struct fm_bank fm_bank;
  * fm_expand_fetch_many gained `slot`, fm_expand_desc gained `metric`; revision 4, r04: additions only; revision 5, r04:
  * fm_expand_desc gained the trailing `lazy`; revision 7, r05: additions -- fm_self_dist_plan, fm_bank_create_f32_cap,
  * fm_bank_append_f32, fm_expand_set_log / _log_counts / _fetch_log -- and fm_expand_run_lazy refuses to resume a run
- * that did not park).  A binding
+ * that did not park; revision 8, r06: additions -- fm_knn, the option "f32_bound_every" -- and rounds[i][5] of the
+ * per-round log may be -2).  A binding
  * compares fm_abi_version() with the FM_ABI_VERSION it was written against before its first call.            */
-#define FM_ABI_VERSION 7
+#define FM_ABI_VERSION 8
 int  fm_abi_version(void);
 
 typedef struct fm_stats {
@@ -170,6 +171,13 @@ int  fm_upload_fence(fm_ctx* ctx);
  * and n + 1 can share a root from 4 197 200 on); idx -1 / dist +inf where t has fewer than 2 rows. */
 int  fm_knn2(fm_ctx* ctx, const fm_bank* q, const fm_bank* t,
              int32_t* idx /*[nq*2]*/, float* dist /*[nq*2]*/);
+
+/* knnMatch(q, t, k) for the other k the reference's operator signature admits (matchutil.py:39-43 bf_match(dt1, dt2, k),
+ * 46-67 flann_match: `k` is any int; the reference itself calls k = 1 and 2 only).  idx[k*i+r], dist[k*i+r] as in fm_knn2;
+ * k = 1, 2: the matrix-core path of fm_knn2; 3 <= k <= 8: an exact vector-ALU kernel (off the hot path: ~20 ms for
+ * 100k x 100k uint8 rows); k > 8: FM_EUNSUPPORTED.                                                           */
+int  fm_knn(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t k,
+            int32_t* idx /*[nq*k]*/, float* dist /*[nq*k]*/);
 
 /* Classic Ratio-Match in one call: knnMatch(q, t, k=2) then ratio = m[0].distance /
  * m[1].distance (float64) and ratio < tau  -- Classic Matching.ipynb cell 3 (JSON 59-72), the
@@ -491,11 +499,13 @@ int  fm_expand_fetch_many(fm_ctx* ctx, int32_t n_ex, const fm_expand* const* ex,
  * With fm_expand_set_log(enable != 0) the runs of the pair (fm_expand_run and fm_expand_run_lazy) record, per processed round
  * in order, rounds[i][0..3] = the popped (query_pos, target_pos) as float64 bit patterns, rounds[i][4] = the cell the round
  * fetched (col * rows + row: Grid_Cache.last is the crop of the most recently COMPUTED cell, cache.pyx:102-106, which the
- * caller derives from the order in which cells first appear), rounds[i][5] = its accepted matches; and, for every accepted
+ * caller derives from the order in which cells first appear), rounds[i][5] = its accepted matches (-1: the cell has no
+ * features, -2: no pair passed the cross-check, an empty radius subset included -- in both cases match_position's arrays come
+ * from an empty list and have shape (0,), not (0, 2, 2): fastmatch.pyx:155-156, 162-167); and, for every accepted
  * match in the round's order BEFORE the result dedup (fastmatch.pyx:82-86 dedups the matches, not the log), its query row, its
  * row of the (packed / growing) target bank and its float64 ratio.  fm_expand_log_counts gives the sizes of the last run in
- * `slot`, fm_expand_fetch_log copies them (any pointer may be NULL).  The arrays grow fourfold with the run states
- * ("expand_grow"); a run that still overflows ends with FM_EXPAND_LOG_FULL.  enable > 1: on, with `enable` records and
+ * `slot`, fm_expand_fetch_log copies them (any pointer may be NULL).  The arrays grow fourfold up to 12 times (when
+ * there is no memory for larger ones the old ones stand); a run that still overflows ends with FM_EXPAND_LOG_FULL.  enable > 1: on, with `enable` records and
  * `enable` accepted matches as the arrays' FIRST capacity (the defaults: 4 x the grid's cells, 4 x the query's keypoints).  */
 int  fm_expand_set_log(fm_ctx* ctx, fm_expand* ex, int32_t enable);
 int  fm_expand_log_counts(fm_ctx* ctx, const fm_expand* ex, int32_t slot, int64_t* n_rounds, int64_t* n_entries);

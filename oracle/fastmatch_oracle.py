@@ -139,8 +139,8 @@ def o_match_position(pos, query, grid, radius=100):          # fastmatch.pyx:145
         return np.array([]), np.array([]), np.array([])
     ox, oy = grid.offset(tx, ty)
     t_pos = t_kp + np.array([ox, oy], dtype=np.float64)
-    if len(q_idx) == 0:
-        return np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64)
+    if len(q_idx) == 0:                                      # knnMatch of an empty query set: matches = [] (next case)
+        return np.array([]), np.array([]), np.array([])
     tidx, dist = oracle.bf_xcheck1(q_ds, t_ds, order=FLOAT_ORDER)
     positions, ratios, indices = [], [], []
     for qi in range(len(tidx)):                              # knnMatch order = query order
@@ -149,8 +149,8 @@ def o_match_position(pos, query, grid, radius=100):          # fastmatch.pyx:145
         ratios.append(np.float64(dist[qi]) / q_dis[qi])      # fastmatch.pyx:165
         positions.append((q_pos[qi], t_pos[tidx[qi]]))
         indices.append(q_idx[qi])
-    if not ratios:
-        return np.zeros((0, 2, 2)), np.zeros(0), np.zeros(0, dtype=np.int64)
+    if not ratios:                                           # numpy.array([...]) of an empty list: shape (0,), float64
+        return np.array([]), np.array([]), np.array([])      # (fastmatch.pyx:165-167)
     return np.array(positions), np.array(ratios), np.array(indices)
 
 

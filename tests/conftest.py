@@ -26,3 +26,16 @@ def ctx():
     """Process-wide HIP context; fails loudly (no fallback) when the device is missing."""
     import fastmatch_amd
     return fastmatch_amd.default_context(0)
+
+
+# The driver runs `pytest tests -x -q -m gpu` under a time limit: the hot-path parity files go first, so that whatever
+# happens later (a slow box, a new replay) the rows of SURVEY.md 8(a) have been tested (VERDICT r05 item 6).
+_FIRST = ["test_parity_gpu.py", "test_selfdist_gpu.py", "test_configs_fullsize_gpu.py", "test_bfmatcher_golden.py",
+          "test_fastmatch_gpu.py", "test_gather_gpu.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return _FIRST.index(name) if name in _FIRST else len(_FIRST)
+    items.sort(key=rank)            # (stable: the order inside a file, and of the other files, stays)

@@ -74,7 +74,9 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
     _same_matches(dev, host)
     assert len(dev) > 20000
 
-    cap = int(os.environ.get("FM_C3_ORACLE_ROUNDS", "12000"))
+    # (r06: the GPU suite has a time budget -- VERDICT r05 item 6 -- and the oracle replays 200 rounds per second: the
+    # default prefix is 6000 rounds; FM_C3_ORACLE_ROUNDS=0 replays all 41 704.  Device loop == host loop covers every round.)
+    cap = int(os.environ.get("FM_C3_ORACLE_ROUNDS", "6000"))
     oget = fo.o_match(oq, ot, {"max_rounds": cap} if cap else {})
     exp = oget(0.7)
     if cap and oget.rounds >= cap:
@@ -95,9 +97,11 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
     for k in (0, 7):
         _same_matches(many[k], get(taus[k]))
     assert [len(m) for m in many] == sorted(len(m) for m in many)
-    # (the oracle's second replay stops after FM_C3_ORACLE_ROUNDS_2 rounds, default 8000 -- a minute instead of
-    # five; its match list is then a prefix of the full one.  0 = the whole run.)
-    cap2 = int(os.environ.get("FM_C3_ORACLE_ROUNDS_2", "8000"))
+    # (the oracle's second replay, at another threshold, runs when FM_C3_ORACLE_ROUNDS_2 is set: that many rounds, its match
+    # list then a prefix of the full one; 0 = the whole run.  Not by default: r06, the suite's time budget.)
+    if "FM_C3_ORACLE_ROUNDS_2" not in os.environ:
+        return
+    cap2 = int(os.environ["FM_C3_ORACLE_ROUNDS_2"])
     o2 = fo.o_match(oq, ot, {"max_rounds": cap2} if cap2 else {})
     exp2 = o2(0.55)
     assert len(exp2) > 1000
@@ -109,7 +113,7 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
 
 def test_config4_batch_of_64_pairs_one_launch(ctx):
     n_pairs = 64
-    n_oracle = int(os.environ.get("FM_C4_ORACLE_PAIRS", "8"))
+    n_oracle = int(os.environ.get("FM_C4_ORACLE_PAIRS", "4"))
     raw, pairs = [], []
     for i in range(n_pairs):
         q, t = synth.image_pair((1000, 1000), 12500, seed=20250100 + i)

@@ -412,7 +412,16 @@ def test_device_loop_on_clustered_keypoints(ctx):
                    thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]})
     ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
           "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
-    _same_matches(host, fo.o_match(oq, ot, {})(0.7))
+    # (the oracle replays a prefix of the run by default -- the suite's time budget; the rounds beyond it
+    # are covered by device loop == host loop above.  FM_CLUSTERED_ORACLE_ROUNDS=0: all of them.)
+    cap = int(os.environ.get("FM_CLUSTERED_ORACLE_ROUNDS", "1200"))
+    oget = fo.o_match(oq, ot, {"max_rounds": cap} if cap else {})
+    exp = oget(0.7)
+    if cap and oget.rounds >= cap:
+        assert len(exp) > 100
+        _same_matches(host[:len(exp)], exp)
+    else:
+        _same_matches(host, exp)
 
 
 def test_device_loop_reruns_in_the_large_capacity_kernel(ctx):

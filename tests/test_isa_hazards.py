@@ -24,13 +24,68 @@ def _regs(operand_text):
     return out
 
 
+_ASM = {}
+
+
+def _isa(unit, tmp_path_factory):
+    """Device ISA of csrc/<unit>.hip (compiled once per test session)."""
+    if unit not in _ASM:
+        asm = str(tmp_path_factory.mktemp("isa") / (unit + ".s"))
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               os.path.join(ROOT, "fast-match_amd", "csrc", unit + ".hip"), "-o", asm],
+                              stderr=subprocess.DEVNULL)
+        _ASM[unit] = open(asm).read()
+    return _ASM[unit]
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-def test_untracked_bound_loads_are_not_touched_before_their_wait(tmp_path):
-    asm = str(tmp_path / "rowreduce.s")
-    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                           os.path.join(ROOT, "fast-match_amd", "csrc", "rowreduce.hip"), "-o", asm],
-                          stderr=subprocess.DEVNULL)
-    text = open(asm).read()
+@pytest.mark.parametrize("unit", ["rowreduce", "filter_f16"])
+def test_lds_dma_through_inline_asm_sets_m0_itself(unit, tmp_path_factory):
+    """The LDS-DMA helpers written as inline asm (rowreduce.hip lds_dma_16 / lds_dma_4, filter_f16.hip f_lds_dma_16) load M0
+    inside the asm statement.  M0 is a reserved register to the compiler -- it is not accepted in a clobber list (ADVICE
+    r05) -- so the compiler does not know the statement changes it.  That is safe exactly as long as (a) every such
+    instruction has its own s_mov_b32 m0 in front of it in the SAME statement and (b) no kernel that uses the asm form also
+    holds a compiler-generated user of M0 (the builtin's global_load_lds, whose M0 set-up the compiler may hoist or reuse
+    across our statements).  This reads the generated ISA and checks both, kernel by kernel."""
+    text = _isa(unit, tmp_path_factory)
+    kernels = re.split(r"\n(?=_ZN2fm\w+:)", text)
+    asm_kernels = 0
+    for k in kernels:
+        name = k.split(":", 1)[0]
+        if not name.startswith("_ZN2fm"):
+            continue
+        lines = [l.strip() for l in k.split("s_endpgm")[0].splitlines()]
+        in_asm, block = False, []
+        asm_form, compiler_form = 0, 0
+        for l in lines:
+            if "ASMSTART" in l:
+                in_asm, block = True, []
+                continue
+            if "ASMEND" in l:
+                in_asm = False
+                continue
+            if not l or l.startswith((";", ".", "//")):
+                continue
+            if in_asm:
+                block.append(l)
+            if l.startswith("global_load_lds_dword"):
+                if in_asm:
+                    asm_form += 1
+                    assert len(block) >= 3 and block[-3].startswith("s_mov_b32 m0,") and block[-2].startswith("s_nop"), (name, block)
+                else:
+                    compiler_form += 1
+            elif not in_asm and re.search(r"\bm0\b", l) and asm_form + compiler_form >= 0 and not l.startswith("s_mov_b32 m0"):
+                # any other reader of M0 the compiler emitted (s_movrel, ds_gws, sendmsg ...) next to the asm form
+                compiler_form += 1 if "global_load_lds" not in l else 0
+        if asm_form:
+            asm_kernels += 1
+            assert compiler_form == 0, "%s mixes the inline-asm LDS-DMA with %d compiler-generated users of M0" % (name, compiler_form)
+    assert asm_kernels >= 3
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_untracked_bound_loads_are_not_touched_before_their_wait(tmp_path_factory):
+    text = _isa("rowreduce", tmp_path_factory)
     kernels = re.split(r"\n(?=_ZN2fm\w+:)", text)
     checked = 0
     for k in kernels:

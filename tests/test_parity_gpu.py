@@ -922,3 +922,39 @@ def test_results_do_not_depend_on_the_options():
         got = run()
         assert all(_eq(a, b) for a, b in zip(got, ref)), s
     c.close()
+
+
+# ---- knnMatch for k > 2 (fm_knn) ---------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8])
+def test_bf_match_for_any_k_up_to_8(ctx, k):
+    """matchutil.bf_match(dt1, dt2, k) (matchutil.py:39-43: `k` is any int) == oracle.bf_knn on SIFT-like banks, on banks of
+    duplicates and ties (lower train index first), in the float32-root tie range, on non-integer float32 banks, and on
+    train sets with fewer than k rows (OpenCV returns shorter inner lists: -1 / inf here)."""
+    rng = np.random.default_rng(900 + k)
+    Q, T, _ = synth.planted_pair(700, 5300, seed=31 + k)
+    T[100:140] = T[60]                                       # 41 identical train rows: ties in ascending index
+    Q[5] = T[60]
+    cases = [(Q, T), (Q[:3], T[:max(1, k - 1)]), (Q[:65], T[:k])]
+    far_q, far_t = far_banks(120, 900, rng)                  # d2 up to the float32-root tie range
+    cases.append((far_q, far_t))
+    Qf = (Q[:300] + rng.uniform(-0.5, 0.5, (300, 128))).astype(np.float32)
+    Tf = (T[:2100] + rng.uniform(-0.5, 0.5, (2100, 128))).astype(np.float32)
+    Tf[700:704] = Tf[3]
+    cases.append((Qf, Tf))
+    for q, t in cases:
+        order = 1 if q.dtype == np.float32 else 0
+        oi, od = oracle.bf_knn(q, t, k, order=order)
+        idx, dist = matchutil.bf_match_arrays(q, t, k=k, options={"context": ctx})
+        assert _eq(idx, oi) and _eq(dist, od), (k, q.shape, t.shape, q.dtype)
+    lists = matchutil.bf_match(Q[:4], T[:k - 1] if k > 1 else T[:1], k=k, options={"context": ctx})
+    assert [len(m) for m in lists] == [max(1, k - 1) if k > 1 else 1] * 4      # shorter inner lists, as cv2 returns them
+    if k == 3:
+        with pytest.raises(ValueError):
+            matchutil.bf_match_arrays(Q, T, k=9, options={"context": ctx})
+        with pytest.raises(_ffi.FastMatchHipError) as e:
+            ctx.knn(ctx.bank(Q), ctx.bank(T), 9)
+        assert e.value.code == -4                            # FM_EUNSUPPORTED
+        big_q, big_t, _ = synth.planted_pair(9000, 70000, seed=77)      # several splits of the train range
+        oi, od = oracle.bf_knn(big_q, big_t, 4)
+        idx, dist = ctx.knn(ctx.bank(big_q), ctx.bank(big_t), 4)
+        assert _eq(idx, oi) and _eq(dist, od)

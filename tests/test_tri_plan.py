@@ -102,3 +102,19 @@ def test_plan_under_address_and_undefined_behaviour_sanitizers(tmp_path):
                           stderr=subprocess.DEVNULL)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
+
+
+def test_count_only_call_equals_the_table_and_large_sizes_are_refused():
+    """The count-only form (cap 0) is arithmetic in 64 bits and agrees with the walked table; a bank whose workgroup count
+    would leave int32 is refused with FM_EINVAL instead of a negative count."""
+    import ctypes
+    lib = _ffi.load_library()
+    for n_pad in (128, 512, 640, 33792, 100096, 1000064):
+        for stages in (0, 4, 17, 72):
+            nwg, nd, su = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            assert lib.fm_self_dist_plan(n_pad, stages, None, 0, ctypes.byref(nwg), ctypes.byref(nd), ctypes.byref(su)) == 0
+            table, n_diag, used = _ffi.self_dist_plan(n_pad, stages)
+            assert (nwg.value, nd.value, su.value) == (table.shape[0], n_diag, used)
+    nwg = ctypes.c_int32()
+    assert lib.fm_self_dist_plan((1 << 26) + 128, 0, None, 0, ctypes.byref(nwg), None, None) != 0
+    assert lib.fm_self_dist_plan(1 << 26, 0, None, 0, ctypes.byref(nwg), None, None) == 0 and nwg.value > 0
