@@ -299,6 +299,65 @@ def leg_expand_c3_taus(ctx, get, single_wall):
                     "(the largest threshold); the other 14 run beside it"}
 
 
+def leg_train_sharded(ctx, rank, world, dev, backend, reps=5):
+    """N > 1 only, not part of the headline: BASELINE config 2 as ONE problem (second half; the reference
+    call is fastmatch.pyx:161-162 on one image pair too large or too urgent for one GPU).  The query bank is replicated,
+    the train rows are split by row range; every rank runs the reverse-NN + election of its shard
+    (fm_xcheck1_keys_dev) and ONE all-reduce(min) of NQ packed 64-bit keys (RCCL) leaves the cross-checked 1-NN of the
+    whole problem on every rank.  Reported: wall per problem (max over ranks), the time of the shard kernels alone, the
+    collective's bytes, and whether the result is the single-GPU fm_xcheck1's bit for bit (checked on rank 0)."""
+    import torch
+    import torch.distributed as dist
+    from fastmatch_amd import synth, sharding
+    Q, T, _ = synth.planted_pair(NQ, NT, seed=SEED)                     # the same problem on every rank
+    lo, hi = sharding.shard_rows(NT, rank, world)
+    qb, tb = ctx.bank(Q), ctx.bank(T[lo:hi])
+    on_gpu = backend == "nccl"
+    keys_t = torch.empty(NQ, dtype=torch.int64, device=dev) if on_gpu else None
+
+    def barrier():
+        dist.barrier()
+
+    def shard_only():                                                   # the kernels of this rank's shard, keys in HBM
+        if on_gpu:
+            ctx.xcheck1_keys_dev(qb, tb, lo, keys_t.data_ptr())
+            ctx.sync()
+        else:
+            ctx.xcheck1_keys(qb, tb, lo)
+
+    tidx, d = sharding.xcheck1_sharded(ctx, qb, tb, lo, device=dev)     # warm-up (communicator, workspaces)
+    shard_only()
+    t_all, t_shard = [], []
+    for _ in range(reps):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tidx, d = sharding.xcheck1_sharded(ctx, qb, tb, lo, device=dev)
+        torch.cuda.synchronize(); barrier()
+        t_all.append(time.perf_counter() - t0)
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        shard_only()
+        torch.cuda.synchronize(); barrier()
+        t_shard.append(time.perf_counter() - t0)
+    tt = torch.tensor([min(t_all), min(t_shard)], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    same = None
+    if rank == 0:
+        fb = ctx.bank(T)
+        ft, fd = ctx.xcheck1(qb, fb)                                    # the unsharded call
+        same = bool(np.array_equal(ft, tidx) and np.array_equal(fd.view(np.uint32), d.view(np.uint32)))
+        fb.close()
+    qb.close(); tb.close()
+    wall, shard = float(tt[0].item()), float(tt[1].item())
+    return {"mode": "one %d x %d problem, train rows sharded over %d ranks" % (NQ, NT, world),
+            "wall_ms": 1e3 * wall, "shard_kernels_ms": 1e3 * shard, "exchange_exposed_ms": 1e3 * (wall - shard),
+            "pairs_per_s": float(NQ) * NT / wall, "identical_to_single_gpu": same,
+            "collective": {"op": "all_reduce(min)", "backend": ("rccl (torch.distributed nccl)" if on_gpu else backend),
+                           "elements": NQ, "bytes_per_rank": NQ * 8, "collectives_per_problem": 1},
+            "note": "un-timed leg; wall = barrier-bracketed best of %d, max over ranks, results on the host of every rank; "
+                    "exposed = wall - the shard's kernels alone (the collective, the key decode and the copy to the host)" % reps}
+
+
 def leg_expand_c4(ctx, rank, world, dev, backend, n_pairs=int(os.environ.get("FM_BENCH_C4_PAIRS", "64")), reps=3):
     """BASELINE.json configs[3]: 64 independent 1-MP pairs (1000 x 1000, 12.5k keypoints per
     side) sharded over the ranks (pair i -> rank i mod N), one launch per rank, one
@@ -859,6 +918,8 @@ def main():
     c4 = None
     if legs and os.environ.get("FM_BENCH_C4", "1") != "0":
         c4 = leg_expand_c4(ctx, rank, world, dev, backend)
+    # N > 1: the OTHER multi-GPU mode of SURVEY.md 8(e), un-timed, so that a multi-GPU record covers both halves
+    tsh = leg_train_sharded(ctx, rank, world, dev, backend) if world > 1 and os.environ.get("FM_BENCH_TRAIN_SHARDED", "1") != "0" else None
 
     if rank == 0:
         pairs_per_step = float(NQ) * NT * PAIRS_PER_STEP
@@ -933,6 +994,7 @@ def main():
                                  "per launch / that time; mfma_pipe_busy_frac = rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GPU "
                                  "cycles of the launch (profiles/)"},
             "collective": collective,
+            "train_sharded": tsh,
             "self_2nn": self2,
             "classic_ratio_match": crm,
             "single_pair": single,

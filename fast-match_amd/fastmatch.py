@@ -93,7 +93,8 @@ def match(query_cache, target_img, options={}):
         if not use_lazy_loop or state["lazy"] is False:
             return None
         if state["lazy"] is None:
-            state["lazy"] = make_lazy_expander(query_cache, target_cache, radius, context, options.get("lazy_capacity"))
+            state["lazy"] = make_lazy_expander(query_cache, target_cache, radius, context, options.get("lazy_capacity"),
+                                               float_route=state.get("lazy_float", False))
             if state["lazy"] is False:
                 return None
             if log is not None:
@@ -117,9 +118,26 @@ def match(query_cache, target_img, options={}):
                             ds = ds.astype(np.float32, copy=False)              # the float32 route takes any finite values
                         elif ds.dtype != np.uint8:
                             u8 = ds.astype(np.uint8)
-                            if not np.array_equal(u8.astype(ds.dtype), ds):     # not integer valued, the query bank is: no int8 route
-                                state["lazy"] = False
-                                return None
+                            if not np.array_equal(u8.astype(ds.dtype), ds):
+                                # not integer valued, the query bank is: the pair moves to the float32 route (r06: it used
+                                # to leave the device loop here).  A fresh lazy pair on the query bank's float32 twin, the
+                                # run from its start; the cells computed so far are in the Grid_Cache, so the function is
+                                # not called again for them -- and the log is rebuilt from the run that finishes.
+                                if state.get("lazy_float", False):
+                                    state["lazy"] = False
+                                    return None
+                                state["lazy_float"] = True
+                                old_ex = state["lazy"][0]
+                                state["lazy"] = make_lazy_expander(query_cache, target_cache, radius, context,
+                                                                   options.get("lazy_capacity"), float_route=True)
+                                old_ex.close()
+                                if state["lazy"] is False:
+                                    return None
+                                if log is not None:
+                                    state["lazy"][0].set_log(True, first_capacity=options.get("log_first_capacity", 0))
+                                ex, t_bank = state["lazy"]
+                                resume = False
+                                continue
                             ds = u8
                         off = np.array([row * target_cache.cell_width - target_cache.margin,
                                         col * target_cache.cell_height - target_cache.margin], dtype=np.float64)
@@ -272,12 +290,17 @@ def _expand_launch(context, expanders, seeds, taus):
     return results, fetched
 
 
-def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None):
+def make_lazy_expander(query_cache, target_grid, radius, context, capacity=None, float_route=False):
     """(expander, growing target bank) for a target whose cells are computed on demand, or False (oversize geometry;
     r05: a float32 query bank gets a growing float32-route target bank).  ``capacity``: rows the target bank has room for; default 6 x the query's keypoints (a cell's
-    crop includes its margins: a keypoint lands in up to four cells) + 32 per cell (cells start at multiples of 32 rows)."""
+    crop includes its margins: a keypoint lands in up to four cells) + 32 per cell (cells start at multiples of 32 rows).
+    ``float_route`` (r06): an integer-valued query bank is paired through its float32-route twin -- the feature function
+    of the target returned descriptors that are not integer valued (make_expander does the same for pre-extracted targets)."""
     from . import _ffi
     q_bank = query_cache.bank(context)
+    if float_route and q_bank.kind == _ffi.FM_BANK_I8:
+        q_bank = context.bank(query_cache.original["descriptors"], float_route=True)
+        q_bank.set_selfdist(query_cache.original["distances"])
     ncells = target_grid.rows * target_grid.cols
     if capacity is None:
         capacity = 6 * max(q_bank.n, 4096) + 32 * ncells + 4096

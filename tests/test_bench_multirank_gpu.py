@@ -48,6 +48,14 @@ def test_two_rank_bench_equals_the_sum_of_its_ranks(gather):
     assert c["step_ms_with_gather"] > 0 and c["step_ms_without_gather"] > 0
     assert abs(c["gather_exposed_ms"] - (c["step_ms_with_gather"] - c["step_ms_without_gather"])) < 1e-9
     assert all(s["collective"] is None for s in solo)
+    # the other multi-GPU mode (second half): ONE problem, train rows sharded, one
+    # all-reduce(min) of the election keys -- in the line whenever N > 1, checked against the single-GPU call on rank 0
+    t = two["train_sharded"]
+    assert t["identical_to_single_gpu"] is True and t["collective"]["op"] == "all_reduce(min)"
+    assert t["collective"]["elements"] == 33000 and t["collective"]["bytes_per_rank"] == 33000 * 8 and t["collective"]["backend"] == "gloo"
+    assert t["wall_ms"] > 0 and t["shard_kernels_ms"] > 0 and abs(t["exchange_exposed_ms"] - (t["wall_ms"] - t["shard_kernels_ms"])) < 1e-9
+    assert t["pairs_per_s"] == pytest.approx(33000.0 * 33000.0 / (t["wall_ms"] * 1e-3))
+    assert all(s["train_sharded"] is None for s in solo)
     # the batch's last pair comes from another distribution: its accepted count differs from pair 0's
     assert solo[0]["accepted_matches_independent_pair"] not in (None, solo[0]["accepted_matches_pair0"])
     # configs[3] leg: the same four pairs, sharded over the ranks or not -- same rounds, pairs and matches

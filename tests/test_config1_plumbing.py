@@ -446,3 +446,63 @@ def test_pixel_target_with_float32_descriptors_stays_on_the_device(ctx, monkeypa
                 assert ia == ib and da["ratio"] == db["ratio"] and np.array_equal(da["positions"], db["positions"])
     finally:
         ctx.set_option("expand_delegate", keep)
+
+
+@pytest.mark.gpu
+def test_pixel_target_whose_cells_turn_out_non_integer_stays_on_the_device(ctx, monkeypatch):
+    """The last host-loop fallback of the lazy device loop (fastmatch.pyx:154 -> cache.pyx:102-106,
+    124-138): an integer-valued query bank (plain SIFT) against a pixel target whose feature function returns descriptors
+    that are NOT integer valued for some crops.  Until r06 the first such cell sent the run to the host-driven loop; now the
+    pair moves to the float32 route on the device (the query bank's float32 twin, a fresh growing float32 target bank, the
+    run from its start, cells already computed come from the Grid_Cache) -- device loop == host loop == oracle, log
+    included, the feature function called as often as the host loop calls it."""
+    from fastmatch_amd import cache, fastmatch, _ffi
+    from oracle import fastmatch_oracle as fo
+    monkeypatch.setattr(fo, "FLOAT_ORDER", 1)
+    img1 = texture(800, 640, seed=1)
+    mild = np.array([[1.0, 0.01, 18.0], [-0.008, 1.0, -11.0], [1e-5, -5e-6, 1.0]])
+    img4 = warp(img1, mild)
+    kq, dq = standin.standin_features(img4)
+    thumb_q = imaging.get_thumbnail(img4, (600, 600))
+    ktq, dtq = standin.standin_features(thumb_q)
+    pos = lambda kp: np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+    mc = cache.Metric_Cache.from_arrays(dq, pos(kq), (800, 640), dtq, pos(ktq), (thumb_q.shape[1], thumb_q.shape[0]),
+                                        options={"context": ctx})
+    assert mc.bank(ctx).kind == _ffi.FM_BANK_I8
+    calls = {"dev": 0, "host": 0, "oracle": 0}
+
+    def feat(which):
+        def f(data):
+            calls[which] += 1
+            kp, ds = standin.standin_features(data)
+            if ds is None or len(ds) == 0 or data.shape[0] * data.shape[1] > 300 * 300:
+                return kp, ds                                  # whole images and thumbnails: integer valued, as SIFT's are
+            if int(data[::5, ::5, 0].sum()) % 3 == 0:               # (one channel: the texture has B = G = R)
+                return kp, ds                                  # the cells' crops: integer valued ...
+            return kp, np.asarray(ds, dtype=np.float32) + np.float32(0.25)     # ... except where this fires
+        return f
+    probe = [feat("oracle")(img1[y:y + 110, x:x + 110])[1] for y in range(0, 500, 100) for x in range(0, 600, 100)]
+    kinds = set(bool(np.array_equal(np.asarray(p), np.round(np.asarray(p)))) for p in probe if p is not None and len(p))
+    assert kinds == {True, False}, "the stand-in must return both kinds of cells for this test to mean anything"
+    calls["oracle"] = 0
+    dlog, hlog, ds, hs = [], [], {}, {}
+    dev = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat("dev"), "stats": ds, "log": dlog})
+    host = fastmatch.match(mc, img1, {"context": ctx, "feature_function": feat("host"), "stats": hs, "log": hlog, "device_loop": False})
+    oq = fo.OQuery(dq, pos(kq), (800, 640), thumb={"descriptors": dtq, "positions": pos(ktq), "size": (thumb_q.shape[1], thumb_q.shape[0])})
+    thumb_t = imaging.get_thumbnail(img1, (400, 400))
+    ktt, dtt = standin.standin_features(thumb_t)
+    ot = {"size": (800, 640), "image": img1, "feature_function": feat("oracle"),
+          "thumb": {"descriptors": dtt, "positions": pos(ktt), "size": (thumb_t.shape[1], thumb_t.shape[0])}}
+    oget = fo.o_match(oq, ot, {})
+    for tau in (0.8, 0.95):
+        got, ref, exp = dev(tau), host(tau), oget(tau)
+        assert len(got) == len(ref) == len(exp) > 20
+        for (ia, da), (ib, db), (ic, dc) in zip(got, ref, exp):
+            assert ia == ib == ic and da["ratio"] == db["ratio"] == dc["ratio"]
+            assert np.array_equal(da["positions"], db["positions"]) and np.array_equal(da["positions"], dc["positions"])
+    assert ds.get("device_loops") == 2 and "device_fallbacks" not in ds and ds["rounds"] == hs["rounds"]
+    assert calls["dev"] == calls["host"] > 10
+    assert len(dlog) == len(hlog) == ds["rounds"]
+    for a, b in zip(dlog, hlog):
+        assert a["target_grid"] == b["target_grid"] and np.array_equal(a["matches"], b["matches"]) and np.array_equal(a["ratios"], b["ratios"])
+        assert np.asarray(a["matches"]).shape == np.asarray(b["matches"]).shape

@@ -1,6 +1,8 @@
 """GPU: the product fastmatch.match()/Metric_Cache/Grid_Cache surface (HIP rounds, host
 expansion loop) against the oracle's restatement of fastmatch.pyx on synthetic image pairs:
 identical match lists (indices, positions, ratios), round counts and logs."""
+import os
+
 import numpy as np
 import pytest
 

@@ -414,7 +414,7 @@ def test_matchutil_surface(ctx):
     mf = matchutil.flann_match(Q, Q, k=2, options=opts)          # exact substitute for FLANN
     assert [r[1].distance for r in mf] == oracle.self_dist(Q).tolist()
     with pytest.raises(ValueError):
-        matchutil.bf_match(Q, T, k=3, options=opts)
+        matchutil.bf_match(Q, T, k=9, options=opts)            # (r06: k up to 8 is served, test_bf_match_for_any_k_up_to_8)
     with pytest.raises(_ffi.FastMatchHipError):                   # width mismatch (cv2.error there)
         matchutil.bf_match(Q, T[:, :64], k=2, options=opts)
 

@@ -153,8 +153,17 @@ def fuzz_match(rng):
             for k in ("descriptors", "thumb_descriptors"):
                 d = side[k].astype(np.float32)
                 side[k] = np.sqrt(d / np.maximum(d.sum(axis=1, keepdims=True), 1.0)).astype(np.float32)
-    fo.FLOAT_ORDER = 1 if rootsift else 0                     # (the oracle in the device's accumulation order for those)
     far = (not rootsift) and rng.integers(0, 8) == 0          # r05: every d2 in the float32-root tie range (kat.far_image_pair)
+    # r06: an integer-valued query bank against a target whose descriptors are NOT all integer valued (a share of its rows
+    # shifted by a fraction): the pair runs on the float32 route through the query bank's float32 twin
+    mixed = (not rootsift) and (not far) and rng.integers(0, 8) == 0
+    if mixed:
+        for k in ("descriptors", "thumb_descriptors"):
+            d = t[k].astype(np.float32)
+            rows = rng.random(len(d)) < rng.uniform(0.05, 0.9)
+            d[rows] += np.float32(rng.choice([0.25, 0.5, 0.125]))
+            t[k] = d
+    fo.FLOAT_ORDER = 1 if (rootsift or mixed) else 0          # (the oracle in the device's accumulation order for those)
     if far:
         q, t = far_image_pair(q, t, seed=seed)
     mc = cache.Metric_Cache.from_arrays(q["descriptors"], q["positions"], q["size"], q["thumb_descriptors"],
@@ -178,7 +187,7 @@ def fuzz_match(rng):
         taus = sorted(float(x) for x in rng.choice([900.0, 1045.0, 1100.0, 1150.0, 1300.0], int(rng.integers(1, 3)), replace=False))
         if n > 1200:
             taus = [x for x in taus if x < 1140.0] or [1100.0]         # (above that nearly every row is accepted: minutes of oracle)
-    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else ("far" if far else "u8"))
+    tag = ("match", (w, h), n, seed, sorted(opts.items()), taus, sorted(kw.items()), "rootsift" if rootsift else ("far" if far else ("mixed" if mixed else "u8")))
     if rng.integers(0, 2) and len(taus) > 1:
         got_all = get(taus)
     else:
