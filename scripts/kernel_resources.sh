@@ -8,7 +8,7 @@ X=""; [ "$U" = dist_f32 ] && X=-fno-slp-vectorize
 import sys, re
 rows = []; cur = None
 for line in sys.stdin:
-    m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPR Spill|SGPR Spill|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|SGPRs): (.*?) \[-Rpass", line)
+    m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]|TotalSGPRs): (.*?) \[-Rpass", line)
     if not m: continue
     k, v = m.group(1), m.group(2)
     if k == "Function Name":
@@ -19,5 +19,5 @@ print("%-72s %5s %5s %5s %7s %7s %5s %7s" % ("kernel", "VGPR", "AGPR", "SGPR", "
 for r in rows:
     name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"\(.*$", "", name).replace("void ", "")
-    print("%-72s %5s %5s %5s %7s %7s %5s %7s" % (name[:72], r.get("VGPRs"), r.get("AGPRs"), r.get("SGPRs"), r.get("VGPR Spill"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
+    print("%-72s %5s %5s %5s %7s %7s %5s %7s" % (name[:72], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
 '
