@@ -8,7 +8,7 @@ UNIT=$1; FLAG=$2; shift 2
 cd fast-match_amd/csrc
 cp ../libfastmatch_hip.so /tmp/lib_product.so
 OBJS=""
-for u in rowreduce rounds dist_f32 filter_f16 expand comm api_ctx api_match api_expand api_grid; do
+for u in rowreduce rounds dist_f32 filter_f16 knn_k expand comm api_ctx api_match api_expand api_grid; do
   if [ $u = $UNIT ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $( [ $u = dist_f32 ] && echo -fno-slp-vectorize ) -D$FLAG -c $u.hip -o /tmp/ab_$u.o
     OBJS="$OBJS /tmp/ab_$u.o"

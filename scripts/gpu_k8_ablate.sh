@@ -6,7 +6,7 @@ run() { python scripts/gpu_c5.py 2>&1 | grep -E "^(knn2|xcheck1)" | cut -c1-150;
 build() {
   ( cd fast-match_amd/csrc
     OBJS=""
-    for u in rowreduce rounds dist_f32 filter_f16 expand comm api_ctx api_match api_expand api_grid; do
+    for u in rowreduce rounds dist_f32 filter_f16 knn_k expand comm api_ctx api_match api_expand api_grid; do
       if [ $u = filter_f16 ]; then
         /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $1 -c $u.hip -o /tmp/ab_$u.o
         OBJS="$OBJS /tmp/ab_$u.o"
