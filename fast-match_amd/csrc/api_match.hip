@@ -808,7 +808,32 @@ static int selfdist_device(fm_ctx* ctx, int n, const fm_bank* const* banks, doub
                 ++i;
                 continue;
             }
-            if ((rc = rowreduce_f32_route(ctx, b, b, 1, &pl, true)) != FM_OK) return rc;
+            // r06: every distance once -- the triangular sweep around the fp16 filter (filter_f16.hip, TRI) from 65536 padded
+            // rows on ("self_tri" 1; 2 = always, 0 = never), else the masked full sweep through the filter / K5.  (Measured,
+            // profiles/r06e_f32_selfdist_tri.log: x 1.00 of the masked sweep's time at 50k rows, 0.94 at 65k, 0.83 at 100k,
+            // 0.76 at 200k -- below ~60k rows the sweep has fewer pieces than the chip holds workgroups, every row's visits
+            // happen at once against a stale bound, and the lists overflow into rescans.)
+            const bool tri = ctx->tune.f32_filter != 0 && ctx->tune.self_tri != 0 && b->n_pad <= kTriMaxRows &&
+                             (ctx->tune.self_tri == 2 || b->n_pad >= 65536) && filter_usable(*b, *b);
+            if (tri) {
+                pl = plan_rowreduce_f32(b->n_pad, b->n_pad, ctx->tune.nsplit);
+                TriPlan tp;
+                if ((rc = tri_plan_for(ctx, b->n_pad, &tp)) != FM_OK) return rc;
+                const size_t part = (pl.partial_bytes(1) + 255) & ~(size_t)255;
+                const size_t bnd = ((size_t)tp.ncols_alloc * 4 + 255) & ~(size_t)255;
+                if ((rc = ws_ensure(ctx, &ctx->ws_partial, &ctx->ws_partial_bytes, part + bnd + filter_tri_bytes(tp.ncols_alloc) + 64)) != FM_OK) return rc;
+                unsigned long long* d_part = (unsigned long long*)ctx->ws_partial;
+                int* d_bound = (int*)((char*)ctx->ws_partial + part);
+                void* d_tri = (char*)d_bound + bnd;
+                HIP_TRY(ctx, hipMemsetAsync(d_part, 0xff, pl.partial_bytes(1), ctx->stream));
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_bound, filter_empty_bound(), (size_t)tp.ncols_alloc, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8, ctx->stream));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+                HIP_TRY(ctx, launch_filter_tri(*b, tp, ctx->tune.f32_bound_every, d_tri, d_bound, ctx->d_counters, d_part, ctx->stream));
+                HIP_TRY(ctx, launch_rowreduce_f32(*b, *b, 1, pl, d_part, ctx->d_counters, ctx->stream, true));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+                ctx->filter_launches += 1;
+            } else if ((rc = rowreduce_f32_route(ctx, b, b, 1, &pl, true)) != FM_OK) return rc;
             ctx->kernel_timed = true;
             ctx->pending_pairs += b->n * b->n;
             ctx->pending_bytes += bank_bytes(b);

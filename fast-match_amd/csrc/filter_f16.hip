@@ -78,8 +78,13 @@ struct FParams {
     const float* col_rowsf;
     const float* red_rowsf;
     unsigned long long* partial;   // [n][KTOP] packed keys (split 0 of the caller's layout)
-    int          bound_mask;    // filter2_kernel: the shared bounds are re-read at every stage of a sweep's first 8, then at
+    int          bound_mask;    // the shared bounds are re-read at every stage of a sweep's first 8, then at
                                 // the stages whose number & bound_mask == 0
+    // TRI (float32 triangular self sweep, below): workgroup list entry = tri_first + blockIdx.x, piece length tri_S;
+    // per-row candidate lists cand[row][kFTriCap] with their counters cnt[row] (bit 30: the list may be incomplete)
+    int          tri_first, tri_S;
+    unsigned long long* cand;
+    int*         cnt;
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -131,24 +136,54 @@ __device__ __forceinline__ void f_issue_stage(const FParams& p, int stage, char*
 
 // SELF (K = 1): both banks are the same bank and the pair (n, n) is masked -- the top-1 over the OTHER rows,
 // which is what Metric_Cache keeps of the self 2-NN (cache.pyx:250-252, 271-273; rowreduce.hip has the int8 form).
-template <int NC, int KTOP, int NW, bool SELF = false>
+// TRI (r06): the float32 form of rowreduce.hip's triangular self sweep.  d(i, j) = d(j, i) bit for bit
+// in K5's chain (v = a - b or b - a, then v * v), so the distances of a bank against itself need computing once: an
+// output chunk sweeps only the stages from its own rows on (launch A: the diagonal blocks, masked, row direction only;
+// launch B: the pieces beyond, piece-number major -- plan_tri / tri_entry as for the integer banks) and every tile of
+// launch B serves BOTH of its rows:
+//   row direction     as ever -- the lane's output row n keeps its P best streamed rows m in registers;
+//   column direction  the streamed row m gains the candidate n.  In row m's own frame the pair is worth
+//                     a' = m.c - |c|^2/2 = acc + |m|^2/2 - |c|^2/2   (acc = c.m - |m|^2/2 is what the lane holds),
+//                     and it matters iff a' >= bound[m] - M_m, i.e.  acc - |c|^2/2 >= bound[m] - M_m - |m|^2/2 =: X[m].
+//                     X[m] (from a bound read two stages ahead: a stale bound is merely weaker), |m|^2/2 and the minimum
+//                     of X over the four rows a lane holds of a tile are staged in LDS beside the rows; the fast path is
+//                     one subtract and one compare per block and tile on the tile maximum the row direction forms anyway.
+//                     A pair that passes publishes a' to bound[m] (atomic maximum: both directions feed the same word)
+//                     and appends (a', n) to row m's list in memory.  The filter is approximate, so -- unlike the
+//                     integer sweep, where bound[] IS the result -- the candidates' identities are needed: the lists.
+// At the end of a piece the lane's own entries that are inside the margin of their row's CURRENT bound go to the same
+// lists; tri_rescore_kernel then evaluates a row's list exactly against its FINAL bound.  A list that overflows, or a lane
+// whose fourth entry is inside the margin, sends the row to rescan_kernel (bit 30 of its counter), as the P-lists always did.
+constexpr int kFTriCap   = 32;                      // entries of a row's candidate list
+constexpr int kFTriRedo  = 1 << 30;                 // in cnt[row]: the list may be incomplete
+constexpr int kFTriXBytes = 128 * 4 + 128 * 4 + 32 * 4;          // per staged stage: X[128], |m|^2/2 [128], X4[32]
+
+template <int NC, int KTOP, int NW, bool SELF = false, bool TRI = false>
 __global__ __launch_bounds__(64 * NW, 2)
 void filter_kernel(FParams p)
 {
     static_assert(!SELF || KTOP == 1, "the masked-diagonal sweep is a top-1");
-    __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes];
+    static_assert(!TRI || (SELF && NW == 8 && NC == 4), "the triangular sweep is built for one shape: 512-row chunks");
+    __shared__ __attribute__((aligned(16))) char smem[2 * kFStageBytes + (TRI ? 3 * kFTriXBytes : 0)];
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g    = lane >> 4;
     const int c16  = lane & 15;
-    const int chunk = blockIdx.x % p.nchunks;        // split major, as in rowreduce.hip
-    const int split = blockIdx.x / p.nchunks;
+    int chunk, split, st0, st1;
+    if constexpr (TRI) {
+        tri_entry(__builtin_amdgcn_readfirstlane(p.tri_first + (int)blockIdx.x), p.nchunks, p.nstages, p.tri_S, chunk, st0, st1);
+        split = 0;
+    } else {
+        chunk = blockIdx.x % p.nchunks;              // split major, as in rowreduce.hip
+        split = blockIdx.x / p.nchunks;
+        st0 = split * p.stages_per_split;
+        st1 = min(st0 + p.stages_per_split, p.nstages);
+    }
     const int cb    = chunk * (16 * NC * NW) + wave * (16 * NC);
-
-    const int st0 = split * p.stages_per_split;
-    const int st1 = min(st0 + p.stages_per_split, p.nstages);
+    // TRI: the chunk's own stages end here (the diagonal block: both directions come out of the row direction there)
+    const int diag_end = TRI ? (chunk + 1) * (16 * NC * NW / kFStageRows) : 0;
     // the first stage is in flight while the stationary operand is loaded
     if (st0 < st1) f_issue_stage<NW>(p, st0, smem, 0, wave, lane);
 
@@ -166,6 +201,49 @@ void filter_kernel(FParams p)
             if (ok) h = *(const v4i*)(p.col_rows + (size_t)n * kFRowBytes + (4 * s + g) * 16);
             bh[j][s] = __builtin_bit_cast(v8h, h);
         }
+    }
+
+    // TRI: |c|^2 / 2 of the lane's output rows, and the words of the streamed rows two stages ahead (threads 0 .. 127:
+    // one row each): bound, |m|^2, accumulator init
+    float hc[NC];
+    int   xb_next = 0;
+    float xn_next = 0.f, xa_next = 0.f;
+    char* const xbase = smem + 2 * kFStageBytes;          // three slots of kFTriXBytes: stage s uses slot s % 3
+    auto x_request = [&](int stg) __attribute__((always_inline)) {
+        if (tid < kFStageRows && stg < st1) {
+            const int m = stg * kFStageRows + tid;                        // (< nred_pad: the arrays cover it)
+            xb_next = __hip_atomic_load(p.bound + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xn_next = p.col_norm[m];
+            xa_next = p.red_aux[m];
+        }
+    };
+    auto x_store = [&](int stg) __attribute__((always_inline)) {         // from the words requested for stage stg
+        if (tid < kFStageRows && stg < st1) {
+            const int m = stg * kFStageRows + tid;
+            float X = funmap(xb_next) - fmaf(p.eps_c, xn_next, p.eps_nm) + xa_next;          // bound - M_m - |m|^2/2
+            if (m >= p.nred || stg < diag_end) X = INFINITY;                                   // takes nothing
+#ifdef FM_ABLATE_TRI_NOCOL          // ablation build only (results are wrong): the sweep when the column direction never fires
+            X = INFINITY;
+#endif
+            char* slot = xbase + (stg % 3) * kFTriXBytes;
+            ((float*)slot)[tid] = X;
+            ((float*)(slot + 512))[tid] = -xa_next;
+            float m4 = fminf(X, __shfl_xor(X, 1));
+            m4 = fminf(m4, __shfl_xor(m4, 2));
+            if ((tid & 3) == 0) ((float*)(slot + 1024))[tid >> 2] = m4;
+        }
+    };
+    if constexpr (TRI) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int n = cb + 16 * j + c16;
+            hc[j] = (n < p.ncols_pad) ? 0.5f * p.col_norm[n] : 0.f;
+        }
+
+        // stages st0 and st0 + 1 at once (their loads are waited for here: once per piece), st0 + 2 requested
+        x_request(st0);     x_store(st0);
+        x_request(st0 + 1); x_store(st0 + 1);
+        x_request(st0 + 2);
     }
 
     float ea[NC][kFP];
@@ -263,6 +341,7 @@ void filter_kernel(FParams p)
 
     v4f acc[2][NC];
     unsigned long long hit[NC];         // the lanes whose fast test fired for block j (of the tile reduced last)
+    unsigned long long chit[NC];        // TRI: ... whose column-direction first-level test fired
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[1][j] = v4f{-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // "tile -1": nothing fires
     // reduce of the tile in set S (number tile_no): hit[]
@@ -284,14 +363,26 @@ void filter_kernel(FParams p)
                 }
             }
         }
+        float x4 = INFINITY;
+        if constexpr (TRI) {
+            // the loosest X of the lane's four rows of this tile (the priming call in front of a piece's first tile -- set S holds
+            // -inf, the slot of that tile number is not this piece's -- tests against +inf: nothing fires)
+            if (tile_no >= st0 * (kFStageRows / 16))          // (uniform)
+                x4 = *(const float*)(xbase + ((tile_no >> 3) % 3) * kFTriXBytes + 1024 + 4 * (4 * (tile_no & 7) + g));
+        }
 #pragma unroll
-        for (int j = 0; j < NC; ++j)        // v_maximum3_f32 (no NaN-quieting pre-pass as fmaxf needs); NaN cannot occur here
-            hit[j] = __builtin_amdgcn_ballot_w64(fmax3(fmax3(acc[S][j][0], acc[S][j][1], acc[S][j][2]), acc[S][j][3], acc[S][j][3]) >= thr[j]);
+        for (int j = 0; j < NC; ++j) {      // v_maximum3_f32 (no NaN-quieting pre-pass as fmaxf needs); NaN cannot occur here
+            const float tm = fmax3(fmax3(acc[S][j][0], acc[S][j][1], acc[S][j][2]), acc[S][j][3], acc[S][j][3]);
+            hit[j] = __builtin_amdgcn_ballot_w64(tm >= thr[j]);
+            if constexpr (TRI) chit[j] = __builtin_amdgcn_ballot_w64(tm - hc[j] >= x4);       // column direction, first level
+        }
+        unsigned long long any = hit[0] | hit[1] | hit[2] | hit[3];
+        if constexpr (TRI) any |= chit[0] | chit[1] | chit[2] | chit[3];
 #ifdef FM_ABLATE_F32_NOEXACT
         // ablation build only (scripts/README.md): what the filter costs when NO tile takes the exact path.  Results are wrong.
-        return (hit[0] | hit[1] | hit[2] | hit[3]) != 0ull && p.nstages < 0;
+        return any != 0ull && p.nstages < 0;
 #else
-        return (hit[0] | hit[1] | hit[2] | hit[3]) != 0ull;
+        return any != 0ull;
 #endif
     };
     // tile K of half h of stage st: its MFMAs into set K & 1 and, in the same block, the reduce of the tile before it
@@ -319,6 +410,12 @@ void filter_kernel(FParams p)
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
                         gnext[j] = __hip_atomic_load(boundk + cb + 16 * j + c16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if constexpr (TRI) {
+                    // stage st + 2's words (requested one hand-over ago, landed behind the wait above) into its slot -- the
+                    // slot of stage st - 1, which every wave left before the barrier above; then stage st + 3's are requested
+                    x_store(st + 2);
+                    x_request(st + 3);
                 }
             }
             // the next tile is the first of the other half -- of the other buffer behind the second half
@@ -373,6 +470,39 @@ void filter_kernel(FParams p)
             }
             thr[j] = fmaxf(thr[j], ea[j][KTOP - 1] - marg[j]);
         }
+        if constexpr (TRI) {
+            // column direction: the streamed rows of this tile gain candidates from the lane's output rows
+            // (r06, measured and not kept: ONE first-level test for the four blocks -- more false visits than it saves --, the
+            // append's returning atomic consumed a stage later instead of at once (1.820 against 1.816 ms), and a fire raising
+            // the row's X in LDS for the rest of the workgroup, as the integer sweep does (1.90 against 1.81 ms))
+            if ((chit[0] | chit[1] | chit[2] | chit[3]) != 0ull) {
+                const char* slot = xbase + ((tile_no >> 3) % 3) * kFTriXBytes;
+                const v4f xr = *(const v4f*)(slot + 4 * (16 * (tile_no & 7) + 4 * g));
+                const v4f hm = *(const v4f*)(slot + 512 + 4 * (16 * (tile_no & 7) + 4 * g));
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    if (chit[j] == 0ull) continue;
+                    const int n = cb + 16 * j + c16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[S][j][r] - hc[j];
+                        const bool fire = v >= xr[r] && n < p.ncols;
+                        if (__builtin_amdgcn_ballot_w64(fire) == 0ull) continue;
+                        if (fire) {
+                            const int m = row0 + r;
+                            const float ap = v + hm[r];                    // the pair in row m's frame
+                            __hip_atomic_fetch_max(p.bound + m, fmap(ap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FM_ABLATE_TRI_NOAPPEND       // ablation build only (results are wrong): the column direction without its list append
+                            continue;
+#endif
+                            const int pos = __hip_atomic_fetch_add(p.cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (kFTriRedo - 1);
+                            if (pos < kFTriCap) p.cand[(size_t)m * kFTriCap + pos] = ((unsigned long long)__float_as_uint(ap) << 32) | (unsigned)n;
+                            else __hip_atomic_fetch_or(p.cnt + m, kFTriRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
     };
 
     int t0 = st0 * (kFStageRows / 16);
@@ -396,6 +526,26 @@ void filter_kernel(FParams p)
 #ifdef FM_ABLATE_K8_NORESCORE       // ... the sweep without its fused epilogue
     if (p.fused && p.nstages > 0) return;
 #endif
+    if constexpr (TRI) {
+        // the lane's entries that are inside the margin of their row's bound as it stands now (it only rises: a superset of
+        // what the final bound admits) join the row's list; a fourth entry inside it: rows the lane dropped may be too
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int n = cb + 16 * j + c16;
+            if (n >= p.ncols) continue;
+            const float t = funmap(__hip_atomic_load(p.bound + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - marg[j];
+#pragma unroll
+            for (int i = 0; i < kFP; ++i) {
+                if (ei[j][i] >= 0 && ei[j][i] < p.nred && ea[j][i] >= t) {
+                    const int pos = __hip_atomic_fetch_add(p.cnt + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (kFTriRedo - 1);
+                    if (pos < kFTriCap) p.cand[(size_t)n * kFTriCap + pos] = ((unsigned long long)__float_as_uint(ea[j][i]) << 32) | (unsigned)ei[j][i];
+                    if (pos >= kFTriCap || i == kFP - 1)
+                        __hip_atomic_fetch_or(p.cnt + n, kFTriRedo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        return;
+    }
     if (p.fused) {
         // ---- exact rescoring in place (the rule of rescore_kernel below, on registers) --------------
 #pragma unroll
@@ -635,6 +785,72 @@ void rescan_kernel(RParams p, int nred)
     }
 }
 
+// TRI: a row's candidate list (both directions of the triangular sweep) against its final bound, exactly.  16 lanes per row.
+struct TParams {
+    const unsigned long long* cand;
+    const int*   cnt;
+    const int*   bound;
+    const float* rowsf;
+    const float* norm;
+    float        eps_c, eps_nm;
+    int          n;
+    unsigned long long* partial;    // [n]
+    int*         flag;              // as RParams::flag
+};
+
+__global__ __launch_bounds__(256)
+void tri_rescore_kernel(TParams p)
+{
+    const int sub = threadIdx.x & 15;
+    const int n = (int)((blockIdx.x * 256 + threadIdx.x) >> 4);
+    const bool live = n < p.n;
+    const int nn = live ? n : 0;
+    const int c = p.cnt[nn];
+    const int total = c & (kFTriRedo - 1);
+    const int nent = live ? min(total, kFTriCap) : 0;
+    const float thr = funmap(p.bound[nn]) - fmaf(p.eps_c, p.norm[nn], p.eps_nm);
+    const float4* cp = (const float4*)(p.rowsf + (size_t)nn * kDim);
+    unsigned long long k0 = ~0ull;
+    for (int e0 = 0; e0 < kFTriCap; e0 += 16) {
+        const int e = e0 + sub;
+        unsigned long long slot = ~0ull;
+        if (e < nent) slot = p.cand[(size_t)nn * kFTriCap + e];
+        const unsigned idx = (unsigned)slot;
+        const bool valid = e < nent && __uint_as_float((unsigned)(slot >> 32)) >= thr && idx != (unsigned)nn;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+        if (valid) {
+            const float4* rp = (const float4*)(p.rowsf + (size_t)idx * kDim);
+            float sum = 0.f;
+#pragma unroll 8
+            for (int k4 = 0; k4 < kDim / 4; ++k4) {
+                const float4 a = cp[k4];
+                const float4 b = rp[k4];
+                float v;
+                v = a.x - b.x; sum = __builtin_fmaf(v, v, sum);
+                v = a.y - b.y; sum = __builtin_fmaf(v, v, sum);
+                v = a.z - b.z; sum = __builtin_fmaf(v, v, sum);
+                v = a.w - b.w; sum = __builtin_fmaf(v, v, sum);
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(sqrtf(sum)) << 32) | idx;
+            k0 = key < k0 ? key : k0;
+        }
+    }
+#pragma unroll
+    for (int mask = 1; mask < 16; mask <<= 1) {
+        const unsigned long long o = __shfl_xor(k0, mask);
+        k0 = o < k0 ? o : k0;
+    }
+    if (live && sub == 0) {
+        p.partial[n] = k0;
+        if ((c & kFTriRedo) || total > kFTriCap) {          // the list may be incomplete: a full exact scan of this row
+            const int pos = atomicAdd(p.flag + 1, 1);
+            atomicAdd(p.flag + 3, 1);
+            if (pos < kFMaxRescan) p.flag[4 + pos] = n;
+            else atomicOr(p.flag, 1);
+        }
+    }
+}
+
 // Accumulator inits of a reduced bank in the accumulator units of a pair of banks of different scales (times 2^(kc - km),
 // exact); padding rows keep their -3.4e38 so that no scale brings them above an empty threshold.
 __global__ __launch_bounds__(256)
@@ -784,6 +1000,50 @@ hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const Filt
         if (ktop == 1) FM_LAUNCH_RESCORE(1); else FM_LAUNCH_RESCORE(2);
 #undef FM_LAUNCH_RESCORE
     }
+    return hipGetLastError();
+}
+
+size_t filter_tri_bytes(int ncols_alloc) { return (size_t)ncols_alloc * kFTriCap * 8 + (size_t)ncols_alloc * 4 + 256; }
+
+// fm_self_dist of a float32-route bank by the triangular sweep: partial[n] = key of row n's nearest OTHER row (K5's key).
+// ws: filter_tri_bytes(plan.ncols_alloc) bytes (lists, then counters); bound: plan.ncols_alloc words preset to
+// filter_empty_bound(); flag as launch_filter's.
+hipError_t launch_filter_tri(const Bank& bank, const TriPlan& plan, int bound_every, void* ws, int* bound, int* flag,
+                             unsigned long long* partial, hipStream_t stream)
+{
+    if (plan.npieces < 1 || plan.stages < 4 || !bank.rowsh || !bank.filt_ok) return hipErrorInvalidValue;
+    const float eps = 1.1f / 1024.0f;
+    FParams p{};
+    p.col_rows = (const char*)bank.rowsh;  p.col_norm = bank.normf;  p.ncols = (int)bank.n;  p.ncols_pad = (int)bank.n_pad;
+    p.red_rows = (const char*)bank.rowsh;  p.red_aux = bank.auxf;    p.nred = (int)bank.n;
+    p.nstages = (int)(bank.n_pad / kFStageRows);
+    p.nsplit = 1;  p.nchunks = plan.nchunks;  p.stages_per_split = p.nstages;  p.ncols_alloc = plan.ncols_alloc;
+    p.eps_c = eps;  p.eps_nm = eps * bank.nm_max;  p.aux_mul = 1.0f;
+    p.slots = nullptr;  p.bound = bound;  p.flag = flag;  p.fused = 0;
+    p.col_rowsf = bank.rowsf;  p.red_rowsf = bank.rowsf;  p.partial = partial;
+    p.bound_mask = 0;
+    for (int b = 2; b <= 64; b <<= 1) if (bound_every == b) p.bound_mask = b - 1;
+    p.tri_S = plan.stages;
+    p.cand = (unsigned long long*)ws;
+    p.cnt = (int*)((char*)ws + (size_t)plan.ncols_alloc * kFTriCap * 8);
+    hipError_t e = hipMemsetAsync(p.cnt, 0, (size_t)plan.ncols_alloc * 4, stream);
+    if (e != hipSuccess) return e;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int first = phase == 0 ? 0 : plan.ndiag, count = phase == 0 ? plan.ndiag : plan.npieces - plan.ndiag;
+        if (count <= 0) continue;
+        p.tri_first = first;
+        hipLaunchKernelGGL((filter_kernel<4, 1, 8, true, true>), dim3((unsigned)count), dim3(512), 0, stream, p);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    TParams t;
+    t.cand = p.cand;  t.cnt = p.cnt;  t.bound = bound;  t.rowsf = bank.rowsf;  t.norm = bank.normf;
+    t.eps_c = p.eps_c;  t.eps_nm = p.eps_nm;  t.n = (int)bank.n;  t.partial = partial;  t.flag = flag;
+    hipLaunchKernelGGL(tri_rescore_kernel, dim3((unsigned)(((size_t)bank.n * 16 + 255) / 256)), dim3(256), 0, stream, t);
+    RParams r{};
+    r.slots = nullptr;  r.nsplit = 1;  r.ncols_alloc = plan.ncols_alloc;  r.bound = bound;
+    r.col_rowsf = bank.rowsf;  r.col_norm = bank.normf;  r.red_rowsf = bank.rowsf;
+    r.eps_c = p.eps_c;  r.eps_nm = p.eps_nm;  r.ncols = (int)bank.n;  r.partial = partial;  r.flag = flag;  r.self = 1;
+    hipLaunchKernelGGL((rescan_kernel<1>), dim3(kFMaxRescan * kFRescanSplit), dim3(256), 0, stream, r, (int)bank.n);
     return hipGetLastError();
 }
 

@@ -86,8 +86,8 @@ struct Tuning {
                                       // two; r04 A/B on two boxes, ms per pair in the 12-pair launch: 1 -> 0.8356 / 0.8501, 8 -> 0.8290 /
                                       // 0.8399, 32 -> 0.8277, 1024 -> 0.8340: profiles/r04c_k1_bound_every_*)
     int refill_grid = 128;            // fm_bank_refill_u8_async: workgroups of the preparation kernel (each walks its share of the tiles)
-    int self_tri = 1;                 // fm_self_dist on integer banks: 1 = the triangular sweep (every distance once) from 32768 rows
-                                      // on, 0 = the masked full sweep always, 2 = the triangular sweep always (tests)
+    int self_tri = 1;                 // fm_self_dist: 1 = the triangular sweep (every distance once) from 32768 rows on (integer banks) /
+                                      // 65536 (float32-route banks, r06), 0 = the masked full sweep always, 2 = the triangular sweep always (tests)
     int tri_stages = 0;               // ... stages (128 rows) per slice of the triangular sweep (0 = plan_tri's search)
     int k1_order = 0;                 // K1: workgroup -> (chunk, split) mapping (rowreduce.hip, map_block): 0 split major,
                                       // 1 an XCD owns output chunks, 2 an XCD owns a contiguous share of the split-major order
@@ -167,6 +167,11 @@ bool filter_usable(const Bank& cols, const Bank& red);   // both banks carry fil
 hipError_t launch_filter(const Bank& cols, const Bank& red, int ktop, const FilterPlan& plan,
                          unsigned long long* slots, int* bound, int* flag,
                          unsigned long long* partial, hipStream_t stream, bool self = false, float* aux_scratch = nullptr);
+
+// fm_self_dist of a float32-route bank by the triangular sweep (filter_f16.hip, TRI): every distance once
+size_t filter_tri_bytes(int ncols_alloc);
+hipError_t launch_filter_tri(const Bank& bank, const TriPlan& plan, int bound_every, void* ws, int* bound, int* flag,
+                             unsigned long long* partial, hipStream_t stream);
 
 // ---- K9: exact k-NN lists for k up to 8 on the vector ALUs (knn_k.hip; the reference's own calls -- k = 1, 2 -- stay on K1 / K8)
 size_t knnk_partial_bytes(int64_t nq, int64_t nt, int k);

@@ -171,6 +171,27 @@ struct TopK8 {
     }
 };
 
+// ---- the triangular self sweeps (rowreduce.hip TRI, filter_f16.hip TRI) ------------------------------------
+// Entry e of the triangular sweep's workgroup list (plan_tri / tri_pieces in api_grid.hip build the same list on the host, for
+// fm_self_dist_plan and the tests): the first nchunks entries are the diagonal blocks (chunk e against its own four stages);
+// then piece-number major -- round i holds piece i of every chunk k that still has stages from 4 k + 4 + i S on, i.e. the first
+// ceil((nstages - 4 - i S) / 4) chunks.  (r05, last: a device table per bank size -- hipMalloc, upload, a cache of 64 -- made
+// the plan of a NEW size cost ~50 us; a dataset of small images has a new size per image.)  Scalar: at most nstages / S rounds.
+__device__ __forceinline__ void tri_entry(int e, int nchunks, int nstages, int S, int& chunk, int& st0, int& st1)
+{
+    if (e < nchunks) { chunk = e; st0 = 4 * e; st1 = min(nstages, 4 * e + 4); return; }
+    int r = e - nchunks, i = 0;
+    for (;;) {
+        const int cnt = (nstages - 4 - i * S + 3) >> 2;       // chunks of round i (> 0 for every entry of the list)
+        if (r < cnt || cnt <= 0) break;
+        r -= cnt;
+        ++i;
+    }
+    chunk = r;
+    st0 = 4 * r + 4 + i * S;
+    st1 = min(nstages, st0 + S);
+}
+
 // ---- float32 sqrt ties of the integer route -------------------------------------------------
 // cv::batchDistance takes dist = sqrtf((float)d2) BEFORE the k-NN insertion and the cross-check
 // compare, so candidates are ordered by (float32 bits of the distance,

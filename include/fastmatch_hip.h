@@ -91,7 +91,8 @@ int  fm_ctx_destroy(fm_ctx* ctx);
  *                         contiguous share of the split-major order (the guide's XCD remap); see rowreduce.hip
  *   "bound_every"  1..1024  K1 / K2: workgroups re-read the shared K-th-best bounds at every stage of a sweep's first
  *                         eight and then at every n-th (a power of two; 16).  A stale bound is merely weaker
- *   "self_tri"     0..2   fm_self_dist / fm_self_dist_batch on integer banks: 1 = the triangular sweep from 32768 padded rows
+ *   "self_tri"     0..2   fm_self_dist / fm_self_dist_batch: 1 = the triangular sweep (every distance once) -- float32-route banks (r06)
+ *                         from 65536 padded rows on; integer banks from 32768 padded rows
  *                         on and for every run of two or more integer banks in a batch call, whatever their sizes (1),
  *                         0 = always the masked full sweep, 2 = always the triangular one
  *   "tri_stages"   0..    ... 128-row stages per workgroup of its launch B (0 = chosen per bank size: fm_self_dist_plan)

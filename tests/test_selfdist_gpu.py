@@ -100,6 +100,60 @@ def test_self_dist_float32_route(ctx, n):
     assert _eq(sd, oracle.self_dist(D, order=1))
 
 
+@pytest.mark.parametrize("n,stages", [(2, 0), (130, 0), (512, 0), (513, 4), (700, 0), (1023, 5), (1537, 0), (4100, 17), (9000, 0)])
+def test_self_dist_float32_triangular_sweep_small_sizes(n, stages):
+    """r06: the float32 route's triangular self sweep -- every tile above the diagonal once, the
+    column direction as a filter against the streamed rows' bounds + per-row candidate lists, exact rescoring -- forced on
+    ("self_tri" 2) for sizes around the chunk (512) and stage (128) boundaries and several piece lengths: the oracle's
+    order-1 chain bit for bit, duplicates (distance 0) included, and the masked full sweep's bits."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    c.set_option("f32_filter", 2)
+    rng = np.random.default_rng(600 + n)
+    D = (synth.synth_sift(n, rng).astype(np.float32) + rng.uniform(-0.4, 0.4, (n, 128)).astype(np.float32))
+    if n >= 100:
+        D[7] = D[60]
+        D[n - 1] = D[n // 2]
+    b = c.bank(D)
+    before = c.f32_filter_stats()[0]
+    c.set_option("self_tri", 2)
+    c.set_option("tri_stages", stages)
+    tri = c.self_dist(b)
+    c.set_option("self_tri", 0)
+    full = c.self_dist(b)
+    assert c.f32_filter_stats()[0] == before + 2
+    assert _eq(tri, oracle.self_dist(D, order=1)) and _eq(tri, full)
+    c.close()
+
+
+def test_self_dist_float32_triangular_sweep_at_size_and_on_near_duplicates():
+    """The sizes the rule sends there by itself (from 65536 padded rows): 70 001 rows against the masked sweep (all rows) and
+    the oracle (a row sample); a bank of near duplicates, where everything is inside the margin and the lists overflow into
+    rescans or the whole call into K5 -- same bits either way."""
+    import fastmatch_amd
+    c = fastmatch_amd.Context(0)
+    rng = np.random.default_rng(701)
+    n = 70001
+    D = (synth.synth_sift(n, rng).astype(np.float32) + rng.uniform(-0.4, 0.4, (n, 128)).astype(np.float32))
+    D[11] = D[40000]; D[n - 1] = D[123]
+    b = c.bank(D)
+    assert c.get_option("self_tri") == 1
+    tri = c.self_dist(b)                                    # (the default rule: triangular at this size)
+    c.set_option("self_tri", 0)
+    full = c.self_dist(b)
+    assert _eq(tri, full) and tri[11] == 0.0 and tri[n - 1] == 0.0
+    rows = np.sort(rng.choice(n, 600, replace=False))
+    oi, od = oracle.bf_knn(D[rows], D, 2, order=1)
+    assert _eq(tri[rows], od[:, 1].astype(np.float64))
+    assert c.f32_filter_stats()[1] == 0                     # neither call needed the all-pairs kernel
+    base = synth.synth_sift(40, rng).astype(np.float32)
+    E = np.repeat(base, 60, axis=0) + rng.normal(0, 1e-3, (2400, 128)).astype(np.float32)
+    c.set_option("f32_filter", 2)
+    c.set_option("self_tri", 2)
+    assert _eq(c.self_dist(c.bank(E)), oracle.self_dist(E, order=1))
+    c.close()
+
+
 def test_self_dist_float32_filter_forced_and_rescans(ctx):
     """The fp16 filter on a bank of near duplicates (many rows inside the margin -> rescans) with the option that
     sends every call through it."""

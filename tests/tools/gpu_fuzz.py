@@ -170,8 +170,10 @@ def fuzz_match(rng):
                                         q["thumb_positions"], q["thumb_size"], options=dict(opts, context=ctx))
     fi = cache.Feature_Image(t["size"], t["positions"], t["descriptors"], t["thumb_positions"],
                              t["thumb_descriptors"], t["thumb_size"])
-    oq = fo.OQuery(q["descriptors"], q["positions"], q["size"],
-                   thumb={"descriptors": q["thumb_descriptors"], "positions": q["thumb_positions"], "size": q["thumb_size"]},
+    # (the oracle wants both sides in one dtype: for the mixed case it gets the query's integers as float32 -- the same numbers)
+    oqd = (lambda a: a.astype(np.float32)) if mixed else (lambda a: a)
+    oq = fo.OQuery(oqd(q["descriptors"]), q["positions"], q["size"],
+                   thumb={"descriptors": oqd(q["thumb_descriptors"]), "positions": q["thumb_positions"], "size": q["thumb_size"]},
                    **({"metric": opts["metric"]} if "metric" in opts else {}))
     ot = {"size": t["size"], "positions": t["positions"], "descriptors": t["descriptors"],
           "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
