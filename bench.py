@@ -903,6 +903,27 @@ def main():
         del Qall
         qall.close()
         tbf.close()
+        # Metric_Cache build of a RootSIFT-style query image (cache.pyx:250-252, 271-273): the self distances of a 100k-row
+        # float32-route bank -- the masked full sweep against the triangular one (r06: every distance once)
+        sb = ctx.bank(Tf[:100000])
+        keep_tri = ctx.get_option("self_tri")
+        sd_ms, sd_out = {}, {}
+        for name, opt in (("masked_full_sweep", 0), ("triangular_sweep", 2)):
+            ctx.set_option("self_tri", opt)
+            sd_out[name] = ctx.self_dist(sb)
+            ctx.reset_stats()
+            for _ in range(3):
+                ctx.self_dist(sb)
+            sst = ctx.stats()
+            sd_ms[name] = sst["kernel_ms"] / max(sst["kernel_launches"], 1)
+        ctx.set_option("self_tri", keep_tri)
+        f32["self_dist_100k"] = {
+            "kernel_ms_masked_full_sweep": sd_ms["masked_full_sweep"], "kernel_ms_triangular_sweep": sd_ms["triangular_sweep"],
+            "ratio": sd_ms["triangular_sweep"] / sd_ms["masked_full_sweep"],
+            "identical": bool(np.array_equal(sd_out["masked_full_sweep"].view(np.uint64), sd_out["triangular_sweep"].view(np.uint64))),
+            "frac_fp16_mfma_peak_over_n_squared": 1e10 * 256 / (sd_ms["triangular_sweep"] * 1e-3) / 2.5e15,
+            "note": "fm_self_dist of a 100k-row float32-route bank (the default rule takes the triangular sweep from 65536 padded rows)"}
+        sb.close()
 
     fresh = None
     if rank == 0 and world == 1 and legs and use_async and os.environ.get("FM_BENCH_FRESH", "1") != "0":
