@@ -861,6 +861,7 @@ def main():
         Tf = synth.synth_sift(n_bank, rng5).astype(np.float32) + rng5.uniform(-0.5, 0.5, (n_bank, 128)).astype(np.float32)
         Qf = synth.synth_sift(n_query, rng5).astype(np.float32) + rng5.uniform(-0.5, 0.5, (n_query, 128)).astype(np.float32)
         tbf, qbf = ctx.bank(Tf), ctx.bank(Qf)
+        Sf = Tf[:100000].copy()               # (the self-distance entry below)
         del Tf
         f32 = {}
         for name, fn in (("knn2", lambda: ctx.knn2(qbf, tbf)), ("xcheck1", lambda: ctx.xcheck1(qbf, tbf))):
@@ -905,7 +906,7 @@ def main():
         tbf.close()
         # Metric_Cache build of a RootSIFT-style query image (cache.pyx:250-252, 271-273): the self distances of a 100k-row
         # float32-route bank -- the masked full sweep against the triangular one (r06: every distance once)
-        sb = ctx.bank(Tf[:100000])
+        sb = ctx.bank(Sf)
         keep_tri = ctx.get_option("self_tri")
         sd_ms, sd_out = {}, {}
         for name, opt in (("masked_full_sweep", 0), ("triangular_sweep", 2)):

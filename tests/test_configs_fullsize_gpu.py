@@ -75,8 +75,8 @@ def test_config3_full_size_device_loop_host_loop_oracle(ctx):
     assert len(dev) > 20000
 
     # (r06: the GPU suite has a time budget -- VERDICT r05 item 6 -- and the oracle replays 200 rounds per second: the
-    # default prefix is 6000 rounds; FM_C3_ORACLE_ROUNDS=0 replays all 41 704.  Device loop == host loop covers every round.)
-    cap = int(os.environ.get("FM_C3_ORACLE_ROUNDS", "6000"))
+    # default prefix is 4000 rounds; FM_C3_ORACLE_ROUNDS=0 replays all 41 704.  Device loop == host loop covers every round.)
+    cap = int(os.environ.get("FM_C3_ORACLE_ROUNDS", "4000"))
     oget = fo.o_match(oq, ot, {"max_rounds": cap} if cap else {})
     exp = oget(0.7)
     if cap and oget.rounds >= cap:

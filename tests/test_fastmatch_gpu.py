@@ -416,7 +416,7 @@ def test_device_loop_on_clustered_keypoints(ctx):
           "thumb": {"descriptors": t["thumb_descriptors"], "positions": t["thumb_positions"], "size": t["thumb_size"]}}
     # (the oracle replays a prefix of the run by default -- the suite's time budget; the rounds beyond it
     # are covered by device loop == host loop above.  FM_CLUSTERED_ORACLE_ROUNDS=0: all of them.)
-    cap = int(os.environ.get("FM_CLUSTERED_ORACLE_ROUNDS", "1200"))
+    cap = int(os.environ.get("FM_CLUSTERED_ORACLE_ROUNDS", "800"))
     oget = fo.o_match(oq, ot, {"max_rounds": cap} if cap else {})
     exp = oget(0.7)
     if cap and oget.rounds >= cap:

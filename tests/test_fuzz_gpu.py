@@ -15,5 +15,6 @@ pytestmark = pytest.mark.gpu
 def test_fixed_fuzz_slice_equals_oracle(ctx, seed0):
     import gpu_fuzz
     # (no wall-clock budget: only the fixed seed slice decides, a loaded host cannot end it early)
-    n, counts = gpu_fuzz.run(budget=float("inf"), seed0=seed0, max_problems=20, context=ctx)
-    assert n == 20 and counts.get("match", 0) == 5 and len(counts) >= 4
+    # (r06: 12 problems per slice instead of 20 -- the suite's time budget; the open-ended tool runs hundreds per round)
+    n, counts = gpu_fuzz.run(budget=float("inf"), seed0=seed0, max_problems=12, context=ctx)
+    assert n == 12 and counts.get("match", 0) == 3 and len(counts) >= 3
