@@ -697,10 +697,14 @@ extern "C" int fm_knn(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t k
     if (nq > 0 && (!idx || !dist)) return fail(ctx, FM_EINVAL, "fm_knn: output pointer is NULL");
     if (nq == 0) return FM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t out_bytes = (size_t)nq * (size_t)(k < 2 ? 2 : k) * 4;
-    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, 2 * ((out_bytes + 255) & ~(size_t)255) + 64)) != FM_OK) return rc;
+    // idx [nq][max(k, 2)] | dist [nq][max(k, 2)] | (k = 1) first columns idx1 [nq], dist1 [nq]
+    const size_t out_bytes = (((size_t)nq * (size_t)(k < 2 ? 2 : k) * 4) + 255) & ~(size_t)255;
+    const size_t col_bytes = (((size_t)nq * 4) + 255) & ~(size_t)255;
+    if ((rc = ws_ensure(ctx, &ctx->ws_out, &ctx->ws_out_bytes, 2 * out_bytes + 2 * col_bytes + 64)) != FM_OK) return rc;
     int32_t* d_idx = (int32_t*)ctx->ws_out;
-    float* d_dist = (float*)((char*)ctx->ws_out + ((out_bytes + 255) & ~(size_t)255));
+    float* d_dist = (float*)((char*)ctx->ws_out + out_bytes);
+    int32_t* d_idx1 = (int32_t*)((char*)ctx->ws_out + 2 * out_bytes);
+    float* d_dist1 = (float*)((char*)ctx->ws_out + 2 * out_bytes + col_bytes);
     CallScope cs(ctx);
     if (k <= 2) {
         // the matrix-core path; k = 1 is the first column of the 2-NN lists
@@ -709,10 +713,10 @@ extern "C" int fm_knn(fm_ctx* ctx, const fm_bank* q, const fm_bank* t, int32_t k
             HIP_TRY(ctx, d2h(ctx, idx, d_idx, (size_t)nq * 8));
             HIP_TRY(ctx, d2h(ctx, dist, d_dist, (size_t)nq * 8));
         } else {
-            HIP_TRY(ctx, hipMemcpy2DAsync(d_idx + 2 * nq, 4, d_idx, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpy2DAsync(d_dist + 2 * nq, 4, d_dist, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(ctx, d2h(ctx, idx, d_idx + 2 * nq, (size_t)nq * 4));
-            HIP_TRY(ctx, d2h(ctx, dist, d_dist + 2 * nq, (size_t)nq * 4));
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_idx1, 4, d_idx, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpy2DAsync(d_dist1, 4, d_dist, 8, 4, (size_t)nq, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, d2h(ctx, idx, d_idx1, (size_t)nq * 4));
+            HIP_TRY(ctx, d2h(ctx, dist, d_dist1, (size_t)nq * 4));
         }
         return cs.finish();
     }

@@ -136,7 +136,7 @@ def match(query_cache, target_img, options={}):
                                 if log is not None:
                                     state["lazy"][0].set_log(True, first_capacity=options.get("log_first_capacity", 0))
                                 ex, t_bank = state["lazy"]
-                                resume = False
+                                resume, added = False, 0
                                 continue
                             ds = u8
                         off = np.array([row * target_cache.cell_width - target_cache.margin,

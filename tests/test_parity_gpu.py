@@ -946,6 +946,11 @@ def test_bf_match_for_any_k_up_to_8(ctx, k):
         oi, od = oracle.bf_knn(q, t, k, order=order)
         idx, dist = matchutil.bf_match_arrays(q, t, k=k, options={"context": ctx})
         assert _eq(idx, oi) and _eq(dist, od), (k, q.shape, t.shape, q.dtype)
+    # the C-ABI entry point itself for every k (k = 1, 2 take the matrix-core path inside it); 704 query rows: a multiple of 64
+    qb, tb = ctx.bank(Q[:704] if len(Q) >= 704 else Q), ctx.bank(T)
+    oi, od = oracle.bf_knn(Q[:704] if len(Q) >= 704 else Q, T, k)
+    idx, dist = ctx.knn(qb, tb, k)
+    assert _eq(idx, oi) and _eq(dist, od)
     lists = matchutil.bf_match(Q[:4], T[:k - 1] if k > 1 else T[:1], k=k, options={"context": ctx})
     assert [len(m) for m in lists] == [max(1, k - 1) if k > 1 else 1] * 4      # shorter inner lists, as cv2 returns them
     if k == 3:
