@@ -486,7 +486,7 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     P.lg_round = (gptr<long long>)M.lg_round; P.lg_q = (gptr<int32_t>)M.lg_q; P.lg_t = (gptr<int32_t>)M.lg_t; P.lg_ratio = (gptr<double>)M.lg_ratio;
     P.lg_round_cap = M.lg_round_cap; P.lg_entry_cap = M.lg_entry_cap;
     const RoundF32G RF(M.rf);
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
 
     long long top = 0;            // stack height: owned by thread 0, published in sh_top each round
     long long seed_i = 0;
@@ -539,6 +539,11 @@ void expand_kernel(const ExpandPair* __restrict__ pairs)
     }
 
     for (;;) {
+        // (the chunked / lazy variants sit at the 256-register ceiling: with the thread number opaque per round, the address
+        // arithmetic on it is redone where it is used instead of being hoisted out of the loop and parked in scratch)
+#ifndef FM_K7_NO_OPAQUE_TID         // (A/B builds: scripts/README.md)
+        if constexpr (HUGE || LAZY || F32) asm volatile("" : "+v"(tid));
+#endif
         HUGE_STAMP(6);
         // ---- 1. next unseen (query_pos, target_pos) -----------------------------------------
         if ((LAZY || HUGE) && skip_pop) {
