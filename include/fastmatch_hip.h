@@ -285,12 +285,13 @@ int  fm_wait(fm_ctx* ctx, int64_t ticket);
  * rules: every qidx[i] / tidx[i] / dist[i] / ratio[i] / n_accepted[i] page-locked, results valid after
  * fm_sync).  Consecutive pairs go through the distance kernel TOGETHER, up to eight pairs per launch (option
  * "batch_group": up to sixteen) -- r05: of ANY sizes (a dataset's images all differ; before, only pairs of equal padded sizes
- * shared a launch and the others cost 7 % more per descriptor pair), as long as each is large enough for the 8-wave kernel
- * (train banks from 32768 rows): inside one launch the
+ * shared a launch and the others cost 7 % more per descriptor pair), small ones included (a pair whose train bank has fewer than
+ * 32768 rows is planned with 4-wave workgroups when it runs alone; inside a batch it is planned again in the batched kernel's
+ * 8-wave shape, the other pairs fill the chip): inside one launch the
  * workgroups of the next pair fill the CUs the previous pair leaves, where separate launches drain the chip and pay a launch gap (~4 % of
  * a 100k x 100k pair).  The reference maps its matcher over the pairs of a dataset one after the
- * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (empty banks, small
- * ones) are enqueued one by one; pairs on the float32 route, which has no enqueue-only form,
+ * other (turntable.py:59); this is that loop as one call.  Pairs that cannot be grouped (an empty bank, a query
+ * bank without self distances, an option that forces another kernel shape) are enqueued one by one; pairs on the float32 route, which has no enqueue-only form,
  * run synchronously in their place (their outputs are complete when the call returns, the pairs around
  * them stay asynchronous).  Every pair is validated before anything is enqueued.  A run of pairs ends with
  * a short launch (2 pairs) because only the LAST launch's small kernels are exposed to a caller that
