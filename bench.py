@@ -832,6 +832,19 @@ def main():
             s3 = ctx.stats()
             ctx.set_option("self_tri", 1)
             self2["kernel_ms_steady_full_sweep"] = s3["kernel_ms"] / max(s3["kernel_launches"], 1)
+        if PAIRS_PER_STEP > 1:                               # the way a dataset's Metric_Caches are built: all query banks in ONE call
+            qbs = [q for q, _ in banks]                      # (two launches for all of them; the same values are attached again)
+            ctx.self_dist_batch(qbs, want_host=False)
+            ctx.sync()                                       # (the call is enqueue-only: its events are read at the next sync)
+            ctx.reset_stats()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.self_dist_batch(qbs, want_host=False)
+            ctx.sync()
+            self2["ms_per_bank_in_a_batch"] = (time.perf_counter() - t0) * 1e3 / (5.0 * len(qbs))
+            s4 = ctx.stats()
+            self2["kernel_ms_steady_per_bank_in_a_batch"] = s4["kernel_ms"] / max(s4["kernel_launches"], 1) / len(qbs)
+            self2["banks_per_batch_call"] = len(qbs)
 
     # ONE configs[1] call, the way a caller without a batch makes it: fm_match_accepted (K1 + election +
     # ratio test + compaction into page-locked buffers) and its synchronisation, 20 repetitions.
