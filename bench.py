@@ -55,12 +55,38 @@ def k1_source_hash():
     return h.hexdigest()
 
 
+def host_cpu_allowance():
+    """(threads to use, CPU quota or None): the CPUs this process may run on -- its affinity mask, cut to the cgroup's CPU
+    quota where one is set (cpu.max, or cfs_quota_us / cfs_period_us under cgroup v1).  r06: the GPU boxes of the pool show 256
+    logical CPUs and grant 16 (cpu.max 1600000 100000); 128 threads under that quota are throttled, not faster, and "cores: 128"
+    in the line was not what the figure was measured on."""
+    import math
+    import oracle
+    n = min(len(os.sched_getaffinity(0)), oracle.max_threads())
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.floor(quota + 1e-9))))
+    return n, quota
+
+
 def cpu_baseline(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_BUDGET_S", "12")), keep=None):
     """Oracle (kind 'port': the reference's .so cannot run here) on a bounded row sample of
     the same workload, all host cores.  keep (a dict): receives the sample size and the oracle's
     (tidx, dist) of the sample, for the self-check of the timed batch."""
     import oracle
-    threads = oracle.max_threads()
+    threads, quota = host_cpu_allowance()
     s0 = 256
     t0 = time.perf_counter()
     oracle.bf_xcheck1(Q[:s0], T, threads=threads)
@@ -72,9 +98,9 @@ def cpu_baseline(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_BUDGET_S", "1
     dt = time.perf_counter() - t0
     if keep is not None:
         keep["rows"], keep["tidx"], keep["dist"] = s, res[0], res[1]
-    return {"value": s * len(T) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "oracle bf_xcheck1 (C, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s"
-                      % (s, len(Q), len(T), dt)}
+    return {"value": s * len(T) / dt, "unit": "pairs/s", "cores": threads, "kind": "port", "host_cpu_quota": quota,
+            "sample": "oracle bf_xcheck1 (C, OpenMP, %d threads%s) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s"
+                      % (threads, "" if quota is None else " = this container's CPU quota of %.4g" % quota, s, len(Q), len(T), dt)}
 
 
 def cpu_baseline_simd(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_SIMD_BUDGET_S", "6"))):
@@ -82,7 +108,7 @@ def cpu_baseline_simd(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_SIMD_BUD
     output rows per pass over the other bank; oracle.bf_xcheck1_simd, results identical): the faithful restatement runs
     at ~1 multiply-add per cycle and thread, and a GPU / CPU ratio against THAT flatters the GPU."""
     import oracle
-    threads = oracle.max_threads()
+    threads, quota = host_cpu_allowance()
     s0 = 1024
     t0 = time.perf_counter()
     oracle.bf_xcheck1_simd(Q[:s0], T, threads=threads)
@@ -96,13 +122,42 @@ def cpu_baseline_simd(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_SIMD_BUD
     # = 32 multiply-adds of the 128 a descriptor pair takes, i.e. 0.25 pairs per cycle and core
     phys, ghz = host_cores_and_ghz(threads)
     peak = phys * ghz * 1e9 * 32.0 / 128.0
-    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port",
+    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port", "host_cpu_quota": quota,
             "physical_cores": phys, "ghz": ghz, "host_vpmaddwd_peak_pairs_per_s": peak, "frac_of_host_peak": value / peak,
             "sample": "oracle bf_xcheck1_simd (C, AVX2 vpmaddwd, OpenMP) on the first %d of %d query rows x all %d target rows of pair 0, %.1f s; "
                       "= %.1f %% of this host's vpmaddwd peak (%d physical cores x %.2f GHz x 32 multiply-adds per cycle / 128 per pair): "
                       "one target row streams past eight query rows per pass, a horizontal sum and a scalar compare per pair -- a "
-                      "cache-blocked kernel with vector compares would run several times faster, so the GPU / CPU ratio from this "
-                      "figure still flatters the GPU; the fraction of the MFMA roof is the number that counts"
+                      "cache-blocked kernel with vector compares runs many times faster (cpu_baseline_blocked, where the host has AVX-512 VNNI): "
+                      "the GPU / CPU ratio from THIS figure flatters the GPU; the fraction of the MFMA roof is the number that counts"
+                      % (s, len(Q), len(T), dt, 100.0 * value / peak, phys, ghz)}
+
+
+def cpu_baseline_blocked(Q, T, budget_s=float(os.environ.get("FM_BENCH_CPU_BLOCKED_BUDGET_S", "6"))):
+    """The same oracle semantics programmed for the host's dot-product units and caches (AVX-512 VNNI vpdpbusd, 64 output rows
+    x 6 candidates per register block, vector compares; oracle.bf_xcheck1_blocked, results identical): the honest denominator
+    of a GPU / CPU ratio.  Raises on a host without VNNI."""
+    import oracle
+    threads, quota = host_cpu_allowance()
+    s0 = 4096
+    oracle.bf_xcheck1_blocked(Q[:256], T, threads=threads)          # (thread team, page faults)
+    t0 = time.perf_counter()
+    oracle.bf_xcheck1_blocked(Q[:s0], T, threads=threads)
+    dt = time.perf_counter() - t0
+    s = int(min(len(Q), max(s0, budget_s * s0 / dt)))
+    t0 = time.perf_counter()
+    oracle.bf_xcheck1_blocked(Q[:s], T, threads=threads)
+    dt = time.perf_counter() - t0
+    value = s * len(T) / dt
+    # host peak with this instruction, assuming two 512-bit vpdpbusd (64 products each) per cycle and PHYSICAL core = 128 of the
+    # 128 multiply-adds a descriptor pair takes, i.e. one pair per cycle and core (half of that where 512-bit ops issue once per cycle)
+    phys, ghz = host_cores_and_ghz(threads)
+    peak = phys * ghz * 1e9
+    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port", "host_cpu_quota": quota,
+            "pairs_per_s_per_core": value / threads, "whole_host_physical_cores": host_cores_and_ghz(1 << 20)[0],
+            "physical_cores": phys, "ghz": ghz, "host_vpdpbusd_peak_pairs_per_s": peak, "frac_of_host_peak": value / peak,
+            "sample": "oracle bf_xcheck1_blocked (C, AVX-512 VNNI vpdpbusd, register-blocked 64 x 6, OpenMP) on the first %d of %d query "
+                      "rows x all %d target rows of pair 0, %.2f s; = %.0f %% of this host's vpdpbusd peak (%d physical cores x %.2f GHz x "
+                      "128 multiply-adds per cycle / 128 per pair); the GPU / CPU ratio to quote is against THIS figure"
                       % (s, len(Q), len(T), dt, 100.0 * value / peak, phys, ghz)}
 
 
@@ -1049,6 +1104,10 @@ def main():
                 out["cpu_baseline_simd"] = cpu_baseline_simd(Q, T)
             except Exception as e:                                   # (a host without AVX2)
                 out["cpu_baseline_simd"] = {"value": None, "note": str(e)}
+            try:
+                out["cpu_baseline_blocked"] = cpu_baseline_blocked(Q, T)
+            except Exception as e:                                   # (a host without AVX-512 VNNI)
+                out["cpu_baseline_blocked"] = {"value": None, "note": str(e)}
             # self-check: the oracle result just computed against what the timed batch left for pair 0
             verified, scope, n_want = verify_against_oracle(ctx, Q, T, selfdist0, keep, timed_rows0, banks[0])
             out["verified_vs_oracle"] = verified

@@ -49,6 +49,7 @@ def _lib():
     lib.orc_bf_xcheck1_f32.argtypes = [p, c.c_int64, p, c.c_int64, c.c_int, c.c_int, p, p, c.c_int]
     lib.orc_bf_xcheck1_u8.argtypes = [p, c.c_int64, p, c.c_int64, c.c_int, p, p, c.c_int]
     lib.orc_bf_xcheck1_u8_simd.argtypes = [p, c.c_int64, p, c.c_int64, c.c_int, p, p, c.c_int]
+    lib.orc_bf_xcheck1_u8_blocked.argtypes = [p, c.c_int64, p, c.c_int64, c.c_int, p, p, c.c_int]
     lib.orc_ratio_filter.argtypes = [p, p, p, c.c_int64, c.c_double, p, p, p]
     lib.orc_lowe_ratio.argtypes = [p, c.c_int64, p]
     lib.orc_max_threads.restype = c.c_int
@@ -133,6 +134,27 @@ def bf_xcheck1_simd(Q, T, threads=0):
     rc = _lib().orc_bf_xcheck1_u8_simd(Q.ctypes.data, nq, T.ctypes.data, nt, dim, tidx.ctypes.data, dist.ctypes.data, threads)
     if rc != 0:
         raise RuntimeError("oracle bf_xcheck1_simd failed: %d" % rc)
+    return tidx, dist
+
+
+def have_vnni():
+    """Does this host run the blocked baseline (AVX-512 VNNI)?"""
+    return bool(_lib().orc_have_vnni())
+
+
+def bf_xcheck1_blocked(Q, T, threads=0):
+    """``bf_xcheck1`` for uint8 banks the way a CPU with AVX-512 VNNI would be programmed (vpdpbusd, 64 output rows x 6
+    candidates per register block, vector compares; bfmatch_oracle.c ``knn1_rows_u8_vnni``): the same results bit for bit --
+    bench.py's third CPU baseline, the honest denominator of a GPU / CPU ratio.  RuntimeError on a host without VNNI."""
+    Q, T, kind = _pair(Q, T)
+    if kind != "u8":
+        raise ValueError("the blocked baseline exists for uint8 banks")
+    nq, nt, dim = Q.shape[0], T.shape[0], Q.shape[1]
+    tidx = np.empty(nq, dtype=np.int32)
+    dist = np.empty(nq, dtype=np.float32)
+    rc = _lib().orc_bf_xcheck1_u8_blocked(Q.ctypes.data, nq, T.ctypes.data, nt, dim, tidx.ctypes.data, dist.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("oracle bf_xcheck1_blocked failed: %d%s" % (rc, " (no AVX-512 VNNI on this host)" if rc == -2 else ""))
     return tidx, dist
 
 

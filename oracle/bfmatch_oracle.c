@@ -331,6 +331,185 @@ ORC_API int orc_bf_xcheck1_u8_simd(const uint8_t* Q, int64_t nq, const uint8_t* 
 #endif
 }
 
+/* ---- the same cross-check, blocked for the caches and the dot-product units (a third CPU baseline; results identical) ----
+ * What a CPU programmer with AVX-512 VNNI would write, so that bench.py's GPU / CPU ratio has an honest denominator:
+ *   d2(a, c) = |a|^2 + |c|^2 - 2 a.c,   a.c = sum a_k (c_k - 128) + 128 sum a_k  -- vpdpbusd (u8 x s8 -> int32, 64 products per
+ *   instruction, no saturation) on the candidates' bytes with the top bit flipped;
+ *   output rows packed 16 to a register (lane = output row, 4 consecutive bytes of it), the candidate's 4 bytes broadcast:
+ *   one vpdpbusd advances 16 pairs by 4 dimensions, nothing is summed across lanes;
+ *   register block: 64 output rows x 6 candidates = 24 accumulators; a block's 64 rows stream the candidate bank once;
+ *   the reduction keeps (d2, float32 root, index) of the best candidate per lane: an integer compare d2 <= best d2 per
+ *   accumulator, and only where a lane passes the float32 roots are formed and compared with the strict '<' of the scan
+ *   above -- candidates in ascending index order, so the same winner, bit for bit (tests/test_oracle_kat.py).
+ * Compiled for the instruction set by a target attribute, chosen at run time (orc_have_vnni).                            */
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define ORC_VNNI_TARGET __attribute__((target("avx512f,avx512bw,avx512vl,avx512dq,avx512vnni")))
+#define ORC_VG 4      /* groups of 16 output rows per block */
+#define ORC_VC 6      /* candidates per block (vnni_block names its 4 x 6 accumulators: change both) */
+#define ORC_UNROLL _Pragma("GCC unroll 8")
+
+/* (no-tree-pre: with partial-redundancy elimination gcc 11 keeps a copy of every accumulator on the stack inside the loop) */
+ORC_VNNI_TARGET __attribute__((optimize("no-tree-pre")))
+static void vnni_block(const uint8_t* ap /* [kg][ORC_VG][64] */, const int32_t* P /* [ORC_VG][16] */, int kg,
+                       const int8_t* const* cand /* ORC_VC rows, kg * 4 bytes each */, const int32_t* nc, int valid, int64_t j0,
+                       int32_t* best2, float* bestd, int32_t* besti /* each [ORC_VG][16] */)
+{
+    /* (24 named accumulators: as an array gcc keeps copying them between registers inside the loop) */
+#define ORC_ROW(c) __m512i acc##c##0 = _mm512_setzero_si512(), acc##c##1 = acc##c##0, acc##c##2 = acc##c##0, acc##c##3 = acc##c##0;
+    ORC_ROW(0) ORC_ROW(1) ORC_ROW(2) ORC_ROW(3) ORC_ROW(4) ORC_ROW(5)
+#undef ORC_ROW
+    const int8_t* const cp0 = cand[0]; const int8_t* const cp1 = cand[1]; const int8_t* const cp2 = cand[2];
+    const int8_t* const cp3 = cand[3]; const int8_t* const cp4 = cand[4]; const int8_t* const cp5 = cand[5];
+    for (int k = 0; k < kg; k++) {
+        const __m512i a0 = _mm512_load_si512((const void*)(ap + ((size_t)k * ORC_VG + 0) * 64));
+        const __m512i a1 = _mm512_load_si512((const void*)(ap + ((size_t)k * ORC_VG + 1) * 64));
+        const __m512i a2 = _mm512_load_si512((const void*)(ap + ((size_t)k * ORC_VG + 2) * 64));
+        const __m512i a3 = _mm512_load_si512((const void*)(ap + ((size_t)k * ORC_VG + 3) * 64));
+#define ORC_STEP(c) { int32_t w; memcpy(&w, cp##c + 4 * k, 4); const __m512i b = _mm512_set1_epi32(w); \
+        acc##c##0 = _mm512_dpbusd_epi32(acc##c##0, a0, b); acc##c##1 = _mm512_dpbusd_epi32(acc##c##1, a1, b); \
+        acc##c##2 = _mm512_dpbusd_epi32(acc##c##2, a2, b); acc##c##3 = _mm512_dpbusd_epi32(acc##c##3, a3, b); }
+        ORC_STEP(0) ORC_STEP(1) ORC_STEP(2) ORC_STEP(3) ORC_STEP(4) ORC_STEP(5)
+#undef ORC_STEP
+    }
+    /* d2 = P + |c|^2 - 2 acc, lane by lane; does any lane of any accumulator reach its best d2?
+     * (named values again: an array here makes gcc keep a copy of the accumulators in memory through the loop above) */
+    const __m512i pg0 = _mm512_load_si512((const void*)(P + 0)), pg1 = _mm512_load_si512((const void*)(P + 16));
+    const __m512i pg2 = _mm512_load_si512((const void*)(P + 32)), pg3 = _mm512_load_si512((const void*)(P + 48));
+    const __m512i bb0 = _mm512_load_si512((const void*)(best2 + 0)), bb1 = _mm512_load_si512((const void*)(best2 + 16));
+    const __m512i bb2 = _mm512_load_si512((const void*)(best2 + 32)), bb3 = _mm512_load_si512((const void*)(best2 + 48));
+    __mmask16 any = 0;
+#define ORC_D2(c, g) const __m512i d##c##g = _mm512_sub_epi32(_mm512_add_epi32(pg##g, n##c), _mm512_slli_epi32(acc##c##g, 1)); \
+    any |= _mm512_cmple_epi32_mask(d##c##g, bb##g);
+#define ORC_D2ROW(c) const __m512i n##c = _mm512_set1_epi32(nc[c]); ORC_D2(c, 0) ORC_D2(c, 1) ORC_D2(c, 2) ORC_D2(c, 3)
+    ORC_D2ROW(0) ORC_D2ROW(1) ORC_D2ROW(2) ORC_D2ROW(3) ORC_D2ROW(4) ORC_D2ROW(5)
+#undef ORC_D2ROW
+#undef ORC_D2
+    if (!any) return;
+    __m512i d2[ORC_VC][ORC_VG];
+#define ORC_ST(c) d2[c][0] = d##c##0; d2[c][1] = d##c##1; d2[c][2] = d##c##2; d2[c][3] = d##c##3;
+    ORC_ST(0) ORC_ST(1) ORC_ST(2) ORC_ST(3) ORC_ST(4) ORC_ST(5)
+#undef ORC_ST
+    for (int c = 0; c < valid; c++) {          /* ascending candidate index */
+        for (int g = 0; g < ORC_VG; g++) {
+            const __m512i b2 = _mm512_load_si512((const void*)(best2 + 16 * g));
+            const __mmask16 m = _mm512_cmple_epi32_mask(d2[c][g], b2);
+            if (!m) continue;
+            const __m512 bd = _mm512_load_ps(bestd + 16 * g);
+            const __m512 d = _mm512_sqrt_ps(_mm512_cvtepi32_ps(d2[c][g]));      /* d2 < 2^24: exact conversion; IEEE root = sqrtf */
+            const __mmask16 w = _mm512_mask_cmp_ps_mask(m, d, bd, _CMP_LT_OQ);
+            if (!w) continue;
+            _mm512_store_ps(bestd + 16 * g, _mm512_mask_mov_ps(bd, w, d));
+            _mm512_store_si512((void*)(best2 + 16 * g), _mm512_mask_mov_epi32(b2, w, d2[c][g]));
+            _mm512_store_si512((void*)(besti + 16 * g), _mm512_mask_mov_epi32(_mm512_load_si512((const void*)(besti + 16 * g)), w,
+                                                                            _mm512_set1_epi32((int32_t)(j0 + c))));
+        }
+    }
+}
+
+ORC_VNNI_TARGET
+static void knn1_rows_u8_vnni(const uint8_t* A, int64_t na, const uint8_t* B, int64_t nb, int dim,
+                              int32_t* idx, float* dist, int threads)
+{
+    const int kg = (dim + 3) / 4, dpad = 4 * kg;
+    const int rows_per_block = 16 * ORC_VG;
+    const int64_t nblk = (na + rows_per_block - 1) / rows_per_block;
+    /* the candidates once: bytes with the top bit flipped (c - 128 as int8), rows padded to dpad (+ 4 bytes of slack), norms */
+    int8_t* bs = (int8_t*)aligned_alloc(64, (((size_t)(nb > 0 ? nb : 1) * (size_t)dpad + 4 + 63) / 64) * 64);
+    int32_t* ncv = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nb > 0 ? nb : 1));
+    {
+        int64_t cap = (na * nb) / 4000000 + 1;
+        if (cap < threads) threads = (int)cap;
+        if (threads < 1) threads = 1;
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t j = 0; j < nb; j++) {
+        int32_t n2 = 0;
+        for (int k = 0; k < dpad; k++) {
+            const int v = k < dim ? B[j * dim + k] : 128;          /* (padding: c - 128 = 0, and a's padding is 0 as well) */
+            bs[j * dpad + k] = (int8_t)(v - 128);
+            n2 += k < dim ? v * v : 0;
+        }
+        ncv[j] = n2;
+    }
+#pragma omp parallel num_threads(threads)
+    {
+        uint8_t* ap = (uint8_t*)aligned_alloc(64, (size_t)kg * ORC_VG * 64);
+        int32_t* P = (int32_t*)aligned_alloc(64, sizeof(int32_t) * 16 * ORC_VG);
+        int32_t* best2 = (int32_t*)aligned_alloc(64, sizeof(int32_t) * 16 * ORC_VG);
+        int32_t* besti = (int32_t*)aligned_alloc(64, sizeof(int32_t) * 16 * ORC_VG);
+        float* bestd = (float*)aligned_alloc(64, sizeof(float) * 16 * ORC_VG);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t blk = 0; blk < nblk; blk++) {
+            const int64_t i0 = blk * rows_per_block;
+            for (int g = 0; g < ORC_VG; g++)
+                for (int l = 0; l < 16; l++) {
+                    const int64_t i = i0 + 16 * g + l;
+                    int32_t n2 = 0, s1 = 0;
+                    for (int k = 0; k < dpad; k++) {
+                        const int v = (i < na && k < dim) ? A[i * dim + k] : 0;
+                        ap[((size_t)(k >> 2) * ORC_VG + g) * 64 + 4 * l + (k & 3)] = (uint8_t)v;
+                        n2 += v * v; s1 += v;
+                    }
+                    P[16 * g + l] = n2 - 256 * s1;
+                    best2[16 * g + l] = INT32_MAX; besti[16 * g + l] = -1; bestd[16 * g + l] = FLT_MAX;
+                }
+            for (int64_t j = 0; j < nb; j += ORC_VC) {
+                const int8_t* cand[ORC_VC];
+                int32_t nc[ORC_VC];
+                const int valid = (int)((nb - j) < ORC_VC ? (nb - j) : ORC_VC);
+                for (int c = 0; c < ORC_VC; c++) {        /* (beyond the bank: row j again, never visited by the reduction) */
+                    cand[c] = bs + (c < valid ? j + c : j) * dpad;
+                    nc[c] = c < valid ? ncv[j + c] : (1 << 30);
+                }
+                vnni_block(ap, P, kg, cand, nc, valid, j, best2, bestd, besti);
+            }
+            for (int r = 0; r < rows_per_block && i0 + r < na; r++) {
+                idx[i0 + r] = besti[r];
+                dist[i0 + r] = besti[r] < 0 ? INFINITY : bestd[r];
+            }
+        }
+        free(ap); free(P); free(best2); free(besti); free(bestd);
+    }
+    free(bs); free(ncv);
+}
+#endif
+
+ORC_API int orc_have_vnni(void)
+{
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vnni");
+#else
+    return 0;
+#endif
+}
+
+/* orc_bf_xcheck1_u8 through the blocked VNNI scan; -2 where the host has no AVX-512 VNNI. */
+ORC_API int orc_bf_xcheck1_u8_blocked(const uint8_t* Q, int64_t nq, const uint8_t* T, int64_t nt, int dim,
+                                      int32_t* tidx_out, float* dist_out, int threads)
+{
+#if defined(__x86_64__)
+    if (dim < 1) return -1;
+    if (!orc_have_vnni()) return -2;
+    int32_t* rq = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+    float* rd = (float*)malloc(sizeof(float) * (size_t)(nt > 0 ? nt : 1));
+    knn1_rows_u8_vnni(T, nt, Q, nq, dim, rq, rd, nthreads(threads));
+    for (int64_t q = 0; q < nq; q++) { dist_out[q] = FLT_MAX; tidx_out[q] = -1; }
+    for (int64_t i = 0; i < nt; i++) {
+        const int32_t q = rq[i];
+        if (q < 0) continue;
+        if (rd[i] < dist_out[q]) { dist_out[q] = rd[i]; tidx_out[q] = (int32_t)i; }
+    }
+    for (int64_t q = 0; q < nq; q++) if (tidx_out[q] < 0) dist_out[q] = INFINITY;
+    free(rq); free(rd);
+    return 0;
+#else
+    (void)Q; (void)nq; (void)T; (void)nt; (void)dim; (void)tidx_out; (void)dist_out; (void)threads;
+    return -2;
+#endif
+}
+
 ORC_API int orc_bf_xcheck1_f32(const float* Q, int64_t nq, const float* T, int64_t nt, int dim,
                                int order, int32_t* tidx, float* dist, int threads)
 {

@@ -145,6 +145,32 @@ def test_vectorised_baseline_equals_the_faithful_scan():
     same(*far_banks(300, 200, rng))
 
 
+def test_blocked_vnni_baseline_equals_the_faithful_scan():
+    """oracle.bf_xcheck1_blocked (bench.py's third CPU baseline: vpdpbusd on sign-flipped bytes, 64 output rows x 6 candidates
+    per register block, integer pre-test + float32-root compare per lane) returns what the one-pair-at-a-time restatement
+    returns, bit for bit -- sizes around the block edges (64 rows, 6 candidates), dims that are not multiples of 4,
+    duplicates, empty banks, the float32-root tie range, descriptor values 0 and 255 (the sign flip's corners)."""
+    import oracle as orc
+    if not orc.have_vnni():
+        pytest.skip("this host has no AVX-512 VNNI")
+    rng = np.random.default_rng(37)
+
+    def same(Q, T):
+        a, b = orc.bf_xcheck1(Q, T), orc.bf_xcheck1_blocked(Q, T)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    for nq, nt, dim in [(1, 1, 128), (5, 6, 128), (6, 64, 128), (7, 65, 128), (13, 63, 127), (300, 200, 128), (200, 300, 100),
+                        (50, 64, 3), (129, 13, 1), (0, 5, 128), (5, 0, 128), (1000, 700, 128)]:
+        Q = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+        T = rng.integers(0, 256, (nt, dim), dtype=np.uint8)
+        if nq > 20 and nt > 20:
+            T[3] = Q[5]; T[11] = Q[5]; Q[17] = Q[5]
+        same(Q, T)
+    same(*far_banks(300, 200, rng))
+    ext = rng.choice(np.array([0, 255], dtype=np.uint8), size=(90, 128))
+    same(ext, ext[::-1].copy())
+    same(np.full((70, 128), 255, np.uint8), np.zeros((9, 128), np.uint8))       # the largest d2 there is
+
+
 def test_oracle_c_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     """oracle/bfmatch_oracle.c compiled with -fsanitize=address,undefined into tests/tools/oracle_sanitize.c: 600 random
     shapes (0 / 1 rows, k = 2 against one row, dim 1 .. 128, exact-size heap blocks), the four float32 accumulation

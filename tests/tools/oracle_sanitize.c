@@ -1,5 +1,5 @@
 /* ASAN / UBSAN harness for the CPU oracle's C restatement (oracle/bfmatch_oracle.c, compiled into this program): random
- * shapes incl. 0 and 1 rows, k = 2 against one row, dim < 128, the vectorised cross-check against the scalar one, all four
+ * shapes incl. 0 and 1 rows, k = 2 against one row, dim < 128, the vectorised and the blocked (VNNI) cross-checks against the scalar one, all four
  * float32 accumulation orders.  Prints "ok" when no sanitizer report fired and the internal cross-checks held. */
 #include <math.h>
 #include <stdint.h>
@@ -13,6 +13,8 @@ int orc_bf_xcheck1_u8_simd(const uint8_t*, int64_t, const uint8_t*, int64_t, int
 int orc_bf_xcheck1_f32(const float*, int64_t, const float*, int64_t, int, int, int32_t*, float*, int);
 int orc_bf_xcheck1_u8(const uint8_t*, int64_t, const uint8_t*, int64_t, int, int32_t*, float*, int);
 int orc_have_simd(void);
+int orc_bf_xcheck1_u8_blocked(const uint8_t*, int64_t, const uint8_t*, int64_t, int, int32_t*, float*, int);
+int orc_have_vnni(void);
 
 static uint64_t s = 88172645463325252ull;
 static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
@@ -45,6 +47,10 @@ int main(void)
         if (orc_have_simd() && dim == 128) {
             if (orc_bf_xcheck1_u8_simd(Q, nq, T, nt, dim, ti2, td2, thr) != 0) return 2;
             if (memcmp(ti, ti2, sizeof(int32_t) * (size_t)nq) || memcmp(td, td2, sizeof(float) * (size_t)nq)) { printf("simd != scalar\n"); return 1; }
+        }
+        if (orc_have_vnni()) {          /* (every dim: rows are padded to 4-byte groups inside) */
+            if (orc_bf_xcheck1_u8_blocked(Q, nq, T, nt, dim, ti2, td2, thr) != 0) return 2;
+            if (memcmp(ti, ti2, sizeof(int32_t) * (size_t)nq) || memcmp(td, td2, sizeof(float) * (size_t)nq)) { printf("blocked != scalar\n"); return 1; }
         }
         /* cross-check property: a matched query is the reverse nearest neighbour of its train row (ties: an equal distance) */
         for (int64_t q = 0; q < nq; ++q)
