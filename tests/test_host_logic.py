@@ -289,3 +289,39 @@ def test_cell_planner_under_address_and_undefined_behaviour_sanitizers(tmp_path)
                           stderr=subprocess.DEVNULL)
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
+
+
+def test_bench_cpu_baselines_follow_the_containers_cpu_quota(monkeypatch):
+    """bench.py's CPU baselines run on the CPUs the container is GRANTED (r06: the GPU boxes show 256 logical CPUs and
+    grant 16 through cpu.max; 128 threads under that quota were throttled and the line said "cores: 128")."""
+    import builtins
+    import io
+    import bench
+    real_open = builtins.open
+
+    def fake(files):
+        def _open(path, *a, **k):
+            if str(path).startswith("/sys/fs/cgroup/"):
+                if path in files:
+                    return io.StringIO(files[path])
+                raise FileNotFoundError(path)
+            return real_open(path, *a, **k)
+        return _open
+    import oracle
+    limit = min(len(__import__("os").sched_getaffinity(0)), oracle.max_threads())
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    n, quota = bench.host_cpu_allowance()
+    assert quota == 16.0 and n == min(limit, 16)
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "max 100000\n"}))
+    assert bench.host_cpu_allowance() == (limit, None)
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "150000 100000\n"}))          # 1.5 CPUs: one thread
+    assert bench.host_cpu_allowance() == (1, 1.5)
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "400000\n",    # cgroup v1
+                                                "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    n, quota = bench.host_cpu_allowance()
+    assert quota == 4.0 and n == min(limit, 4)
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1\n",
+                                                "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert bench.host_cpu_allowance() == (limit, None)
+    monkeypatch.setattr(builtins, "open", fake({}))
+    assert bench.host_cpu_allowance() == (limit, None)
