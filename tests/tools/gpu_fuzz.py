@@ -63,12 +63,21 @@ def fuzz_operators(rng):
     else:
         qb, tb = ctx.bank(Q), ctx.bank(T)
     order = 1 if kind == "nonint" else 0                 # the device's fixed float32 accumulation order
-    what = rng.choice(["knn2", "xcheck", "accepted", "selfdist", "batch"])
+    what = rng.choice(["knn2", "xcheck", "accepted", "selfdist", "batch", "knnk"])
     tag = (what, kind, Q.shape[0], T.shape[0], str(Q.dtype))
     if what == "knn2":
         idx, d = ctx.knn2(qb, tb)
         oi, od = oracle.bf_knn(Q, T, 2, order=order)
         assert eq(idx, oi) and eq(d, od), tag
+    elif what == "knnk":                                     # r06: fm_knn, the rest of bf_match's signature (k up to 8)
+        k = int(rng.integers(1, 9))
+        nq = min(Q.shape[0], 3000)                           # (the k > 2 kernels run on the vector ALU: keep the problem small)
+        nt = min(T.shape[0], 6000)
+        qs, ts = ctx.bank(Q[:nq]), ctx.bank(T[:nt])
+        idx, d = ctx.knn(qs, ts, k)
+        oi, od = oracle.bf_knn(Q[:nq], T[:nt], k, order=order)
+        assert eq(idx, oi) and eq(d, od), tag + (k,)
+        qs.close(); ts.close()
     elif what == "xcheck":
         for a, b, A, B in ((qb, tb, Q, T), (tb, qb, T, Q)):
             t, x = ctx.xcheck1(a, b)
